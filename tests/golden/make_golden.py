@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE on CPU.
+
+Run only in the build container (``/root/reference`` does not exist on the GPU
+box and nothing under tests/ reads it at test time):
+
+    python tests/golden/make_golden.py
+
+The reference's torch-only modules are imported from ``/root/reference/src``
+(read-only); their parameters are overwritten with the deterministic synthetic
+values of ``tests/synth.py``; inputs come from the same helper.  Only OUTPUTS
+(and a few intermediates) are stored, as float32 ``.npz`` files, so the
+fixtures stay small.  Weights/inputs are regenerated from seeds at test time.
+
+Nothing here is reference source text: the fixtures are data.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))          # tests/ -> synth
+sys.path.insert(0, "/root/reference/src")          # reference flat modules
+
+import synth  # noqa: E402
+
+import attention as ref_attention  # noqa: E402
+import convolution as ref_convolution  # noqa: E402
+import encoder as ref_encoder  # noqa: E402
+import encoder_layer as ref_encoder_layer  # noqa: E402
+import feedforward as ref_feedforward  # noqa: E402
+import utils as ref_utils  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+CFG1 = dict(input_dim=80, kernel_size=15, encoder_dim=144, dropout=0.1, attention_dropout=0.1,
+            pos_enc_dropout=0.1, hidden_dim=576, num_heads=4, encoder_num_layers=2, max_len=5000,
+            use_relative=True)
+CFG2 = dict(input_dim=80, kernel_size=15, encoder_dim=256, dropout=0.1, attention_dropout=0.1,
+            pos_enc_dropout=0.1, hidden_dim=2048, num_heads=4, encoder_num_layers=12, max_len=5000,
+            use_relative=True)
+
+
+def t2n(t):
+    t = t.detach().cpu()
+    if t.dtype == torch.bool:
+        return t.numpy().astype(np.uint8)
+    return t.contiguous().numpy()
+
+
+def save(name, arrays, meta):
+    arrays = dict(arrays)
+    arrays["meta"] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-24s %8.1f KB  %d arrays" % (name, os.path.getsize(path) / 1024.0, len(arrays)))
+
+
+def build_encoder(cfg, wseed, **extra):
+    kw = dict(cfg)
+    kw.update(extra)
+    enc = ref_encoder.ConformerEncoder(cmvn=None, **kw).eval()
+    synth.load_synth_(enc, wseed)
+    return enc
+
+
+def run_encoder(enc, x, lens, keep_layers, **fw):
+    keep = {}
+    hooks = [enc.embed.register_forward_hook(
+        lambda m, i, o: keep.update(embed_out=t2n(o[0]), pos_embed=t2n(o[1])))]
+    for li in keep_layers:
+        hooks.append(enc.encoders[li].register_forward_hook(
+            lambda m, i, o, li=li: keep.update({"layer_out_%d" % li: t2n(o[0])})))
+    with torch.no_grad():
+        y, m = enc(torch.from_numpy(x), torch.tensor(lens, dtype=torch.int32), **fw)
+    for h in hooks:
+        h.remove()
+    keep["y"] = t2n(y)
+    keep["mask"] = t2n(m)
+    return keep
+
+
+def state_manifest(mod):
+    return {k: list(v.shape) for k, v in mod.state_dict().items()}
+
+
+# ----------------------------------------------------------------------------- encoders
+def gen_encoders():
+    # config 1 (BASELINE.json configs[0]): 2-layer d=144 h=4, B=2, T=200
+    x = synth.fbank(21, 2, 200)
+    lens = [200, 163]
+    enc = build_encoder(CFG1, 11)
+    out = run_encoder(enc, x, lens, [0, 1])
+    save("enc_cfg1", out, dict(cfg=CFG1, wseed=11, xseed=21, batch=2, frames=200, lens=lens,
+                               state=state_manifest(enc)))
+
+    # dynamic-chunk training mask (decoding_chunk_size>0) and static chunk mask
+    enc = build_encoder(CFG1, 11, use_dynamic_chunk_size=True)
+    o1 = run_encoder(enc, x, lens, [], decoding_chunk_size=4, num_decoding_chunk_size=2)
+    o2 = run_encoder(enc, x, lens, [], decoding_chunk_size=-1)
+    enc = build_encoder(CFG1, 11, static_chunk_size=3)
+    o3 = run_encoder(enc, x, lens, [])
+    save("enc_cfg1_chunk", dict(y_dyn4_left2=o1["y"], y_dynfull=o2["y"], y_static3=o3["y"], mask=o1["mask"]),
+         dict(cfg=CFG1, wseed=11, xseed=21, batch=2, frames=200, lens=lens))
+
+    # absolute-position variant (use_relative=False): fp16-quantised PE table, plain MHSA
+    cfg = dict(CFG1, use_relative=False)
+    enc = build_encoder(cfg, 13)
+    out = run_encoder(enc, x, lens, [0])
+    save("enc_cfg1_norel", dict(y=out["y"], mask=out["mask"], embed_out=out["embed_out"],
+                                layer_out_0=out["layer_out_0"]),
+         dict(cfg=cfg, wseed=13, xseed=21, batch=2, frames=200, lens=lens, state=state_manifest(enc)))
+
+    # config-2 architecture (12-layer d=256 h=4 ff=2048) on a small ragged batch
+    x2 = synth.fbank(22, 3, 120)
+    lens2 = [120, 97, 64]
+    enc = build_encoder(CFG2, 12)
+    out = run_encoder(enc, x2, lens2, [0, 5, 11])
+    save("enc_cfg2s", out, dict(cfg=CFG2, wseed=12, xseed=22, batch=3, frames=120, lens=lens2))
+
+    # streaming (config 5 semantics at batch 1): chunk=16, left chunks 4 and unbounded
+    enc = build_encoder(CFG1, 11)
+    xs = torch.from_numpy(synth.fbank(23, 1, 331))
+    arrays = {}
+    with torch.no_grad():
+        ys, _ = enc.forward_chunk_by_chunk(xs, 16, 4)
+        yu, _ = enc.forward_chunk_by_chunk(xs, 16, -1)
+        arrays["y_left4"] = t2n(ys)
+        arrays["y_unbounded"] = t2n(yu)
+        # two explicit forward_chunk calls so the caches themselves are pinned
+        empty = torch.zeros((0, 0, 0, 0))
+        c0, a0, n0 = enc.forward_chunk(xs[:, 0:67], 0, 32, empty, empty)
+        c1, a1, n1 = enc.forward_chunk(xs[:, 64:131], 16, 32, a0, n0)
+        c2, a2, n2 = enc.forward_chunk(xs[:, 128:195], 32, 32, a1, n1)
+        arrays.update(chunk0=t2n(c0), chunk1=t2n(c1), chunk2=t2n(c2),
+                      cache0=t2n(a0), cache1=t2n(a1), cache2=t2n(a2))
+        arrays["cnn_cache_shape"] = np.array(list(n2.shape), dtype=np.int64)
+    save("enc_cfg1_stream", arrays, dict(cfg=CFG1, wseed=11, xseed=23, frames=331, chunk=16))
+
+
+# ----------------------------------------------------------------------------- modules
+def gen_modules():
+    D, H, FF, K, B, T = 144, 4, 576, 15, 3, 37
+    arrays = {}
+    lens = [37, 30, 19]
+    pad = ~ref_utils.make_pad_mask(torch.tensor(lens, dtype=torch.int32), T).unsqueeze(1)   # (B,1,T) True=valid
+    chunk = ref_utils.subsequent_chunk_mask(T, 5, 1, torch.device("cpu")).unsqueeze(0) & pad    # (B,T,T)
+    empty_mask = torch.ones((0, 0, 0), dtype=torch.bool)
+    with torch.no_grad():
+        # FFN (swish / relu)
+        x = torch.from_numpy(synth.normal(41, (B, T, D)))
+        m = synth.load_synth_(ref_feedforward.PositionwiseFeedForwardModule(D, 0.1, FF).eval(), 31)
+        arrays["ffn_swish"] = t2n(m(x))
+        m = synth.load_synth_(ref_feedforward.PositionwiseFeedForwardModule(D, 0.1, FF, activation="relu").eval(), 31)
+        arrays["ffn_relu"] = t2n(m(x))
+
+        # positional tables
+        rpe = ref_attention.RelativePositionalEncoding(D, 0.1).eval()
+        ape = ref_attention.PositionalEncoding(D, 0.1).eval()
+        arrays["rel_pe_0_64"] = t2n(rpe.pe[:64, 0])
+        arrays["rel_pe_4990_5000"] = t2n(rpe.pe[4990:5000, 0])
+        arrays["abs_pe_0_64"] = t2n(ape.pe[:64, 0].float())
+        arrays["abs_pe_4990_5000"] = t2n(ape.pe[4990:5000, 0].float())
+        rpe256 = ref_attention.RelativePositionalEncoding(256, 0.0)
+        arrays["rel_pe256_1000_1004"] = t2n(rpe256.pe[1000:1004, 0])
+
+        # relative MHSA: batch-path pos_embed (B,1,D), three mask kinds, then KV-cache path at B=1
+        x = torch.from_numpy(synth.normal(42, (B, T, D)))
+        m = synth.load_synth_(ref_attention.RelativeMultiHeadSelfAttentionModule(D, H, 0.1).eval(), 32)
+        pos_b = rpe.pe[0:B]
+        o, c = m(x, x, x, pad, pos_b)
+        arrays["relmhsa_pad"], arrays["relmhsa_pad_cache"] = t2n(o), t2n(c)
+        o, _ = m(x, x, x, chunk, pos_b)
+        arrays["relmhsa_chunk"] = t2n(o)
+        arrays["relmhsa_chunk_fullmasked_rows"] = t2n((chunk.sum(-1) == 0))
+        o, _ = m(x, x, x, empty_mask, pos_b)
+        arrays["relmhsa_nomask"] = t2n(o)
+        cache = torch.from_numpy(synth.normal(46, (1, H, 20, 2 * (D // H))))
+        pos_s = rpe.pe[5:5 + 20 + T]
+        o, c = m(x[:1], x[:1], x[:1], empty_mask, pos_s, cache)
+        arrays["relmhsa_stream"], arrays["relmhsa_stream_cache"] = t2n(o), t2n(c)
+
+        # plain MHSA (use_relative=False variant)
+        m = synth.load_synth_(ref_attention.MultiHeadSelfAttentionModule(D, H, 0.1).eval(), 36)
+        o, c = m(x, x, x, pad)
+        arrays["mhsa_pad"], arrays["mhsa_pad_cache"] = t2n(o), t2n(c)
+        o, c = m(x[:1], x[:1], x[:1], empty_mask, None, cache)
+        arrays["mhsa_stream"], arrays["mhsa_stream_cache"] = t2n(o), t2n(c)
+
+        # convolution module (note Q1: third ctor arg lands in the `bias` slot)
+        x = torch.from_numpy(synth.normal(43, (B, T, D)))
+        m = synth.load_synth_(ref_convolution.ConvolutionModule(D, K, FF).eval(), 33)
+        o, c = m(x, pad)
+        arrays["conv_pad"] = t2n(o)
+        arrays["conv_cache_shape"] = np.array(list(c.shape), dtype=np.int64)
+        o, _ = m(x, empty_mask)
+        arrays["conv_nomask"] = t2n(o)
+
+        # subsampling front-end
+        xf = torch.from_numpy(synth.fbank(44, 3, 83))
+        lf = [83, 60, 7]
+        padf = ~ref_utils.make_pad_mask(torch.tensor(lf, dtype=torch.int32), 83).unsqueeze(1)
+        m = synth.load_synth_(ref_convolution.ConvolutionSubSampling(80, D, ref_attention.RelativePositionalEncoding(D, 0.1)).eval(), 34)
+        o, p, mk = m(xf, padf)
+        arrays["sub_out"], arrays["sub_pos"], arrays["sub_mask"] = t2n(o), t2n(p), t2n(mk)
+        o, p, mk = m(xf, padf, 5)
+        arrays["sub_pos_off5"] = t2n(p)
+        arrays["sub_position_encoding_7_9"] = t2n(m.position_encoding(7, 9))
+
+        # one full encoder layer
+        x = torch.from_numpy(synth.normal(45, (B, T, D)))
+        m = synth.load_synth_(ref_encoder_layer.ConformerEncoderLayer(D, K, 0.1, 0.1, FF, H, True).eval(), 35)
+        o, mk, ac, cc = m(x, pad, pos_b, pad)
+        arrays["layer_out"], arrays["layer_attn_cache"] = t2n(o), t2n(ac)
+        arrays["layer_manifest"] = np.frombuffer(json.dumps(state_manifest(m), sort_keys=True).encode(), dtype=np.uint8)
+    save("mods_d144", arrays, dict(D=D, H=H, FF=FF, K=K, B=B, T=T, lens=lens, sub_lens=lf,
+                                   seeds=dict(ffn=(31, 41), relmhsa=(32, 42), cache=46, mhsa=36, conv=(33, 43),
+                                              sub=(34, 44), layer=(35, 45))))
+
+
+# ----------------------------------------------------------------------------- masks (bit-exact path)
+def gen_masks():
+    arrays = {}
+    dev = torch.device("cpu")
+    lens = torch.tensor([5, 0, 9, 3], dtype=torch.int32)
+    arrays["pad_5_0_9_3__9"] = t2n(ref_utils.make_pad_mask(lens, 9))
+    for size, c, left in [(17, 4, -1), (17, 4, 2), (16, 16, 0), (9, 1, 0), (9, 3, 1), (5, 8, -1), (49, 4, 2), (1, 1, 0)]:
+        arrays["chunk_%d_%d_%d" % (size, c, left)] = np.packbits(t2n(ref_utils.subsequent_chunk_mask(size, c, left, dev)))
+    # subsampled length rule: for every raw length L in 0..320 on a T=320 utterance, the number of valid
+    # frames that survive mask[:, :, 2::2][:, :, 2::2]; and T' for every T in 7..320 from the conv shapes
+    T = 320
+    pm = ~ref_utils.make_pad_mask(torch.arange(0, T + 1, dtype=torch.int32), T).unsqueeze(1)
+    sub = pm[:, :, 2::2][:, :, 2::2]
+    arrays["sub_valid_count_T320"] = sub.sum(-1).squeeze(1).numpy().astype(np.int64)
+    arrays["sub_mask_T320_packed"] = np.packbits(t2n(sub))
+    arrays["sub_mask_T320_shape"] = np.array(list(sub.shape), dtype=np.int64)
+    tprime = []
+    conv = torch.nn.Sequential(torch.nn.Conv2d(1, 1, 3, 2), torch.nn.Conv2d(1, 1, 3, 2))
+    with torch.no_grad():
+        for t in range(7, T + 1):
+            tprime.append(conv(torch.zeros(1, 1, t, 80)).shape[2])
+    arrays["tprime_T7_320"] = np.array(tprime, dtype=np.int64)
+    # make_attn_mask selector (deterministic branches only)
+    x = torch.zeros(2, 13, 4)
+    pad = ~ref_utils.make_pad_mask(torch.tensor([13, 8], dtype=torch.int32), 13).unsqueeze(1)
+    arrays["attn_dyn_full"] = t2n(ref_utils.make_attn_mask(x, pad, True, False, -1, -1, -1))
+    arrays["attn_dyn_c3_l1"] = t2n(ref_utils.make_attn_mask(x, pad, True, False, 3, -1, 1))
+    arrays["attn_static_c4"] = t2n(ref_utils.make_attn_mask(x, pad, False, False, 0, 4, -1))
+    arrays["attn_static_c4_l0"] = t2n(ref_utils.make_attn_mask(x, pad, False, False, 0, 4, 0))
+    arrays["attn_none"] = t2n(ref_utils.make_attn_mask(x, pad, False, False, 0, -1, -1))
+    save("masks", arrays, dict(note="bool arrays stored as uint8 or np.packbits"))
+
+
+if __name__ == "__main__":
+    gen_masks()
+    gen_modules()
+    gen_encoders()
