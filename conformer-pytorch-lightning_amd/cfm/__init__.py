@@ -1,0 +1,189 @@
+"""cfm -- ctypes binding of libconformer_gfx950.so (the C ABI declared in include/cfm.h).
+
+This is plumbing only: it turns torch tensors that already live on an MI355X into raw device
+pointers + sizes, passes the current HIP stream, and converts negative status codes into
+``RuntimeError`` carrying ``cfm_last_error()``.  There is NO CPU fallback and no other backend: if the
+shared library is missing, or a tensor is not on a HIP device, every entry point raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libconformer_gfx950.so")
+
+F32, BF16, F16 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GLU = 0, 1, 2, 3
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+
+c_p = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int32
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", c_p), ("W", c_p), ("W_lo", c_p), ("bias", c_p), ("residual", c_p), ("row_mask", c_p), ("C", c_p),
+                ("lda", c_i64), ("ldc", c_i64), ("ldr", c_i64),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("a_dtype", c_i32), ("w_dtype", c_i32), ("c_dtype", c_i32),
+                ("act", c_i32), ("alpha", ctypes.c_float),
+                ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
+                ("tile", c_i32), ("mask_mode", c_i32)]
+
+
+class AttnDesc(ctypes.Structure):
+    _fields_ = [("q", c_p), ("k", c_p), ("v", c_p), ("p", c_p), ("bias_u", c_p), ("bias_v", c_p), ("mask", c_p), ("out", c_p),
+                ("q_sb", c_i64), ("q_st", c_i64), ("k_sb", c_i64), ("k_st", c_i64), ("k_sh", c_i64),
+                ("v_sb", c_i64), ("v_st", c_i64), ("v_sh", c_i64), ("p_sb", c_i64), ("p_st", c_i64),
+                ("m_sb", c_i64), ("m_sq", c_i64),
+                ("B", c_i32), ("H", c_i32), ("Tq", c_i32), ("Tk", c_i32), ("dk", c_i32),
+                ("q_dtype", c_i32), ("kv_dtype", c_i32), ("p_dtype", c_i32), ("out_dtype", c_i32), ("mma_dtype", c_i32),
+                ("split", c_i32), ("scale", ctypes.c_float)]
+
+
+_LAYER_W_FIELDS = [
+    "ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "ln_conv_b", "ln_ff_g", "ln_ff_b", "ln_final_g", "ln_final_b",
+    "ffm_w1", "ffm_w1_lo", "ffm_w2", "ffm_w2_lo", "ffm_b1", "ffm_b2",
+    "ff_w1", "ff_w1_lo", "ff_w2", "ff_w2_lo", "ff_b1", "ff_b2",
+    "qkv_w", "qkv_w_lo", "pos_w", "pos_w_lo", "out_w", "out_w_lo", "qkv_b", "out_b", "bias_u", "bias_v",
+    "pw1_w", "pw1_w_lo", "pw2_w", "pw2_w_lo", "pw1_b", "pw2_b", "dw_w", "dw_b", "bn_scale", "bn_shift"]
+
+
+class LayerWeights(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in _LAYER_W_FIELDS]
+
+
+class LayerScratch(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw")]
+
+
+class LayerIO(ctypes.Structure):
+    _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("FF", c_i32), ("ktaps", c_i32),
+                ("act_dtype", c_i32), ("w_dtype", c_i32),
+                ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64),
+                ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32),
+                ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded shared library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libconformer_gfx950.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C conformer-pytorch-lightning_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.cfm_version.restype = ctypes.c_int
+        L.cfm_last_error.restype = ctypes.c_char_p
+        L.cfm_device_ok.restype = ctypes.c_int
+        L.cfm_gemm.argtypes = [ctypes.POINTER(GemmDesc), c_p]
+        L.cfm_attention.argtypes = [ctypes.POINTER(AttnDesc), c_p]
+        L.cfm_layernorm.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, ctypes.c_float, c_i64, c_i32, c_p]
+        L.cfm_kv_cache_pack.argtypes = [c_p, c_i32, c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_dwconv_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_conv1_relu.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_valid_mask.argtypes = [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_chunk_mask.argtypes = [c_p, c_i32, c_i32, c_i32, c_p]
+        L.cfm_attn_mask.argtypes = [c_p, c_p, c_p, c_i32, c_i32, c_p]
+        L.cfm_cast.argtypes = [c_p, c_i32, c_p, c_i32, c_i64, c_p]
+        L.cfm_add_rows.argtypes = [c_p, c_p, c_i64, c_i32, c_i32, c_p]
+        L.cfm_encoder_layer_forward.argtypes = [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerScratch),
+                                                ctypes.POINTER(LayerIO), c_p, c_p, c_i32, c_p, c_p, c_p]
+        L.cfm_prof_enable.argtypes = [c_i32]
+        L.cfm_prof_enable.restype = None
+        L.cfm_prof_reset.restype = None
+        L.cfm_prof_collect.restype = ctypes.c_int
+        L.cfm_prof_entry.argtypes = [c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        for name in ("cfm_gemm", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu",
+                     "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
+                     "cfm_encoder_layer_forward", "cfm_prof_entry"):
+            getattr(L, name).restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (status %d): %s" % (what, rc, lib().cfm_last_error().decode(errors="replace")))
+
+
+def dt_code(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise TypeError("cfm: unsupported dtype %s (float32, bfloat16, float16 only)" % (t.dtype if isinstance(t, torch.Tensor) else t))
+
+
+def torch_dtype(code):
+    return _TORCH_DT[code]
+
+
+def require_hip(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("cfm: tensor on %s -- this framework runs on MI355X (HIP) only; there is no CPU path" % t.device)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# precision modes
+# ----------------------------------------------------------------------------------------------------------------------
+class Precision:
+    """How the dense contractions are evaluated.
+
+    bf16 : bf16 MFMA operands, f32 accumulate, bf16 intermediates, f32 residual stream (BASELINE.json config 2)
+    fp16 : same speed, fp16 operands (11-bit mantissa)
+    fp32 : "f32-accurate": f32 intermediates, every product as 3 bf16 MFMAs on hi/lo splits (~16 mantissa bits)
+    """
+
+    def __init__(self, name):
+        if name not in ("bf16", "fp16", "fp32"):
+            raise ValueError("precision must be bf16, fp16 or fp32, got %r" % (name,))
+        self.name = name
+        self.split = name == "fp32"
+        self.w_code = F16 if name == "fp16" else BF16
+        self.act_code = F32 if self.split else self.w_code
+        self.w_dtype = torch_dtype(self.w_code)
+        self.act_dtype = torch_dtype(self.act_code)
+
+    def __repr__(self):
+        return "Precision(%s)" % self.name
+
+
+_precision = Precision(os.environ.get("CFM_PRECISION", "bf16"))
+
+
+def set_precision(name):
+    global _precision
+    _precision = name if isinstance(name, Precision) else Precision(name)
+    return _precision
+
+
+def get_precision():
+    return _precision
+
+
+from .ops import *  # noqa: E402,F401,F403

@@ -1,0 +1,162 @@
+"""Device-side weight packing for the HIP kernels.
+
+The nn.Modules keep the reference's parameter names / shapes / dtypes (so state_dicts, optimizers and DDP see what they
+expect); the kernels want: 16-bit (or hi/lo bf16 split) [N,K] matrices, a fused QKV matrix, the pointwise-conv-1
+rows interleaved for the in-register GLU, BatchNorm folded to scale/shift, conv kernels reordered to the implicit-GEMM K
+order.  A pack is rebuilt only when a source tensor's version counter / storage / device changes or the precision mode
+changes (in-place optimizer steps bump ``_version``).
+"""
+import torch
+
+import cfm as _c
+
+
+def _key(tensors, prec):
+    return (prec.name,) + tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in tensors if t is not None)
+
+
+class Packed:
+    """Attribute bag of packed tensors (keeps them alive while raw pointers are in flight)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class PackCache:
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, tensors, prec, build):
+        k = _key(tensors, prec)
+        if k != self._key:
+            with torch.no_grad():
+                self._val = build()
+            self._key = k
+        return self._val
+
+
+def f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def matrix(w, prec):
+    """[N,K] float weight -> (W16, W_lo|None)."""
+    w32 = w.detach().to(torch.float32)
+    if prec.split:
+        hi = w32.to(torch.bfloat16)
+        lo = (w32 - hi.to(torch.float32)).to(torch.bfloat16)
+        return hi.contiguous(), lo.contiguous()
+    return w32.to(prec.w_dtype).contiguous(), None
+
+
+def glu_interleave_index(D, device):
+    """GEMM column blk*32 + half*16 + i  takes weight row  half*D + blk*16 + i  (see gemm.hip epilogue)."""
+    idx = torch.arange(2 * D, device=device)
+    return ((idx % 32) // 16) * D + (idx // 32) * 16 + (idx % 16)
+
+
+def pack_ffn(mod, prec):
+    def build():
+        w1, w1l = matrix(mod.w_1.weight, prec)
+        w2, w2l = matrix(mod.w_2.weight, prec)
+        return Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias))
+    return mod._pack.get([mod.w_1.weight, mod.w_1.bias, mod.w_2.weight, mod.w_2.bias], prec, build)
+
+
+def pack_mhsa(mod, prec, relative):
+    srcs = [mod.linear_q.weight, mod.linear_q.bias, mod.linear_k.weight, mod.linear_k.bias, mod.linear_v.weight,
+            mod.linear_v.bias, mod.linear_out.weight, mod.linear_out.bias]
+    if relative:
+        srcs += [mod.linear_pos.weight, mod.pos_bias_u, mod.pos_bias_v]
+
+    def build():
+        qkv, qkvl = matrix(torch.cat([mod.linear_q.weight, mod.linear_k.weight, mod.linear_v.weight], 0), prec)
+        out, outl = matrix(mod.linear_out.weight, prec)
+        p = Packed(qkv_w=qkv, qkv_w_lo=qkvl, qkv_b=f32(torch.cat([mod.linear_q.bias, mod.linear_k.bias, mod.linear_v.bias], 0)),
+                   out_w=out, out_w_lo=outl, out_b=f32(mod.linear_out.bias), pos_w=None, pos_w_lo=None, bias_u=None, bias_v=None)
+        D = mod.linear_q.weight.shape[0]
+        # row views of the fused matrix for the non-self-attention call pattern (query/key/value differ)
+        p.q_w, p.k_w, p.v_w = qkv[:D], qkv[D:2 * D], qkv[2 * D:]
+        p.q_w_lo, p.k_w_lo, p.v_w_lo = (None, None, None) if qkvl is None else (qkvl[:D], qkvl[D:2 * D], qkvl[2 * D:])
+        p.q_b, p.k_b, p.v_b = p.qkv_b[:D], p.qkv_b[D:2 * D], p.qkv_b[2 * D:]
+        if relative:
+            p.pos_w, p.pos_w_lo = matrix(mod.linear_pos.weight, prec)
+            p.bias_u, p.bias_v = f32(mod.pos_bias_u), f32(mod.pos_bias_v)
+        return p
+    return mod._pack.get(srcs, prec, build)
+
+
+def pack_conv_module(mod, prec):
+    bn = mod.norm
+    srcs = [mod.pointwise_conv1.weight, mod.pointwise_conv1.bias, mod.depthwise_conv.weight, mod.depthwise_conv.bias, bn.weight,
+            bn.bias, bn.running_mean, bn.running_var, mod.pointwise_conv2.weight, mod.pointwise_conv2.bias]
+
+    def build():
+        D = mod.pointwise_conv2.weight.shape[0]
+        dev = mod.pointwise_conv2.weight.device
+        idx = glu_interleave_index(D, dev)
+        w1 = mod.pointwise_conv1.weight.detach()[:, :, 0]
+        b1 = mod.pointwise_conv1.bias.detach() if mod.pointwise_conv1.bias is not None else torch.zeros(2 * D, device=dev)
+        pw1, pw1l = matrix(w1[idx], prec)
+        pw2, pw2l = matrix(mod.pointwise_conv2.weight.detach()[:, :, 0], prec)
+        dwb = mod.depthwise_conv.bias.detach() if mod.depthwise_conv.bias is not None else torch.zeros(D, device=dev)
+        # BatchNorm1d (eval): y = (x - mean) / sqrt(var + eps) * gamma + beta   ->   x * scale + shift
+        gamma = bn.weight.detach().float() if bn.weight is not None else torch.ones(D, device=dev)
+        beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros(D, device=dev)
+        scale = gamma / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        shift = beta - bn.running_mean.detach().float() * scale
+        return Packed(pw1_w=pw1, pw1_w_lo=pw1l, pw1_b=f32(b1[idx]), pw2_w=pw2, pw2_w_lo=pw2l, pw2_b=f32(mod.pointwise_conv2.bias),
+                      dw_w=f32(mod.depthwise_conv.weight.detach()[:, 0, :]), dw_b=f32(dwb), bn_scale=f32(scale), bn_shift=f32(shift))
+    return mod._pack.get(srcs, prec, build)
+
+
+def pack_subsampling(mod, prec):
+    c1, c2, lin = mod.conv[0], mod.conv[2], mod.out[0]
+    srcs = [c1.weight, c1.bias, c2.weight, c2.bias, lin.weight, lin.bias]
+
+    def build():
+        C = c1.weight.shape[0]
+        w1 = f32(c1.weight.detach().reshape(C, 9).t())                               # [9, C] tap-major
+        w2, w2l = matrix(c2.weight.detach().permute(0, 2, 3, 1).reshape(C, 9 * C), prec)   # [co][kt][kf][ci]
+        Dout, CF = lin.weight.shape
+        Fp = CF // C
+        # reference feature order is c*F'+f (convolution.py:74); the implicit GEMM writes [.., f, c]
+        wl, wll = matrix(lin.weight.detach().reshape(Dout, C, Fp).permute(0, 2, 1).reshape(Dout, Fp * C), prec)
+        return Packed(w1=w1, b1=f32(c1.bias), w2=w2, w2_lo=w2l, b2=f32(c2.bias), wl=wl, wl_lo=wll, bl=f32(lin.bias), C=C, Fp=Fp)
+    return mod._pack.get(srcs, prec, build)
+
+
+def layer_weight_struct(layer, prec):
+    """cfm.LayerWeights for one ConformerEncoderLayer (+ the Packed objects it points into)."""
+    relative = layer.use_relative
+    ffm = pack_ffn(layer.feed_forward_macaron, prec)
+    ff = pack_ffn(layer.feed_forward, prec)
+    att = pack_mhsa(layer.self_attn, prec, relative)
+    cv = pack_conv_module(layer.conv_module, prec)
+    norms = {}
+    for short, name in (("ffm", "norm_ff_macaron"), ("mha", "norm_mha"), ("conv", "norm_conv"), ("ff", "norm_ff"), ("final", "norm_final")):
+        ln = getattr(layer, name)
+        norms[short] = (ln.weight.detach(), ln.bias.detach())
+    for g, b in norms.values():
+        if g.dtype != torch.float32 or not g.is_contiguous() or not b.is_contiguous():
+            raise TypeError("LayerNorm parameters must be contiguous float32")
+    w = _c.LayerWeights()
+    for short, (g, b) in norms.items():
+        setattr(w, "ln_%s_g" % short, g.data_ptr())
+        setattr(w, "ln_%s_b" % short, b.data_ptr())
+    for pre, pk in (("ffm", ffm), ("ff", ff)):
+        setattr(w, pre + "_w1", pk.w1.data_ptr())
+        setattr(w, pre + "_w1_lo", _c.ptr(pk.w1_lo))
+        setattr(w, pre + "_w2", pk.w2.data_ptr())
+        setattr(w, pre + "_w2_lo", _c.ptr(pk.w2_lo))
+        setattr(w, pre + "_b1", pk.b1.data_ptr())
+        setattr(w, pre + "_b2", pk.b2.data_ptr())
+    w.qkv_w, w.qkv_w_lo, w.qkv_b = att.qkv_w.data_ptr(), _c.ptr(att.qkv_w_lo), att.qkv_b.data_ptr()
+    w.pos_w, w.pos_w_lo = _c.ptr(att.pos_w), _c.ptr(att.pos_w_lo)
+    w.out_w, w.out_w_lo, w.out_b = att.out_w.data_ptr(), _c.ptr(att.out_w_lo), att.out_b.data_ptr()
+    w.bias_u, w.bias_v = _c.ptr(att.bias_u), _c.ptr(att.bias_v)
+    w.pw1_w, w.pw1_w_lo, w.pw1_b = cv.pw1_w.data_ptr(), _c.ptr(cv.pw1_w_lo), cv.pw1_b.data_ptr()
+    w.pw2_w, w.pw2_w_lo, w.pw2_b = cv.pw2_w.data_ptr(), _c.ptr(cv.pw2_w_lo), cv.pw2_b.data_ptr()
+    w.dw_w, w.dw_b, w.bn_scale, w.bn_shift = cv.dw_w.data_ptr(), cv.dw_b.data_ptr(), cv.bn_scale.data_ptr(), cv.bn_shift.data_ptr()
+    return w, (ffm, ff, att, cv, norms)

@@ -1,0 +1,334 @@
+// attention.hip -- fused (relative-position) multi-head self-attention for gfx950.
+//
+//   out[b,i,h,:] = softmax_j( scale * ((q_i+u_h).k_j + (q_i+v_h).p_{b,j}) ) . v_j      (attention.py:81-96)
+//
+// with the reference's masking rule (masked score = -inf, fully masked row -> zero context) and its
+// un-shifted positional term (p_{b,j} is one broadcast row in the batch path, an absolute
+// position-by-key table in the streaming path).  Nothing of size Tq x Tk ever reaches HBM: scores,
+// probabilities and the running max/sum live in registers (online softmax over 64-key tiles).
+//
+// Work split: one 256-thread workgroup per (batch, head, 64-query tile); each of its 4 wavefronts
+// owns 16 queries.  Both MFMA products are evaluated in SWAPPED orientation,
+//     S^T[key, q] = K~[key, :] . Q~[q, :]^T          O^T[d, q] = V^T[d, key] . P^T[key, q]
+// so that a lane always owns ONE query column (q = lane & 15): the row max / row sum reductions are
+// 15 register ops + 2 shuffles, the O rescale is lane-local, and P goes from the S accumulators into
+// the next MFMA's B operand with no LDS round trip (the k-order inside a 32-key step is permuted the
+// same way on the V^T fragment).  K~ / P~ tiles are staged row-major + XOR swizzle (ds_read_b128,
+// conflict-free); V is staged transposed with a padded row stride (ds_read_b64, conflict-free).
+//
+// SPLIT evaluates every product as hi*hi + lo*hi + hi*lo on bf16 hi/lo planes (f32-accurate mode).
+#include "cfm_common.h"
+
+struct AttnArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* p;
+    const float* bias_u;
+    const float* bias_v;
+    const uint8_t* mask;
+    void* out;
+    int64_t q_sb, q_st, k_sb, k_st, k_sh, v_sb, v_st, v_sh, p_sb, p_st, m_sb, m_sq;
+    int B, H, Tq, Tk, dk;
+    int q_dtype, kv_dtype, p_dtype, out_dtype;
+    float scale;
+};
+
+namespace {
+
+constexpr int QT = 64;    // queries per workgroup
+constexpr int KT = 64;    // keys per tile
+constexpr int DKP = 64;   // padded head dim
+constexpr int VSTR = 68;  // V^T row stride in 16-bit elements (136 B: conflict-free ds_read_b64)
+
+// 8 consecutive elements starting at element offset `off`, as f32; elements >= nvalid read as 0.
+__device__ __forceinline__ void load8f(const void* base, int dt, int64_t off, int nvalid, float (&o)[8]) {
+    if (nvalid >= 8 && dt == CFM_F32 && (off & 3) == 0) {
+        const f32x4 a = *(const f32x4*)((const float*)base + off);
+        const f32x4 b = *(const f32x4*)((const float*)base + off + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+        return;
+    }
+    if (nvalid >= 8 && dt != CFM_F32 && (off & 7) == 0) {
+        const u32x4 r = *(const u32x4*)((const u16*)base + off);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u16 lo = (u16)(w[i] & 0xffffu), hi = (u16)(w[i] >> 16);
+            o[2 * i] = dt == CFM_BF16 ? BF16::to_f32(lo) : F16::to_f32(lo);
+            o[2 * i + 1] = dt == CFM_BF16 ? BF16::to_f32(hi) : F16::to_f32(hi);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = i < nvalid ? load_as_f32(base, off + i, dt) : 0.f;
+}
+
+template <typename HT, bool SPLIT>
+__device__ __forceinline__ void pack_planes(const float (&f)[8], u32x4& hi, u32x4& lo) {
+    const f32x4 a = {f[0], f[1], f[2], f[3]}, b = {f[4], f[5], f[6], f[7]};
+    if constexpr (SPLIT) {
+        split8(a, b, hi, lo);
+    } else {
+        hi = pack8<HT>(a, b);
+        lo = hi;
+    }
+}
+
+__device__ __forceinline__ int k_swz(int row, int c) { return row * 8 + (c ^ ((row >> 1) & 7)); }
+
+template <typename HT, bool HAS_POS, bool SPLIT>
+__global__ __launch_bounds__(256) void cfm_attn_kernel(const AttnArgs a) {
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int KS_PLANE = KT * 8;                // u32x4 per K~ plane
+    constexpr int VT_PLANE = DKP * VSTR;            // u16 per V^T plane
+    __shared__ u32x4 Ks[KS_PLANE * NPL];
+    __shared__ u32x4 Ps[HAS_POS ? KS_PLANE * NPL : 1];
+    __shared__ __attribute__((aligned(16))) u16 Vt[VT_PLANE * NPL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qi = blockIdx.x * QT + wave * 16 + (lane & 15);
+    const int qc = qi < a.Tq ? qi : a.Tq - 1;  // clamped for loads; stores are predicated on qi
+    const int dk = a.dk;
+
+    // ---- Q~ fragments (B operand of S^T = K~ . Q~^T): lane holds q=lane&15, d = kk*32 + g*8 + j ----
+    u32x4 qu[2], qul[2], qv[HAS_POS ? 2 : 1], qvl[HAS_POS ? 2 : 1];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int d0 = kk * 32 + g * 8;
+        float f[8], fu[8], fv[8];
+        load8f(a.q, a.q_dtype, (int64_t)b * a.q_sb + (int64_t)qc * a.q_st + h * dk + d0, dk - d0, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = d0 + j < dk;
+            fu[j] = f[j] + ((ok && a.bias_u) ? a.bias_u[h * dk + d0 + j] : 0.f);
+            if constexpr (HAS_POS) fv[j] = f[j] + ((ok && a.bias_v) ? a.bias_v[h * dk + d0 + j] : 0.f);
+        }
+        pack_planes<HT, SPLIT>(fu, qu[kk], qul[kk]);
+        if constexpr (HAS_POS) pack_planes<HT, SPLIT>(fv, qv[kk], qvl[kk]);
+    }
+
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (a.Tk + KT - 1) / KT;
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * KT;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K~ (and P~) rows, V transposed ---------------------------------------------
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int id = pss * 256 + tid;
+            const int key = id >> 3, c = id & 7;
+            const int kj = k0 + key;
+            const int d0 = c * 8;
+            const int nv = kj < a.Tk ? dk - d0 : 0;
+            float f[8];
+            u32x4 hi, lo;
+            load8f(a.k, a.kv_dtype, (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)(kj < a.Tk ? kj : 0) * a.k_st + d0, nv, f);
+            pack_planes<HT, SPLIT>(f, hi, lo);
+            Ks[k_swz(key, c)] = hi;
+            if constexpr (SPLIT) Ks[KS_PLANE + k_swz(key, c)] = lo;
+            if constexpr (HAS_POS) {
+                load8f(a.p, a.p_dtype, (int64_t)b * a.p_sb + (int64_t)(kj < a.Tk ? kj : 0) * a.p_st + h * dk + d0, nv, f);
+                pack_planes<HT, SPLIT>(f, hi, lo);
+                Ps[k_swz(key, c)] = hi;
+                if constexpr (SPLIT) Ps[KS_PLANE + k_swz(key, c)] = lo;
+            }
+            load8f(a.v, a.kv_dtype, (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + (int64_t)(kj < a.Tk ? kj : 0) * a.v_st + d0, nv, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (SPLIT) {
+                    const u16 hb = BF16::from_f32(f[j]);
+                    Vt[(d0 + j) * VSTR + key] = hb;
+                    Vt[VT_PLANE + (d0 + j) * VSTR + key] = BF16::from_f32(f[j] - BF16::to_f32(hb));
+                } else {
+                    Vt[(d0 + j) * VSTR + key] = HT::from_f32(f[j]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T tile: 4 key fragments of 16 ---------------------------------------------------
+        f32x4 s[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int idx = k_swz(f * 16 + (lane & 15), kk * 4 + g);
+                const u32x4 kf = Ks[idx];
+                if constexpr (SPLIT) {
+                    s[f] = HT::mfma(kf, qul[kk], s[f]);
+                    s[f] = HT::mfma(Ks[KS_PLANE + idx], qu[kk], s[f]);
+                }
+                s[f] = HT::mfma(kf, qu[kk], s[f]);
+                if constexpr (HAS_POS) {
+                    const u32x4 pf = Ps[idx];
+                    if constexpr (SPLIT) {
+                        s[f] = HT::mfma(pf, qvl[kk], s[f]);
+                        s[f] = HT::mfma(Ps[KS_PLANE + idx], qv[kk], s[f]);
+                    }
+                    s[f] = HT::mfma(pf, qv[kk], s[f]);
+                }
+            }
+        }
+        // ---- scale, mask, online softmax (lane owns query qi; keys k0 + f*16 + g*4 + r) ---------
+        float tmax = -INFINITY;
+        float sv[4][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kj = k0 + f * 16 + g * 4 + r;
+                bool ok = kj < a.Tk;
+                if (ok && a.mask) ok = a.mask[(int64_t)b * a.m_sb + (int64_t)qc * a.m_sq + kj] != 0;
+                const float x = ok ? s[f][r] * a.scale : -INFINITY;
+                sv[f][r] = x;
+                tmax = fmaxf(tmax, x);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        float alpha = 1.f;
+        if (m_new != -INFINITY) alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (m_new == -INFINITY) ? 0.f : __expf(sv[f][r] - m_new);
+                sv[f][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_o[i] *= alpha;
+
+        // ---- O^T += V^T . P^T over the tile's two 32-key steps ------------------------------------
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            float pf[8] = {sv[2 * k2][0], sv[2 * k2][1], sv[2 * k2][2], sv[2 * k2][3],
+                           sv[2 * k2 + 1][0], sv[2 * k2 + 1][1], sv[2 * k2 + 1][2], sv[2 * k2 + 1][3]};
+            u32x4 ph, pl;
+            pack_planes<HT, SPLIT>(pf, ph, pl);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                const int d = fd * 16 + (lane & 15);
+                const int o0 = d * VSTR + (2 * k2) * 16 + g * 4;
+                const u32x2 v0 = *(const u32x2*)(Vt + o0);
+                const u32x2 v1 = *(const u32x2*)(Vt + o0 + 16);
+                const u32x4 vf = {v0.x, v0.y, v1.x, v1.y};
+                if constexpr (SPLIT) {
+                    const u32x2 w0 = *(const u32x2*)(Vt + VT_PLANE + o0);
+                    const u32x2 w1 = *(const u32x2*)(Vt + VT_PLANE + o0 + 16);
+                    const u32x4 vl = {w0.x, w0.y, w1.x, w1.y};
+                    acc_o[fd] = HT::mfma(vf, pl, acc_o[fd]);
+                    acc_o[fd] = HT::mfma(vl, ph, acc_o[fd]);
+                }
+                acc_o[fd] = HT::mfma(vf, ph, acc_o[fd]);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane holds O[q=qi][d = fd*16 + g*4 + r] --------------------------------
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;  // fully masked row -> zeros (attention.py:92)
+    if (qi < a.Tq) {
+        const int64_t ob = ((int64_t)b * a.Tq + qi) * ((int64_t)a.H * dk) + (int64_t)h * dk;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            const int d = fd * 16 + g * 4;
+            if (d >= dk) continue;  // dk % 4 == 0: the 4 columns are valid together
+            const f32x4 o = acc_o[fd] * inv;
+            if (a.out_dtype == CFM_F32)
+                *(f32x4*)((float*)a.out + ob + d) = o;
+            else if (a.out_dtype == CFM_BF16)
+                *(u32x2*)((u16*)a.out + ob + d) = (u32x2){pack2<BF16>(o.x, o.y), pack2<BF16>(o.z, o.w)};
+            else
+                *(u32x2*)((u16*)a.out + ob + d) = (u32x2){pack2<F16>(o.x, o.y), pack2<F16>(o.z, o.w)};
+        }
+    }
+}
+
+// new_cache[b,h,t,:] = [K_t | V_t]  (f32), rows t < Tc from the old cache, the rest from the new k/v.
+__global__ void cfm_kv_pack_kernel(const float* old_cache, int Tc, const void* k, const void* v, int dt, int64_t k_sb,
+                                   int64_t k_st, int64_t v_sb, int64_t v_st, float* out, int B, int H, int Tn, int dk) {
+    const int Tk = Tc + Tn;
+    const int64_t n = (int64_t)B * H * Tk * 2 * dk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % (2 * dk));
+        int64_t r = i / (2 * dk);
+        const int t = (int)(r % Tk);
+        r /= Tk;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        float val;
+        if (t < Tc) {
+            val = old_cache[(((int64_t)b * H + h) * Tc + t) * (2 * dk) + e];
+        } else if (e < dk) {
+            val = load_as_f32(k, (int64_t)b * k_sb + (int64_t)(t - Tc) * k_st + h * dk + e, dt);
+        } else {
+            val = load_as_f32(v, (int64_t)b * v_sb + (int64_t)(t - Tc) * v_st + h * dk + (e - dk), dt);
+        }
+        out[i] = val;
+    }
+}
+
+template <typename HT, bool SPLIT>
+int launch_attn(const AttnArgs& a, bool has_pos, hipStream_t s, const char* name) {
+    const dim3 grid((a.Tq + QT - 1) / QT, a.H, a.B), block(256);
+    const double flops = 4.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
+    const double bytes = 2.0 * a.B * a.H * ((double)a.Tq * 2 + (double)a.Tk * 2) * a.dk;
+    CfmProfScope prof(name, s, flops, bytes);
+    if (has_pos)
+        hipLaunchKernelGGL((cfm_attn_kernel<HT, true, SPLIT>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((cfm_attn_kernel<HT, false, SPLIT>), grid, block, 0, s, a);
+    return cfm_launch_status(name);
+}
+
+}  // namespace
+
+extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
+    CFM_CHECK_ARG(d && d->q && d->k && d->v && d->out, "cfm_attention: null pointer");
+    CFM_CHECK_ARG(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "cfm_attention: empty problem");
+    CFM_CHECK_ARG(d->dk > 0 && d->dk <= DKP && d->dk % 4 == 0, "cfm_attention: need dk %% 4 == 0 and dk <= 64 (dk=%d)", d->dk);
+    CFM_CHECK_ARG(d->B <= 65535 && d->H <= 65535, "cfm_attention: B,H must fit a grid dimension");
+    CFM_CHECK_ARG(d->mma_dtype == CFM_BF16 || d->mma_dtype == CFM_F16, "cfm_attention: mma_dtype must be bf16 or fp16");
+    CFM_CHECK_ARG(!d->split || d->mma_dtype == CFM_BF16, "cfm_attention: split mode uses bf16 planes");
+    CFM_CHECK_ARG(!d->p || (d->bias_u && d->bias_v), "cfm_attention: positional term needs bias_u and bias_v");
+    AttnArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.p = d->p; a.bias_u = d->p ? d->bias_u : nullptr; a.bias_v = d->p ? d->bias_v : nullptr;
+    a.mask = d->mask; a.out = d->out;
+    a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.k_sh = d->k_sh;
+    a.v_sb = d->v_sb; a.v_st = d->v_st; a.v_sh = d->v_sh; a.p_sb = d->p_sb; a.p_st = d->p_st; a.m_sb = d->m_sb; a.m_sq = d->m_sq;
+    a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk; a.dk = d->dk;
+    a.q_dtype = d->q_dtype; a.kv_dtype = d->kv_dtype; a.p_dtype = d->p_dtype; a.out_dtype = d->out_dtype; a.scale = d->scale;
+    hipStream_t s = (hipStream_t)stream;
+    const bool pos = d->p != nullptr;
+    if (d->split) return launch_attn<BF16, true>(a, pos, s, pos ? "attn_rel_bf16x3" : "attn_bf16x3");
+    if (d->mma_dtype == CFM_BF16) return launch_attn<BF16, false>(a, pos, s, pos ? "attn_rel_bf16" : "attn_bf16");
+    return launch_attn<F16, false>(a, pos, s, pos ? "attn_rel_f16" : "attn_f16");
+}
+
+extern "C" int cfm_kv_cache_pack(const float* old_cache, int32_t Tc, const void* k, const void* v, int32_t kv_dtype,
+                                 int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, float* new_cache, int32_t B,
+                                 int32_t H, int32_t Tn, int32_t dk, cfm_stream_t stream) {
+    CFM_CHECK_ARG(k && v && new_cache, "cfm_kv_cache_pack: null pointer");
+    CFM_CHECK_ARG(Tc == 0 || old_cache, "cfm_kv_cache_pack: cache_T > 0 needs old_cache");
+    CFM_CHECK_ARG(B > 0 && H > 0 && Tn > 0 && dk > 0 && Tc >= 0, "cfm_kv_cache_pack: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * H * (Tc + Tn) * 2 * dk;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    CfmProfScope prof("kv_cache_pack", s, 0.0, (double)n * 8);
+    hipLaunchKernelGGL(cfm_kv_pack_kernel, dim3(blocks), dim3(256), 0, s, old_cache, Tc, k, v, kv_dtype, k_sb, k_st, v_sb, v_st,
+                       new_cache, B, H, Tn, dk);
+    return cfm_launch_status("cfm_kv_cache_pack");
+}

@@ -1,0 +1,124 @@
+// cfm_common.h -- shared device/host helpers for libconformer_gfx950 (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cfm.h"
+
+// ---------------------------------------------------------------------------------------------
+// host side: error text + launch check + profiling hooks (abi.cpp)
+// ---------------------------------------------------------------------------------------------
+int cfm_fail(int code, const char* fmt, ...);
+
+struct CfmProfScope {  // brackets one kernel launch with events when profiling is on
+    CfmProfScope(const char* name, hipStream_t s, double flops, double bytes);
+    ~CfmProfScope();
+    void* rec;
+    hipStream_t stream;
+};
+
+#define CFM_CHECK_ARG(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) return cfm_fail(CFM_ERR_ARG, __VA_ARGS__);    \
+    } while (0)
+
+static inline int cfm_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cfm_fail(CFM_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return CFM_OK;
+}
+
+static inline int cfm_elt_size(int dt) { return dt == CFM_F32 ? 4 : 2; }
+static inline bool cfm_is16(int dt) { return dt == CFM_BF16 || dt == CFM_F16; }
+
+// ---------------------------------------------------------------------------------------------
+// device side: 16-bit operand types.  A wavefront is 64 lanes on gfx950; every constant below
+// assumes that.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+struct BF16 {
+    static constexpr int kId = CFM_BF16;
+    typedef bf16x8_t frag;
+    static __device__ __forceinline__ float to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
+    static __device__ __forceinline__ u16 from_f32(float f) {
+        __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        return __builtin_bit_cast(u16, b);
+    }
+    static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c,
+                                                        0, 0, 0);
+    }
+};
+
+struct F16 {
+    static constexpr int kId = CFM_F16;
+    typedef f16x8_t frag;
+    static __device__ __forceinline__ float to_f32(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ u16 from_f32(float f) {
+        _Float16 h = (_Float16)f;
+        return __builtin_bit_cast(u16, h);
+    }
+    static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c,
+                                                       0, 0, 0);
+    }
+};
+
+template <typename HT>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)HT::from_f32(lo) | ((unsigned)HT::from_f32(hi) << 16);
+}
+
+// 8 consecutive f32 -> one 16-byte fragment of 16-bit values
+template <typename HT>
+__device__ __forceinline__ u32x4 pack8(const f32x4& a, const f32x4& b) {
+    u32x4 r;
+    r.x = pack2<HT>(a.x, a.y);
+    r.y = pack2<HT>(a.z, a.w);
+    r.z = pack2<HT>(b.x, b.y);
+    r.w = pack2<HT>(b.z, b.w);
+    return r;
+}
+
+// hi/lo bf16 split of 8 f32 values:  x ~= hi + lo  with ~16 mantissa bits
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u16 hb = BF16::from_f32(v[i]);
+        float r = v[i] - BF16::to_f32(hb);
+        h[i] = hb;
+        l[i] = BF16::from_f32(r);
+    }
+    hi = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    lo = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+
+// generic scalar load/store by runtime dtype (slow paths, edges)
+__device__ __forceinline__ float load_as_f32(const void* p, int64_t i, int dt) {
+    if (dt == CFM_F32) return ((const float*)p)[i];
+    u16 v = ((const u16*)p)[i];
+    return dt == CFM_BF16 ? BF16::to_f32(v) : F16::to_f32(v);
+}
+__device__ __forceinline__ void store_from_f32(void* p, int64_t i, int dt, float v) {
+    if (dt == CFM_F32)
+        ((float*)p)[i] = v;
+    else
+        ((u16*)p)[i] = dt == CFM_BF16 ? BF16::from_f32(v) : F16::from_f32(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

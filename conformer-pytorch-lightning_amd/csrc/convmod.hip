@@ -1,0 +1,222 @@
+// convmod.hip -- the HBM-bound middle of the convolution module and the front-end's first conv.
+//
+//  cfm_dwconv_bn_silu : depthwise k-tap FIR along time on a channels-last [B,T,D] activation, folded
+//                       BatchNorm(eval) affine, SiLU  (convolution.py:43-45).  The GLU in front of it
+//                       is the epilogue of the pointwise-conv-1 GEMM, so the chain GLU->dw->BN->SiLU
+//                       costs one read and one write of [B,T,D].
+//                       A lane owns 2 adjacent channels (coalesced 256 B per wavefront per frame) and a
+//                       32-frame segment; the 32+k-1 input frames are loaded up front (all loads in
+//                       flight together) and the FIR runs out of registers.
+//  cfm_conv1_relu     : Conv2d(1,C,3,stride 2)+ReLU of the fbank image (convolution.py:60-61), written
+//                       channels-last [B,T1,F1,C] so that the second conv is an implicit GEMM whose
+//                       A fragments are contiguous 16-byte loads.
+#include "cfm_common.h"
+
+namespace {
+
+constexpr int TSEG = 32;
+
+template <int KTAPS, bool IN_F32>
+__global__ __launch_bounds__(256) void cfm_dwconv_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ dwb, const float* __restrict__ sc,
+                                                         const float* __restrict__ sh, void* __restrict__ y, int x_dt, int y_dt,
+                                                         int T, int D) {
+    constexpr int HALF = (KTAPS - 1) / 2;
+    constexpr int NIN = TSEG + KTAPS - 1;
+    const int pairs = D >> 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int pr = idx % pairs;
+    const int seg = idx / pairs;
+    const int t0 = seg * TSEG;
+    if (t0 >= T) return;
+    const int b = blockIdx.y;
+    const int c = pr * 2;
+    const int64_t base = (int64_t)b * T * D + c;
+
+    float xin0[NIN], xin1[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int t = t0 - HALF + i;
+        float a0 = 0.f, a1 = 0.f;
+        if (t >= 0 && t < T) {
+            if constexpr (IN_F32) {
+                const float2 v = *(const float2*)((const float*)x + base + (int64_t)t * D);
+                a0 = v.x;
+                a1 = v.y;
+            } else {
+                const unsigned v = *(const unsigned*)((const u16*)x + base + (int64_t)t * D);
+                const u16 lo = (u16)(v & 0xffffu), hi = (u16)(v >> 16);
+                a0 = x_dt == CFM_BF16 ? BF16::to_f32(lo) : F16::to_f32(lo);
+                a1 = x_dt == CFM_BF16 ? BF16::to_f32(hi) : F16::to_f32(hi);
+            }
+        }
+        xin0[i] = a0;
+        xin1[i] = a1;
+    }
+    float w0[KTAPS], w1[KTAPS];
+#pragma unroll
+    for (int k = 0; k < KTAPS; ++k) {
+        w0[k] = w[(int64_t)c * KTAPS + k];
+        w1[k] = w[(int64_t)(c + 1) * KTAPS + k];
+    }
+    const float b0 = dwb[c], b1 = dwb[c + 1], s0 = sc[c], s1 = sc[c + 1], h0 = sh[c], h1 = sh[c + 1];
+#pragma unroll
+    for (int i = 0; i < TSEG; ++i) {
+        const int t = t0 + i;
+        if (t >= T) break;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KTAPS; ++k) {
+            a0 = fmaf(w0[k], xin0[i + k], a0);
+            a1 = fmaf(w1[k], xin1[i + k], a1);
+        }
+        a0 = siluf_((a0 + b0) * s0 + h0);
+        a1 = siluf_((a1 + b1) * s1 + h1);
+        const int64_t o = base + (int64_t)t * D;
+        if (y_dt == CFM_F32)
+            *(float2*)((float*)y + o) = make_float2(a0, a1);
+        else if (y_dt == CFM_BF16)
+            *(unsigned*)((u16*)y + o) = pack2<BF16>(a0, a1);
+        else
+            *(unsigned*)((u16*)y + o) = pack2<F16>(a0, a1);
+    }
+}
+
+// generic tap count (no register window): re-reads inputs through L1/L2
+__global__ __launch_bounds__(256) void cfm_dwconv_generic_kernel(const void* x, const float* w, const float* dwb, const float* sc,
+                                                                 const float* sh, void* y, int x_dt, int y_dt, int T, int D,
+                                                                 int ktaps) {
+    const int64_t n = (int64_t)T * D;
+    const int b = blockIdx.y;
+    const int half = (ktaps - 1) / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % D);
+        const int t = (int)(i / D);
+        float a = 0.f;
+        for (int k = 0; k < ktaps; ++k) {
+            const int tt = t + k - half;
+            if (tt >= 0 && tt < T) a = fmaf(w[(int64_t)c * ktaps + k], load_as_f32(x, ((int64_t)b * T + tt) * D + c, x_dt), a);
+        }
+        a = siluf_((a + dwb[c]) * sc[c] + sh[c]);
+        store_from_f32(y, (int64_t)b * n + i, y_dt, a);
+    }
+}
+
+// one thread: 8 output channels of one (b,t1,f1) position
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void cfm_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, void* __restrict__ y, int y_dt, int B,
+                                                        int T, int F, int T1, int F1, int C) {
+    const int c8n = C >> 3;
+    const int64_t total = (int64_t)B * T1 * F1 * c8n;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int c0 = (int)(id % c8n) * 8;
+    int64_t pos = id / c8n;
+    const int f1 = (int)(pos % F1);
+    pos /= F1;
+    const int t1 = (int)(pos % T1);
+    const int b = (int)(pos / T1);
+    f32x4 a0 = *(const f32x4*)(bias + c0), a1 = *(const f32x4*)(bias + c0 + 4);
+    const float* xp = x + ((int64_t)b * T + 2 * t1) * F + 2 * f1;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) {
+            const float xv = xp[kt * F + kf];
+            const float* wp = w + (kt * 3 + kf) * C + c0;
+            a0 += xv * *(const f32x4*)wp;
+            a1 += xv * *(const f32x4*)(wp + 4);
+        }
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    a0 = __builtin_elementwise_max(a0, z);
+    a1 = __builtin_elementwise_max(a1, z);
+    const int64_t o = (((int64_t)b * T1 + t1) * F1 + f1) * C + c0;
+    if constexpr (OUT_F32) {
+        *(f32x4*)((float*)y + o) = a0;
+        *(f32x4*)((float*)y + o + 4) = a1;
+    } else {
+        *(u32x4*)((u16*)y + o) = y_dt == CFM_BF16 ? pack8<BF16>(a0, a1) : pack8<F16>(a0, a1);
+    }
+}
+
+__global__ void cfm_cast_kernel(const void* src, int sdt, void* dst, int ddt, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        store_from_f32(dst, i, ddt, load_as_f32(src, i, sdt));
+}
+
+__global__ void cfm_add_rows_kernel(float* x, const float* add, int64_t n4, int D4, int group) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D4;
+        const int c = (int)(i % D4);
+        f32x4* px = (f32x4*)x + i;
+        *px = *px + *((const f32x4*)add + (r / group) * D4 + c);
+    }
+}
+
+}  // namespace
+
+extern "C" int cfm_add_rows(float* x, const float* add, int64_t rows, int32_t D, int32_t group, cfm_stream_t stream) {
+    CFM_CHECK_ARG(x && add && rows > 0 && D > 0 && D % 4 == 0 && group > 0, "cfm_add_rows: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = rows * (D / 4);
+    int64_t nb = (n4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    CfmProfScope prof("add_rows", s, 0.0, (double)rows * D * 8);
+    hipLaunchKernelGGL(cfm_add_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, add, n4, D / 4, group);
+    return cfm_launch_status("cfm_add_rows");
+}
+
+extern "C" int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, const float* dw_bias, const float* bn_scale,
+                                  const float* bn_shift, void* y, int y_dtype, int32_t B, int32_t T, int32_t D, int32_t ktaps,
+                                  cfm_stream_t stream) {
+    CFM_CHECK_ARG(x && w && dw_bias && bn_scale && bn_shift && y, "cfm_dwconv_bn_silu: null pointer");
+    CFM_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 2 == 0 && B <= 65535, "cfm_dwconv_bn_silu: bad shape B=%d T=%d D=%d", B, T, D);
+    CFM_CHECK_ARG(ktaps > 0 && ktaps % 2 == 1, "cfm_dwconv_bn_silu: tap count must be odd (got %d)", ktaps);
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = (double)B * T * D * (cfm_elt_size(x_dtype) + cfm_elt_size(y_dtype));
+    CfmProfScope prof("dwconv_bn_silu", s, 2.0 * B * T * (double)D * ktaps, bytes);
+    if (ktaps == 15) {
+        const int segs = (T + TSEG - 1) / TSEG;
+        const dim3 grid((unsigned)(((int64_t)segs * (D / 2) + 255) / 256), B), block(256);
+        if (x_dtype == CFM_F32)
+            hipLaunchKernelGGL((cfm_dwconv_kernel<15, true>), grid, block, 0, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype,
+                               y_dtype, T, D);
+        else
+            hipLaunchKernelGGL((cfm_dwconv_kernel<15, false>), grid, block, 0, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype,
+                               y_dtype, T, D);
+    } else {
+        int64_t nb = ((int64_t)T * D + 255) / 256;
+        if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(cfm_dwconv_generic_kernel, dim3((unsigned)nb, B), dim3(256), 0, s, x, w, dw_bias, bn_scale, bn_shift, y,
+                           x_dtype, y_dtype, T, D, ktaps);
+    }
+    return cfm_launch_status("cfm_dwconv_bn_silu");
+}
+
+extern "C" int cfm_conv1_relu(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B, int32_t T,
+                              int32_t F, int32_t C, cfm_stream_t stream) {
+    CFM_CHECK_ARG(x && w && bias && y, "cfm_conv1_relu: null pointer");
+    CFM_CHECK_ARG(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 8 == 0, "cfm_conv1_relu: bad shape B=%d T=%d F=%d C=%d", B, T, F, C);
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const int64_t total = (int64_t)B * T1 * F1 * (C / 8);
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = (double)B * T * F * 4 + (double)total * 8 * cfm_elt_size(y_dtype);
+    CfmProfScope prof("conv1_relu", s, 2.0 * 9 * (double)total * 8, bytes);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (y_dtype == CFM_F32)
+        hipLaunchKernelGGL((cfm_conv1_kernel<true>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
+    else
+        hipLaunchKernelGGL((cfm_conv1_kernel<false>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
+    return cfm_launch_status("cfm_conv1_relu");
+}
+
+extern "C" int cfm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, cfm_stream_t stream) {
+    CFM_CHECK_ARG(src && dst && n > 0, "cfm_cast: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    CfmProfScope prof("cast", s, 0.0, (double)n * (cfm_elt_size(src_dtype) + cfm_elt_size(dst_dtype)));
+    hipLaunchKernelGGL(cfm_cast_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, src_dtype, dst, dst_dtype, n);
+    return cfm_launch_status("cfm_cast");
+}

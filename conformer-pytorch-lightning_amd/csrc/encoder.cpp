@@ -1,0 +1,120 @@
+// encoder.cpp -- composite: one conformer block enqueued from C++ (17 launches, no host sync).
+//
+// Mirrors reference src/encoder_layer.py:49-71:
+//   x = x + 1/2 FFNm(LN(x)); x = x + MHSA(LN(x)); x = x + Conv(LN(x)); x = x + 1/2 FFN(LN(x)); out = LN(x)
+// with every residual add, bias, activation, GLU and padding mask folded into a GEMM epilogue and the
+// residual stream kept in f32.  Layer norms write the GEMM operand dtype directly.
+#include <math.h>
+
+#include "cfm_common.h"
+
+namespace {
+
+inline const void* eoff(const void* p, int64_t elems, int dt) { return (const char*)p + elems * cfm_elt_size(dt); }
+
+struct Ctx {
+    const cfm_layer_io* io;
+    int M, D, FF, act_dt, w_dt;
+    bool split;
+    cfm_stream_t st;
+};
+
+int gemm(const Ctx& c, const void* A, int a_dt, int64_t lda, const void* W, const void* Wlo, const float* bias, void* C, int c_dt,
+         int64_t ldc, int M, int N, int K, int act, const float* res, float alpha, const uint8_t* row_mask) {
+    cfm_gemm_desc d = {};
+    d.A = A; d.W = W; d.W_lo = c.split ? Wlo : nullptr; d.bias = bias; d.residual = res; d.row_mask = row_mask; d.C = C;
+    d.lda = lda; d.ldc = ldc; d.ldr = ldc; d.M = M; d.N = N; d.K = K;
+    d.a_dtype = a_dt; d.w_dtype = c.w_dt; d.c_dtype = c_dt; d.act = act; d.alpha = alpha;
+    if (c.split && !Wlo) return cfm_fail(CFM_ERR_ARG, "encoder layer: split mode needs the *_lo weight planes");
+    return cfm_gemm(&d, c.st);
+}
+
+#define CFM_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != CFM_OK) return rc__; \
+    } while (0)
+
+}  // namespace
+
+extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_layer_scratch* s, const cfm_layer_io* io,
+                                         const float* x_in, float* x_out, int xn_ready, const float* next_g,
+                                         const float* next_b, cfm_stream_t stream) {
+    CFM_CHECK_ARG(w && s && io && x_in && x_out, "cfm_encoder_layer_forward: null pointer");
+    CFM_CHECK_ARG(io->B > 0 && io->T > 0 && io->D > 0 && io->H > 0 && io->D % io->H == 0 && io->FF > 0,
+                  "cfm_encoder_layer_forward: bad dims B=%d T=%d D=%d H=%d FF=%d", io->B, io->T, io->D, io->H, io->FF);
+    CFM_CHECK_ARG(io->D % 16 == 0, "cfm_encoder_layer_forward: D must be a multiple of 16 (GLU interleave)");
+    CFM_CHECK_ARG(x_in != x_out, "cfm_encoder_layer_forward: x_in and x_out must differ (inputs are not mutated)");
+    Ctx c;
+    c.io = io; c.M = io->B * io->T; c.D = io->D; c.FF = io->FF; c.act_dt = io->act_dtype; c.w_dt = io->w_dtype;
+    c.split = io->act_dtype == CFM_F32;
+    c.st = stream;
+    const int M = c.M, D = c.D, FF = c.FF, H = io->H, dk = D / H, adt = c.act_dt;
+    const float eps = 1e-5f;
+    const bool has_pos = io->pos_rows > 0 && w->pos_w;
+    const int Tc = io->attn_cache ? io->cache_T : 0;
+    const int Tk = Tc + io->T;
+    int P = 0;
+    if (has_pos) {
+        CFM_CHECK_ARG(io->pos_embed && io->pos_rows % io->B == 0, "encoder layer: pos_embed rows (%d) must be a multiple of B (%d)",
+                      io->pos_rows, io->B);
+        P = io->pos_rows / io->B;
+        CFM_CHECK_ARG(P == 1 || P == Tk, "encoder layer: pos_embed gives %d rows per item, need 1 or Tk=%d (attention.py:78-88)", P, Tk);
+    }
+    CFM_CHECK_ARG(Tc == 0 || io->new_cache, "encoder layer: a KV cache input needs new_cache storage");
+
+    // (1) macaron feed-forward: x1 = x + 1/2 W2 silu(W1 LN(x))
+    if (!xn_ready) CFM_TRY(cfm_layernorm(x_in, w->ln_ffm_g, w->ln_ffm_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
+    CFM_TRY(gemm(c, s->xn, adt, D, w->ffm_w1, w->ffm_w1_lo, w->ffm_b1, s->hid, adt, FF, M, FF, D, CFM_ACT_SILU, nullptr, 0.f, nullptr));
+    CFM_TRY(gemm(c, s->hid, adt, FF, w->ffm_w2, w->ffm_w2_lo, w->ffm_b2, x_out, CFM_F32, D, M, D, FF, CFM_ACT_NONE, x_in, 0.5f, nullptr));
+
+    // (2) self-attention
+    CFM_TRY(cfm_layernorm(x_out, w->ln_mha_g, w->ln_mha_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
+    CFM_TRY(gemm(c, s->xn, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, s->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr));
+    if (has_pos)
+        CFM_TRY(gemm(c, io->pos_embed, CFM_F32, D, w->pos_w, w->pos_w_lo, nullptr, s->pos, adt, D, io->pos_rows, D, D, CFM_ACT_NONE,
+                     nullptr, 0.f, nullptr));
+    const void* kq = eoff(s->qkv, D, adt);
+    const void* vq = eoff(s->qkv, 2 * D, adt);
+    const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
+    if (io->new_cache)
+        CFM_TRY(cfm_kv_cache_pack(io->attn_cache, Tc, kq, vq, adt, sb, stt, sb, stt, io->new_cache, io->B, H, io->T, dk, stream));
+    cfm_attn_desc a = {};
+    a.q = s->qkv; a.q_sb = sb; a.q_st = stt; a.q_dtype = adt;
+    if (Tc > 0) {  // keys/values = [cache | new], already concatenated in new_cache (f32)
+        a.k = io->new_cache; a.v = io->new_cache + dk; a.kv_dtype = CFM_F32;
+        a.k_sb = a.v_sb = (int64_t)H * Tk * 2 * dk; a.k_sh = a.v_sh = (int64_t)Tk * 2 * dk; a.k_st = a.v_st = 2 * dk;
+    } else {
+        a.k = kq; a.v = vq; a.kv_dtype = adt;
+        a.k_sb = a.v_sb = sb; a.k_sh = a.v_sh = dk; a.k_st = a.v_st = stt;
+    }
+    if (has_pos) {
+        a.p = s->pos; a.p_dtype = adt; a.p_sb = (int64_t)P * D; a.p_st = P == 1 ? 0 : D;
+        a.bias_u = w->bias_u; a.bias_v = w->bias_v;
+    }
+    a.mask = io->attn_mask; a.m_sb = io->am_sb; a.m_sq = io->am_sq;
+    a.out = s->ctx; a.out_dtype = adt;
+    a.B = io->B; a.H = H; a.Tq = io->T; a.Tk = Tk; a.dk = dk;
+    a.mma_dtype = c.w_dt; a.split = c.split ? 1 : 0;
+    a.scale = 1.0f / sqrtf((float)dk);
+    CFM_TRY(cfm_attention(&a, stream));
+    CFM_TRY(gemm(c, s->ctx, adt, D, w->out_w, w->out_w_lo, w->out_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, nullptr));
+
+    // (3) convolution module: mask -> pw1+GLU -> depthwise+BN+SiLU -> pw2 -> mask
+    CFM_TRY(cfm_layernorm(x_out, w->ln_conv_g, w->ln_conv_b, nullptr, 0, nullptr, nullptr, s->xn, adt, io->pad_valid, eps, M, D, stream));
+    CFM_TRY(gemm(c, s->xn, adt, D, w->pw1_w, w->pw1_w_lo, w->pw1_b, s->glu, adt, D, M, 2 * D, D, CFM_ACT_GLU, nullptr, 0.f, nullptr));
+    CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+    CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, io->pad_valid));
+
+    // (4) feed-forward
+    CFM_TRY(cfm_layernorm(x_out, w->ln_ff_g, w->ln_ff_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
+    CFM_TRY(gemm(c, s->xn, adt, D, w->ff_w1, w->ff_w1_lo, w->ff_b1, s->hid, adt, FF, M, FF, D, CFM_ACT_SILU, nullptr, 0.f, nullptr));
+    CFM_TRY(gemm(c, s->hid, adt, FF, w->ff_w2, w->ff_w2_lo, w->ff_b2, x_out, CFM_F32, D, M, D, FF, CFM_ACT_NONE, x_out, 0.5f, nullptr));
+
+    // (5) norm_final in place (+ the next block's first norm chained in registers)
+    if (next_g)
+        CFM_TRY(cfm_layernorm(x_out, w->ln_final_g, w->ln_final_b, x_out, CFM_F32, next_g, next_b, s->xn, adt, nullptr, eps, M, D, stream));
+    else
+        CFM_TRY(cfm_layernorm(x_out, w->ln_final_g, w->ln_final_b, x_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, eps, M, D, stream));
+    return CFM_OK;
+}

@@ -1,0 +1,348 @@
+// gemm.hip -- C = epilogue(A[M,K] . W[N,K]^T) on gfx950 MFMA (v_mfma_f32_16x16x32_{bf16,f16}).
+//
+// One kernel template serves every dense contraction of the conformer block:
+//   FFN w_1/w_2, fused QKV, linear_pos, linear_out, pointwise conv 1/2, front-end linear, and the
+//   front-end Conv2d(D,D,3,stride 2) as an implicit GEMM over a channels-last image (CONV).
+//
+// Structure (256 threads = 4 wavefronts of 64 lanes, 2x2 over the BMxBN tile):
+//   * both operands are K-contiguous ([M,K] activations, [N,K] nn.Linear weights), staged
+//     global -> registers -> LDS in 16-byte chunks, two LDS buffers, one barrier per K tile; the
+//     global loads of tile t+1 are issued before the MFMAs of tile t (async-STAGE split).
+//   * LDS rows are XOR-swizzled so that the ds_read_b128 fragment reads are bank-conflict free.
+//   * MFMA operand roles are SWAPPED: the weight fragment is the A operand, the activation fragment
+//     the B operand, so a lane's 4 accumulator registers are 4 CONSECUTIVE OUTPUT COLUMNS of one row:
+//     bias / residual loads and the output store are 8- or 16-byte vector accesses.
+//   * SPLIT: activations (f32 in HBM) are split into bf16 hi+lo on the way into LDS, weights come as
+//     hi/lo planes, 3 MFMAs per fragment pair (hi*lo + lo*hi + hi*hi): ~16 mantissa bits.
+//   * every edge is predicated: rows clamp on load / predicate on store, K tail chunks load zeros.
+#include <string>
+
+#include "cfm_common.h"
+
+struct GemmArgs {
+    const void* A;
+    const u16* W;
+    const u16* Wlo;
+    const float* bias;
+    const float* res;
+    const uint8_t* mask;
+    void* C;
+    int64_t lda, ldc, ldr;
+    int M, N, K;
+    int c_dtype, act, mask_mode;
+    float alpha;
+    int convC, T1, F1, T2, F2;
+};
+
+template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV>
+__global__ __launch_bounds__(256) void cfm_gemm_kernel(const GemmArgs g) {
+    constexpr int CPR = BK / 8;      // 16-byte chunks per LDS row
+    constexpr int RPP = 256 / CPR;   // tile rows staged per pass of the 256 threads
+    constexpr int ACH = BM / RPP;    // chunks per thread, activation tile
+    constexpr int WCH = BN / RPP;    // chunks per thread, weight tile
+    constexpr int FM = BM / 32;      // 16-row fragments per wave along M
+    constexpr int FN = BN / 32;      // 16-col fragments per wave along N
+    constexpr int RPB = 16 / CPR;    // LDS rows per 256-byte bank row
+    constexpr int A_PLANE = BM * CPR;
+    constexpr int W_PLANE = BN * CPR;
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int BUF = (A_PLANE + W_PLANE) * NPL;
+    static_assert(!SPLIT || A_F32, "split mode reads f32 activations");
+    static_assert(ACH >= 1 && WCH >= 1 && (FN % 2) == 0, "tile shape");
+    __shared__ u32x4 smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM;
+    const int n0 = (blockIdx.x % tiles_n) * BN;
+
+    auto lds_idx = [](int row, int c) { return row * CPR + (c ^ ((row / RPB) % CPR)); };
+
+    // ---- per-thread staging addresses -------------------------------------------------------
+    const int kc = tid % CPR;
+    const int rl = tid / CPR;
+    int64_t a_off[ACH], w_off[WCH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        int m = m0 + i * RPP + rl;
+        m = m < g.M ? m : g.M - 1;
+        if constexpr (CONV) {
+            const int per_b = g.T2 * g.F2;
+            const int b = m / per_b;
+            const int rem = m - b * per_b;
+            const int t2 = rem / g.F2;
+            const int f2 = rem - t2 * g.F2;
+            a_off[i] = (((int64_t)b * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.convC;
+        } else {
+            a_off[i] = (int64_t)m * g.lda;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+        int n = n0 + j * RPP + rl;
+        n = n < g.N ? n : g.N - 1;
+        w_off[j] = (int64_t)n * g.K;
+    }
+
+    u32x4 ra[A_F32 ? 1 : ACH];
+    f32x4 fa[A_F32 ? ACH : 1][2];
+    u32x4 rw[WCH];
+    u32x4 rwl[SPLIT ? WCH : 1];
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK + kc * 8;
+        const bool kv = k0 < g.K;
+        int64_t koff = k0;
+        if constexpr (CONV) {
+            const int tap = k0 / g.convC;
+            const int ci = k0 - tap * g.convC;
+            const int k3 = tap / 3;
+            const int f3 = tap - 3 * k3;
+            koff = ((int64_t)k3 * g.F1 + f3) * g.convC + ci;
+        }
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            if constexpr (A_F32) {
+                const f32x4* p = (const f32x4*)((const float*)g.A + a_off[i] + koff);
+                fa[i][0] = kv ? p[0] : zf;
+                fa[i][1] = kv ? p[1] : zf;
+            } else {
+                ra[i] = kv ? *(const u32x4*)((const u16*)g.A + a_off[i] + koff) : z4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {
+            rw[j] = kv ? *(const u32x4*)(g.W + w_off[j] + k0) : z4;
+            if constexpr (SPLIT) rwl[j] = kv ? *(const u32x4*)(g.Wlo + w_off[j] + k0) : z4;
+        }
+    };
+
+    auto lstore = [&](int buf) {
+        u32x4* As = smem + buf * BUF;
+        u32x4* Ws = As + A_PLANE * NPL;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int idx = lds_idx(i * RPP + rl, kc);
+            if constexpr (SPLIT) {
+                u32x4 hi, lo;
+                split8(fa[i][0], fa[i][1], hi, lo);
+                As[idx] = hi;
+                As[A_PLANE + idx] = lo;
+            } else if constexpr (A_F32) {
+                As[idx] = pack8<HT>(fa[i][0], fa[i][1]);
+            } else {
+                As[idx] = ra[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {
+            const int idx = lds_idx(j * RPP + rl, kc);
+            Ws[idx] = rw[j];
+            if constexpr (SPLIT) Ws[W_PLANE + idx] = rwl[j];
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const u32x4* As = smem + buf * BUF;
+        const u32x4* Ws = As + A_PLANE * NPL;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            const int c = kk * 4 + (lane >> 4);
+            u32x4 af[FM], wf[FN];
+            u32x4 afl[SPLIT ? FM : 1], wfl[SPLIT ? FN : 1];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int idx = lds_idx(wr * (BM / 2) + i * 16 + (lane & 15), c);
+                af[i] = As[idx];
+                if constexpr (SPLIT) afl[i] = As[A_PLANE + idx];
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int idx = lds_idx(wc * (BN / 2) + j * 16 + (lane & 15), c);
+                wf[j] = Ws[idx];
+                if constexpr (SPLIT) wfl[j] = Ws[W_PLANE + idx];
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (SPLIT) {
+                        acc[i][j] = HT::mfma(wf[j], afl[i], acc[i][j]);
+                        acc[i][j] = HT::mfma(wfl[j], af[i], acc[i][j]);
+                    }
+                    acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+                }
+        }
+    };
+
+    // ---- main loop ----------------------------------------------------------------------------
+    const int nkt = (g.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) gload(kt + 1);
+        compute(kt & 1);
+        if (more) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    const bool glu = g.act == CFM_ACT_GLU;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
+        if (row >= g.M) continue;
+        const bool keep = g.mask ? (g.mask[row] != 0) : true;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if (glu && (j & 1)) continue;
+            const int cb = n0 + wc * (BN / 2) + j * 16;  // first GEMM column of this fragment
+            const int col = cb + (lane >> 4) * 4;
+            if (col >= g.N) continue;
+            const bool in_dead = !keep && g.mask_mode == 1;  // masked INPUT row: x.W = 0, bias/act still apply
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (in_dead) v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (g.bias) {
+                const f32x4 b = *(const f32x4*)(g.bias + col);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            int ocol = col;
+            if (glu) {
+                const int jn = (j + 1 < FN) ? j + 1 : j;  // FN is even; keeps the index static
+                float gt[4] = {acc[i][jn][0], acc[i][jn][1], acc[i][jn][2], acc[i][jn][3]};
+                if (in_dead) gt[0] = gt[1] = gt[2] = gt[3] = 0.f;
+                if (g.bias) {
+                    const f32x4 b = *(const f32x4*)(g.bias + col + 16);
+                    gt[0] += b.x; gt[1] += b.y; gt[2] += b.z; gt[3] += b.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= sigmoidf_(gt[r]);
+                ocol = (cb >> 1) + (lane >> 4) * 4;
+            } else if (g.act == CFM_ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = siluf_(v[r]);
+            } else if (g.act == CFM_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (!keep && g.mask_mode == 0) v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (g.res) {
+                const f32x4 rr = *(const f32x4*)(g.res + (int64_t)row * g.ldr + ocol);
+                v[0] = rr.x + g.alpha * v[0];
+                v[1] = rr.y + g.alpha * v[1];
+                v[2] = rr.z + g.alpha * v[2];
+                v[3] = rr.w + g.alpha * v[3];
+            }
+            const int64_t o = (int64_t)row * g.ldc + ocol;
+            if (g.c_dtype == CFM_F32) {
+                *(f32x4*)((float*)g.C + o) = (f32x4){v[0], v[1], v[2], v[3]};
+            } else if (g.c_dtype == CFM_BF16) {
+                *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])};
+            } else {
+                *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3])};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host dispatch
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV>
+int launch(const GemmArgs& a, hipStream_t s, const char* name) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static const std::string nm = std::string(name) + "_" + std::to_string(BM) + "x" + std::to_string(BN);
+    const double flops = 2.0 * a.M * (double)a.N * a.K;  // algorithmic (the 3 passes of SPLIT are not counted)
+    const double bytes = (double)a.M * a.K * (A_F32 ? 4 : 2) + (double)a.N * a.K * 2 * (SPLIT ? 2 : 1) +
+                         (double)a.M * a.N * (a.c_dtype == CFM_F32 ? 4 : 2);
+    CfmProfScope prof(nm.c_str(), s, flops, bytes);
+    hipLaunchKernelGGL((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV>), dim3(tiles), dim3(256), 0, s, a);
+    return cfm_launch_status(nm.c_str());
+}
+
+template <typename HT, bool A_F32, bool SPLIT, bool CONV>
+int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
+    constexpr int BK = SPLIT ? 32 : 64;
+    if (tile == 0) {
+        // fill the 256 CUs: prefer the biggest tile that still yields >= ~1 workgroup per CU
+        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        const long t64x128 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+        tile = t128 >= 224 ? 1 : (t64x128 >= 224 ? 2 : 3);
+    }
+    switch (tile) {
+        case 1: return launch<HT, 128, 128, BK, A_F32, SPLIT, CONV>(a, s, base);
+        case 2: return launch<HT, 64, 128, BK, A_F32, SPLIT, CONV>(a, s, base);
+        case 3: return launch<HT, 64, 64, BK, A_F32, SPLIT, CONV>(a, s, base);
+        default: return cfm_fail(CFM_ERR_ARG, "cfm_gemm: unknown tile id %d", tile);
+    }
+}
+
+}  // namespace
+
+extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
+    CFM_CHECK_ARG(d && d->A && d->W && d->C, "cfm_gemm: null pointer");
+    CFM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "cfm_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    CFM_CHECK_ARG(d->K % 8 == 0, "cfm_gemm: K=%d must be a multiple of 8", d->K);
+    CFM_CHECK_ARG(d->N % 4 == 0, "cfm_gemm: N=%d must be a multiple of 4", d->N);
+    CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_gemm: w_dtype must be bf16 or fp16");
+    CFM_CHECK_ARG(d->a_dtype == CFM_F32 || d->a_dtype == d->w_dtype, "cfm_gemm: a_dtype must be f32 or equal w_dtype");
+    CFM_CHECK_ARG(d->c_dtype >= CFM_F32 && d->c_dtype <= CFM_F16, "cfm_gemm: bad c_dtype");
+    CFM_CHECK_ARG(d->act >= CFM_ACT_NONE && d->act <= CFM_ACT_GLU, "cfm_gemm: bad activation");
+    CFM_CHECK_ARG(d->mask_mode == 0 || d->mask_mode == 1, "cfm_gemm: bad mask_mode");
+    CFM_CHECK_ARG(d->act != CFM_ACT_GLU || d->N % 32 == 0, "cfm_gemm: GLU needs N %% 32 == 0 (N=%d)", d->N);
+    CFM_CHECK_ARG(d->ldc % 4 == 0, "cfm_gemm: ldc=%lld must be a multiple of 4", (long long)d->ldc);
+    CFM_CHECK_ARG(!d->residual || (d->ldr % 4 == 0), "cfm_gemm: ldr must be a multiple of 4");
+    const bool split = d->W_lo != nullptr;
+    CFM_CHECK_ARG(!split || (d->a_dtype == CFM_F32 && d->w_dtype == CFM_BF16),
+                  "cfm_gemm: split mode needs f32 activations and bf16 weight planes");
+    const bool conv = d->conv_C > 0;
+    if (conv) {
+        CFM_CHECK_ARG(d->conv_C % 8 == 0 && d->K == 9 * d->conv_C, "cfm_gemm: conv needs C %% 8 == 0 and K == 9*C");
+        CFM_CHECK_ARG(d->conv_T2 == (d->conv_T1 - 3) / 2 + 1 && d->conv_F2 == (d->conv_F1 - 3) / 2 + 1 && d->conv_T2 > 0 &&
+                          d->conv_F2 > 0,
+                      "cfm_gemm: conv output shape does not match a 3x3 stride-2 convolution");
+        CFM_CHECK_ARG(d->M % (d->conv_T2 * d->conv_F2) == 0, "cfm_gemm: conv M must be B*T2*F2");
+    } else {
+        CFM_CHECK_ARG(d->lda % 8 == 0, "cfm_gemm: lda=%lld must be a multiple of 8", (long long)d->lda);
+    }
+    GemmArgs a;
+    a.A = d->A; a.W = (const u16*)d->W; a.Wlo = (const u16*)d->W_lo; a.bias = d->bias; a.res = d->residual;
+    a.mask = d->row_mask; a.C = d->C; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.c_dtype = d->c_dtype; a.act = d->act; a.alpha = d->alpha; a.mask_mode = d->mask_mode;
+    a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
+    hipStream_t s = (hipStream_t)stream;
+    const bool a32 = d->a_dtype == CFM_F32;
+    if (split) {
+        return conv ? pick_tile<BF16, true, true, true>(a, d->tile, s, "gemm_conv_bf16x3")
+                    : pick_tile<BF16, true, true, false>(a, d->tile, s, "gemm_bf16x3");
+    }
+    if (d->w_dtype == CFM_BF16) {
+        if (conv) {
+            CFM_CHECK_ARG(!a32, "cfm_gemm: conv mode reads a 16-bit image unless split");
+            return pick_tile<BF16, false, false, true>(a, d->tile, s, "gemm_conv_bf16");
+        }
+        return a32 ? pick_tile<BF16, true, false, false>(a, d->tile, s, "gemm_bf16_a32")
+                   : pick_tile<BF16, false, false, false>(a, d->tile, s, "gemm_bf16");
+    }
+    if (conv) {
+        CFM_CHECK_ARG(!a32, "cfm_gemm: conv mode reads a 16-bit image unless split");
+        return pick_tile<F16, false, false, true>(a, d->tile, s, "gemm_conv_f16");
+    }
+    return a32 ? pick_tile<F16, true, false, false>(a, d->tile, s, "gemm_f16_a32")
+               : pick_tile<F16, false, false, false>(a, d->tile, s, "gemm_f16");
+}

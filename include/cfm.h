@@ -1,0 +1,237 @@
+/* cfm.h -- C ABI of libconformer_gfx950.so: the MI355X (gfx950 / CDNA4) conformer-encoder hot path.
+ *
+ * This is the drop-in boundary described in SURVEY.md section 8(b).  The reference
+ * (Lingeng56/conformer-pytorch-lightning) has no native layer at all: its hot path is eager
+ * torch.nn ops issued from Python.  Each entry point below therefore names the reference Python
+ * call site it replaces (file:line under the reference's src/), and INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only (no torch types).  Every pointer is a DEVICE pointer on the GPU
+ *    that owns `stream`, unless a comment says "host".
+ *  - every launch function returns CFM_OK (0) or a negative cfm_status; it never throws, aborts,
+ *    allocates device memory or synchronises.  Text of the last error of the calling thread:
+ *    cfm_last_error().
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *  - activations are row-major [rows, cols]; "16-bit" means bf16 or fp16 as selected by cfm_dtype.
+ *  - all entry points are re-entrant; the only global state is the optional profiling table
+ *    (cfm_prof_*), guarded by a mutex.
+ */
+#ifndef CFM_H_
+#define CFM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFM_VERSION 100 /* 0.1.0 */
+
+typedef void* cfm_stream_t;
+
+typedef enum { CFM_F32 = 0, CFM_BF16 = 1, CFM_F16 = 2 } cfm_dtype;
+
+typedef enum {
+    CFM_OK = 0,
+    CFM_ERR_ARG = -1,         /* bad shape / alignment / null pointer / unsupported combination */
+    CFM_ERR_LAUNCH = -2,      /* hipGetLastError() after a launch */
+    CFM_ERR_UNSUPPORTED = -3  /* valid request this build has no kernel for */
+} cfm_status;
+
+typedef enum { CFM_ACT_NONE = 0, CFM_ACT_SILU = 1, CFM_ACT_RELU = 2, CFM_ACT_GLU = 3 } cfm_act;
+
+int cfm_version(void);
+const char* cfm_last_error(void);
+/* 1 when the library was built for gfx950 and a gfx950 device is visible (host query, no launch). */
+int cfm_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   C = epilogue( A[M,K] . W[N,K]^T )
+ *
+ * replaces nn.Linear / nn.Conv1d(k=1) / nn.Conv2d(3,stride 2) call sites:
+ *   feedforward.py:17-20 (w_1 + SiLU, w_2), attention.py:62-64,78,99 (linear_q/k/v/pos/out),
+ *   convolution.py:41-42 (pointwise_conv1 + GLU), :46-48 (pointwise_conv2 + mask),
+ *   convolution.py:62-63 (Conv2d(D,D,3,2)+ReLU as implicit GEMM), :74 (out Linear).
+ *
+ *  A        a_dtype 16-bit or f32 (f32 is rounded to `w_dtype` while staging; or split, below)
+ *  W        [N,K] row-major (the nn.Linear weight layout), 16-bit `w_dtype` (bf16|fp16)
+ *  W_lo     optional second plane: when non-NULL the product is evaluated as
+ *           A_hi.W_hi + A_lo.W_hi + A_hi.W_lo with A split on the fly (A must be f32, w_dtype bf16):
+ *           ~16 mantissa bits, the "f32-accurate" mode.
+ *  epilogue v = acc + bias[n];  v = act(v)   (GLU: columns are interleaved in blocks of 16 as
+ *           [a0..a15 | g0..g15 | a16.. ] and the output has N/2 columns = a * sigmoid(g));
+ *           if row_mask && !row_mask[m]: v = 0   (or acc = 0 before the bias, see mask_mode);
+ *           if residual: v = residual[m,n] + alpha * v;     store as c_dtype.
+ *  conv     when conv_C > 0, A is a channels-last image [B, T1, F1, C] and row m = (b, t2, f2) of the
+ *           3x3 stride-2 convolution output [B, T2, F2, N]; K = 9*C ordered (kt, kf, c).
+ *
+ * constraints: K % 8 == 0, lda % 8 == 0 (elements), ldc % 4 == 0, N % 4 == 0 (GLU: N % 32 == 0).
+ */
+typedef struct {
+    const void* A;
+    const void* W;
+    const void* W_lo;
+    const float* bias;
+    const float* residual;
+    const uint8_t* row_mask;
+    void* C;
+    int64_t lda, ldc, ldr;
+    int32_t M, N, K;
+    int32_t a_dtype, w_dtype, c_dtype;
+    int32_t act;
+    float alpha;
+    int32_t conv_C, conv_T1, conv_F1, conv_T2, conv_F2; /* conv_C == 0: plain GEMM */
+    int32_t tile;                                       /* 0 = auto; 1: 128x128, 2: 64x128, 3: 64x64 (tuning) */
+    int32_t mask_mode;                                  /* 0: row_mask zeroes the OUTPUT row (after act, before residual);
+                                                           1: row_mask zeroes the INPUT row (acc = 0, bias/act still apply) */
+} cfm_gemm_desc;
+
+int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (eps inside sqrt, biased variance), optionally two chained norms in one pass:
+ *   y1 = LN(x; g1, b1);  if out1: out1 = y1 (out1_dtype)
+ *   if g2:  y2 = LN(y1; g2, b2) else y2 = y1;  if out2: out2 = row_mask[m] ? y2 : 0  (out2_dtype)
+ * replaces nn.LayerNorm at encoder_layer.py:57,60,64,68,70 and encoder.py:74, and the
+ * masked_fill of convolution.py:36-37 (row_mask).   x is f32 [M,D]; D % 4 == 0, D <= 2048.
+ */
+int cfm_layernorm(const float* x, const float* g1, const float* b1, void* out1, int out1_dtype,
+                  const float* g2, const float* b2, void* out2, int out2_dtype,
+                  const uint8_t* row_mask, float eps, int64_t M, int32_t D, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention:  out[b,i,h,:] = softmax_j( scale * ((q_i+u_h).k_j + (q_i+v_h).p_{b,j}) ) . v_j
+ * with masked scores = -inf and fully masked rows giving 0 (attention.py:81-96 / :162-172).
+ *   q,k,v   element (b,t,h,d) at  base + b*sb + t*st + h*dk + d   (dtype 16-bit or f32)
+ *   p       projected positions, element (b,j,h,d) at p + b*p_sb + j*p_st + h*dk + d;
+ *           p_st == 0 broadcasts one row over all keys (the reference's batch path);
+ *           p == NULL: plain MHSA (no u/v either).
+ *   mask    uint8/bool, element (b,i,j) at mask + b*m_sb + i*m_sq + j ; m_sq == 0 broadcasts over
+ *           queries; NULL = no mask.
+ *   out     [B,Tq,H*dk] row-major, out_dtype.          dk <= 64.
+ */
+typedef struct {
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* p;
+    const float* bias_u; /* [H,dk] f32 */
+    const float* bias_v; /* [H,dk] f32 */
+    const uint8_t* mask;
+    void* out;
+    int64_t q_sb, q_st, k_sb, k_st, k_sh, v_sb, v_st, v_sh, p_sb, p_st, m_sb, m_sq;
+    int32_t B, H, Tq, Tk, dk;
+    int32_t q_dtype, kv_dtype, p_dtype, out_dtype, mma_dtype; /* mma_dtype: bf16|fp16 operand type */
+    int32_t split;                                            /* 1: hi/lo bf16 split (f32-accurate) */
+    float scale;
+} cfm_attn_desc;
+
+int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream);
+
+/* new_cache[b,h,t,0:dk] = K_t, [dk:2dk] = V_t with rows t < Tc copied from old_cache and rows t >= Tc
+ * taken from (k,v) (same addressing as cfm_attn_desc).  f32 output [B,H,Tc+Tn,2dk].
+ * replaces torch.split/cat of attention.py:70-76. */
+int cfm_kv_cache_pack(const float* old_cache, int32_t Tc, const void* k, const void* v, int32_t kv_dtype,
+                      int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, float* new_cache,
+                      int32_t B, int32_t H, int32_t Tn, int32_t dk, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depthwise conv (k taps, zero padding at the tensor edges only) + per-channel affine (folded
+ * BatchNorm, eval) + SiLU on a channels-last [B,T,D] activation.
+ * replaces convolution.py:43-45.   w [D,Ktaps] f32, dw_bias/bn_scale/bn_shift [D] f32.
+ *   y = silu( (sum_k w[d,k] x[b,t+k-(Ktaps-1)/2,d] + dw_bias[d]) * bn_scale[d] + bn_shift[d] )
+ */
+int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, const float* dw_bias,
+                       const float* bn_scale, const float* bn_shift, void* y, int y_dtype, int32_t B,
+                       int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front-end first conv: x [B,T,F] f32 -> relu(conv3x3 stride 2) as channels-last [B,T1,F1,C].
+ * replaces convolution.py:60-61.  w [9,C] f32 (tap-major), bias [C].  C % 8 == 0.
+ */
+int cfm_conv1_relu(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B,
+                   int32_t T, int32_t F, int32_t C, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Masks -- integer/bool, bit-exact with the reference.
+ *  cfm_valid_mask     out[b,t] = (t*stride + first) < len[b]     (uint8 0/1), t in [0,T)
+ *                     first=0,stride=1: ~make_pad_mask (utils.py:84-93, encoder.py:62);
+ *                     first=6,stride=4: the subsampled mask of convolution.py:76 built straight from lengths.
+ *  cfm_chunk_mask     out[i,j] = start_i <= j < end_i            (utils.py:96-111)
+ *  cfm_attn_mask      out[b,i,j] = valid[b,j] & chunk[i,j]       (utils.py:150-152)
+ */
+int cfm_valid_mask(const void* lengths, int len_is_i64, uint8_t* out, int32_t B, int32_t T, int32_t first,
+                   int32_t stride, cfm_stream_t stream);
+int cfm_chunk_mask(uint8_t* out, int32_t size, int32_t chunk, int32_t left, cfm_stream_t stream);
+int cfm_attn_mask(const uint8_t* valid, const uint8_t* chunk, uint8_t* out, int32_t B, int32_t T,
+                  cfm_stream_t stream);
+
+/* element-wise dtype conversion:  dst = cast(src) */
+int cfm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, cfm_stream_t stream);
+/* x[r,:] += add[r / group, :]   (f32, in place; the absolute positional encoding of attention.py:119-120,
+ * where one table row is added to every frame of a batch item: group = T') */
+int cfm_add_rows(float* x, const float* add, int64_t rows, int32_t D, int32_t group, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Composite: one conformer block / the whole encoder stack, enqueued from C++ so that a forward is
+ * ~1 host call instead of ~170 (encoder_layer.py:49-71 and the loop at encoder.py:72-74).
+ * Weights are the PACKED device copies the Python side prepares once (see cfm/packing.py).
+ */
+typedef struct {
+    /* layer norms, f32 [D] */
+    const float *ln_ffm_g, *ln_ffm_b, *ln_mha_g, *ln_mha_b, *ln_conv_g, *ln_conv_b, *ln_ff_g, *ln_ff_b,
+        *ln_final_g, *ln_final_b;
+    /* macaron FFN, FFN: W 16-bit [FF,D] / [D,FF] (+ lo planes in split mode), bias f32 */
+    const void *ffm_w1, *ffm_w1_lo, *ffm_w2, *ffm_w2_lo;
+    const float *ffm_b1, *ffm_b2;
+    const void *ff_w1, *ff_w1_lo, *ff_w2, *ff_w2_lo;
+    const float *ff_b1, *ff_b2;
+    /* attention: fused qkv [3D,D], pos [D,D] (NULL for plain MHSA), out [D,D] */
+    const void *qkv_w, *qkv_w_lo, *pos_w, *pos_w_lo, *out_w, *out_w_lo;
+    const float *qkv_b, *out_b, *bias_u, *bias_v;
+    /* conv module: pw1 [2D,D] GLU-interleaved, dw [D,K], folded BN, pw2 [D,D] */
+    const void *pw1_w, *pw1_w_lo, *pw2_w, *pw2_w_lo;
+    const float *pw1_b, *pw2_b, *dw_w, *dw_b, *bn_scale, *bn_shift;
+} cfm_layer_weights;
+
+typedef struct {
+    void *xn, *hid, *qkv, *pos, *ctx, *glu, *dw; /* activation-dtype scratch: [M,D],[M,FF],[M,3D],[R,D],[M,D],[M,D],[M,D] */
+} cfm_layer_scratch;
+
+typedef struct {
+    int32_t B, T, D, H, FF, ktaps;
+    int32_t act_dtype; /* CFM_BF16 | CFM_F16 (16-bit modes) | CFM_F32 (split mode) */
+    int32_t w_dtype;   /* CFM_BF16 | CFM_F16 */
+    const uint8_t* attn_mask;
+    int64_t am_sb, am_sq;     /* see cfm_attn_desc.mask */
+    const uint8_t* pad_valid; /* [B*T] or NULL */
+    const float* pos_embed;   /* f32 [R,D] rows, R = B*P */
+    int32_t pos_rows;         /* R (0: plain MHSA) */
+    const float* attn_cache;  /* f32 [B,H,Tc,2dk] or NULL */
+    int32_t cache_T;
+    float* new_cache;         /* f32 [B,H,Tc+T,2dk] or NULL (not materialised) */
+} cfm_layer_io;
+
+/* x_in f32 [B*T,D] (not modified) -> x_out f32 [B*T,D] = norm_final(block(x_in)).
+ * If next_g != NULL additionally writes LN(x_out; next_g,next_b) to s->xn for the following block. */
+int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_layer_scratch* s, const cfm_layer_io* io,
+                              const float* x_in, float* x_out, int xn_ready, const float* next_g,
+                              const float* next_b, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Profiling table (aux subsystem: tracing).  When enabled, every kernel launch made through this
+ * library is bracketed by HIP events on its stream; cfm_prof_collect() synchronises those events and
+ * accumulates per-kernel-name totals.  Used by bench.py for the live roofline figure.
+ */
+void cfm_prof_enable(int on);
+void cfm_prof_reset(void);
+int cfm_prof_collect(void);                 /* returns number of distinct kernel names */
+int cfm_prof_entry(int i, char* name, int name_cap, int64_t* calls, double* total_ms, double* flops,
+                   double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFM_H_ */

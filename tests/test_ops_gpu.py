@@ -1,0 +1,308 @@
+"""GPU: every C-ABI op of libconformer_gfx950 against an independent computation on the same inputs.
+
+The checker here is plain torch math in f32/f64 (on the 16-bit-rounded operands where the op rounds them), plus the
+numpy oracle for the bit-exact mask path.  All calls go through the ctypes binding -> C ABI -> HIP kernels.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfm():
+    import cfm as c
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert c.lib().cfm_device_ok() == 1, c.lib().cfm_last_error()
+    return c
+
+
+def rnd(shape, seed, scale=1.0, device="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(device)
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+W_DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+@pytest.mark.parametrize("M,N,K", [(7968, 256, 256), (200, 144, 144), (98, 576, 144), (98, 144, 576), (333, 432, 144),
+                                   (64, 64, 64), (1, 256, 256), (130, 132, 72), (513, 2048, 256)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_gemm_plain(cfm, M, N, K, wdt, tile):
+    a = rnd((M, K), 1)
+    w = rnd((N, K), 2, K ** -0.5)
+    bias = rnd((N,), 3, 0.1)
+    w16 = w.to(W_DT[wdt])
+    a16 = a.to(W_DT[wdt])
+    ref = a16.float() @ w16.float().t() + bias
+    # 16-bit A, f32 out
+    out = cfm.gemm(a16, w16, bias=bias, tile=tile)
+    assert out.dtype == torch.float32 and relerr(out, ref) < 2e-5
+    # f32 A (rounded while staging), 16-bit out
+    out16 = cfm.gemm(a, w16, bias=bias, out_dtype=W_DT[wdt], tile=tile)
+    assert out16.dtype == W_DT[wdt]
+    assert relerr(out16.float(), ref.to(W_DT[wdt]).float()) < (1e-2 if wdt == "bf16" else 2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(7968, 256, 2048), (250, 144, 576), (77, 72, 40)])
+def test_gemm_epilogues(cfm, M, N, K):
+    a = rnd((M, K), 4).bfloat16()
+    w = rnd((N, K), 5, K ** -0.5).bfloat16()
+    bias = rnd((N,), 6, 0.1)
+    res = rnd((M, N), 7)
+    mask = (torch.rand(M, device="cuda") > 0.3).to(torch.uint8)
+    lin = a.float() @ w.float().t()
+    # silu / relu
+    assert relerr(cfm.gemm(a, w, bias=bias, act=cfm.ACT_SILU), torch.nn.functional.silu(lin + bias)) < 2e-5
+    assert relerr(cfm.gemm(a, w, bias=bias, act=cfm.ACT_RELU), torch.relu(lin + bias)) < 2e-5
+    # residual + alpha, in place and out of place; inputs must not change when out-of-place
+    res0 = res.clone()
+    out = cfm.gemm(a, w, bias=bias, residual=res, alpha=0.5)
+    assert torch.equal(res, res0)
+    assert relerr(out, res0 + 0.5 * (lin + bias)) < 2e-5
+    cfm.gemm(a, w, bias=bias, residual=res, alpha=0.5, out=res)
+    assert relerr(res, res0 + 0.5 * (lin + bias)) < 2e-5
+    # output-row mask then residual (pointwise_conv2 + masked_fill + residual)
+    out = cfm.gemm(a, w, bias=bias, residual=res0, alpha=1.0, row_mask=mask)
+    assert relerr(out, res0 + (lin + bias) * mask[:, None].float()) < 2e-5
+    # input-row mask (masked_fill before pointwise_conv1): dead rows still get the bias
+    out = cfm.gemm(a, w, bias=bias, row_mask=mask, mask_mode=1)
+    assert relerr(out, lin * mask[:, None].float() + bias) < 2e-5
+
+
+@pytest.mark.parametrize("M,D", [(7968, 256), (98, 144), (31, 512)])
+def test_gemm_glu(cfm, M, D):
+    a = rnd((M, D), 8).bfloat16()
+    w = rnd((2 * D, D), 9, D ** -0.5)
+    bias = rnd((2 * D,), 10, 0.2)
+    # interleave as the packer does: GEMM col blk*32 + half*16 + i  <-  weight row half*D + blk*16 + i
+    idx = torch.arange(2 * D, device="cuda")
+    src = ((idx % 32) // 16) * D + (idx // 32) * 16 + (idx % 16)
+    wp = w[src].bfloat16().contiguous()
+    bp = bias[src].contiguous()
+    lin = a.float() @ w.bfloat16().float().t() + bias
+    ref = lin[:, :D] * torch.sigmoid(lin[:, D:])
+    out = cfm.gemm(a, wp, bias=bp, act=cfm.ACT_GLU)
+    assert out.shape == (M, D) and relerr(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(7968, 256, 256), (98, 144, 576), (333, 576, 144)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_gemm_split_is_f32_accurate(cfm, M, N, K, tile):
+    a = rnd((M, K), 11)
+    w = rnd((N, K), 12, K ** -0.5)
+    bias = rnd((N,), 13, 0.1)
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    ref = a.double() @ w.double().t() + bias.double()
+    out = cfm.gemm(a, hi, bias=bias, w_lo=lo, tile=tile)
+    assert relerr(out, ref) < 4e-5
+    single = cfm.gemm(a, hi, bias=bias, tile=tile)
+    assert relerr(single, ref) > 10 * relerr(out, ref)      # the split really buys precision
+
+
+@pytest.mark.parametrize("B,T1,F1,C,N", [(2, 21, 39, 144, 144), (3, 99, 39, 256, 256), (1, 7, 9, 16, 32)])
+def test_gemm_conv3x3s2(cfm, B, T1, F1, C, N):
+    img = torch.relu(rnd((B, T1, F1, C), 14)).bfloat16()
+    w = rnd((N, C, 3, 3), 15, (9 * C) ** -0.5)
+    bias = rnd((N,), 16, 0.1)
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    wk = w.permute(0, 2, 3, 1).reshape(N, 9 * C).bfloat16().contiguous()       # [co][kt][kf][ci]
+    ref = torch.nn.functional.conv2d(img.float().permute(0, 3, 1, 2), w.bfloat16().float(), bias, stride=2)
+    ref = torch.relu(ref).permute(0, 2, 3, 1).reshape(B * T2 * F2, N)
+    for tile in (0, 1, 2, 3):
+        out = cfm.gemm(img, wk, bias=bias, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2), tile=tile)
+        assert relerr(out, ref) < 2e-5, tile
+    hi = w.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    whi = hi.bfloat16()
+    wlo = (hi - whi.float()).bfloat16()
+    img32 = torch.relu(rnd((B, T1, F1, C), 14))
+    ref = torch.relu(torch.nn.functional.conv2d(img32.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=2))
+    ref = ref.permute(0, 2, 3, 1).reshape(B * T2 * F2, N)
+    out = cfm.gemm(img32, whi, bias=bias, w_lo=wlo, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2))
+    assert relerr(out, ref) < 4e-5
+
+
+def test_gemm_rejects_bad_arguments(cfm):
+    a = rnd((8, 12), 1).bfloat16()
+    w = rnd((8, 12), 2).bfloat16()
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        cfm.gemm(a, w)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        cfm.gemm(a.cpu(), w.cpu())
+
+
+@pytest.mark.parametrize("M,D", [(7968, 256), (98, 144), (5, 512), (3, 1024), (2, 2048)])
+def test_layernorm(cfm, M, D):
+    x = rnd((M, D), 20, 2.0) + 0.5
+    g1, b1 = 1 + 0.1 * rnd((D,), 21), 0.1 * rnd((D,), 22)
+    g2, b2 = 1 + 0.1 * rnd((D,), 23), 0.1 * rnd((D,), 24)
+    ref1 = torch.nn.functional.layer_norm(x, (D,), g1, b1, 1e-5)
+    ref2 = torch.nn.functional.layer_norm(ref1, (D,), g2, b2, 1e-5)
+    y1, _ = cfm.layernorm(x, g1, b1)
+    assert relerr(y1, ref1) < 2e-6
+    mask = (torch.rand(M, device="cuda") > 0.3).to(torch.uint8)
+    y1, y2 = cfm.layernorm(x, g1, b1, g2=g2, b2=b2, out2_dtype=torch.bfloat16, row_mask=mask)
+    assert relerr(y1, ref1) < 2e-6
+    assert relerr(y2.float(), (ref2 * mask[:, None]).bfloat16().float()) < 1e-2
+    _, y3 = cfm.layernorm(x, g1, b1, want1=False, out2_dtype=torch.float16)
+    assert relerr(y3.float(), ref1) < 2e-3
+    xc = x.clone()
+    cfm.layernorm(xc, g1, b1, out1=xc)                       # in place
+    assert relerr(xc, ref1) < 2e-6
+
+
+def attn_reference(q, k, v, p, u, vb, mask, scale):
+    """q (B,Tq,H,dk) k,v (B,Tk,H,dk) p (B,P,H,dk)|None, all float64."""
+    qh, kh, vh = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    if p is not None:
+        s = torch.einsum("bhid,bhjd->bhij", qh + u[None, :, None, :], kh)
+        s = s + torch.einsum("bhid,bhjd->bhij", qh + vb[None, :, None, :], p.permute(0, 2, 1, 3))
+    else:
+        s = torch.einsum("bhid,bhjd->bhij", qh, kh)
+    s = s * scale
+    if mask is not None:
+        dead = mask.unsqueeze(1) == 0
+        s = s.masked_fill(dead, float("-inf"))
+        a = torch.softmax(s, -1).masked_fill(dead, 0.0)
+        a = torch.nan_to_num(a, nan=0.0)
+    else:
+        a = torch.softmax(s, -1)
+    o = torch.einsum("bhij,bhjd->bhid", a, vh)
+    return o.permute(0, 2, 1, 3).reshape(q.size(0), q.size(1), -1)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dk", [(32, 4, 249, 249, 64), (2, 4, 49, 49, 36), (1, 4, 16, 80, 36), (3, 8, 70, 130, 64), (2, 2, 5, 5, 8)])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("pos", ["none", "broadcast", "perkey"])
+@pytest.mark.parametrize("masking", ["none", "pad", "full"])
+def test_attention(cfm, B, H, Tq, Tk, dk, mode, pos, masking):
+    D = H * dk
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[mode]
+    qkv = rnd((B, Tq, 3 * D), 30).to(dt)
+    kv_src = qkv if Tk == Tq else rnd((B, Tk, 3 * D), 31).to(dt)
+    q = qkv[..., :D].reshape(B, Tq, H, dk)
+    k = kv_src[..., D:2 * D].reshape(B, Tk, H, dk)
+    v = kv_src[..., 2 * D:].reshape(B, Tk, H, dk)
+    u, vb = rnd((H, dk), 32, 0.3), rnd((H, dk), 33, 0.3)
+    P = {"none": 0, "broadcast": 1, "perkey": Tk}[pos]
+    p = rnd((B, P, D), 34).to(dt) if P else None
+    mask = None
+    if masking == "pad":
+        lens = torch.randint(1, Tk + 1, (B,), generator=torch.Generator().manual_seed(35))
+        lens[0] = Tk
+        mask = (torch.arange(Tk)[None, :] < lens[:, None]).unsqueeze(1).cuda()              # (B,1,Tk)
+    elif masking == "full":
+        mask = (torch.rand(B, Tq, Tk, generator=torch.Generator().manual_seed(36)) > 0.4).cuda()
+        mask[:, min(3, Tq - 1), :] = False                                                     # a fully masked row (Q2)
+    out = torch.empty((B, Tq, D), dtype=dt, device="cuda")
+    m8 = cfm.as_u8_mask(mask) if mask is not None else None
+    mstr = (0, 0) if mask is None else (m8.stride(0), m8.stride(1) if m8.size(1) > 1 else 0)
+    cfm.attention(qkv, kv_src[..., D:], kv_src[..., 2 * D:], B, H, Tq, Tk, dk,
+                  (Tq * 3 * D, 3 * D), (Tk * 3 * D, 3 * D, dk), (Tk * 3 * D, 3 * D, dk), out,
+                  p=p, p_str=(P * D, D if P > 1 else 0), bias_u=u if P else None, bias_v=vb if P else None,
+                  mask=m8, mask_str=mstr, mma_code=cfm.F16 if mode == "fp16" else cfm.BF16, split=mode == "fp32")
+    ref = attn_reference(q.double(), k.double(), v.double(), p.double().reshape(B, P, H, dk) if P else None, u.double(), vb.double(),
+                         mask, 1 / math.sqrt(dk))
+    tol = {"bf16": 2e-2, "fp16": 3e-3, "fp32": 2e-4}[mode]
+    assert torch.isfinite(out.float()).all()
+    assert relerr(out.float(), ref) < tol
+    if masking == "full":
+        assert float(out[:, min(3, Tq - 1)].float().abs().max()) == 0.0
+
+
+def test_attention_kv_cache_layout(cfm):
+    B, H, Tc, Tn, dk = 1, 4, 20, 16, 36
+    D = H * dk
+    qkv = rnd((B, Tn, 3 * D), 40).bfloat16()
+    cache = rnd((B, H, Tc, 2 * dk), 41)
+    new = cfm.kv_cache_pack(cache, qkv[..., D:], qkv[..., 2 * D:], (Tn * 3 * D, 3 * D), (Tn * 3 * D, 3 * D), B, H, Tn, dk)
+    k_new = qkv[..., D:2 * D].float().reshape(B, Tn, H, dk).permute(0, 2, 1, 3)
+    v_new = qkv[..., 2 * D:].float().reshape(B, Tn, H, dk).permute(0, 2, 1, 3)
+    ref = torch.cat([torch.cat([cache[..., :dk], k_new], 2), torch.cat([cache[..., dk:], v_new], 2)], -1)
+    assert torch.equal(new, ref)
+    # attention reading K/V straight from the (B,H,Tk,2dk) f32 cache layout
+    Tk = Tc + Tn
+    out = torch.empty((B, Tn, D), dtype=torch.bfloat16, device="cuda")
+    cfm.attention(qkv, new, new[..., dk:], B, H, Tn, Tk, dk, (Tn * 3 * D, 3 * D), (H * Tk * 2 * dk, 2 * dk, Tk * 2 * dk),
+                  (H * Tk * 2 * dk, 2 * dk, Tk * 2 * dk), out)
+    q = qkv[..., :D].double().reshape(B, Tn, H, dk)
+    ref_o = attn_reference(q, ref[..., :dk].double().permute(0, 2, 1, 3), ref[..., dk:].double().permute(0, 2, 1, 3), None, None, None,
+                           None, 1 / math.sqrt(dk))
+    assert relerr(out.float(), ref_o) < 2e-2
+
+
+@pytest.mark.parametrize("B,T,D,K", [(32, 249, 256, 15), (3, 37, 144, 15), (2, 5, 16, 15), (2, 40, 32, 7)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_dwconv_bn_silu(cfm, B, T, D, K, dt):
+    x = rnd((B, T, D), 50).to(dt)
+    w = rnd((D, K), 51, 0.3)
+    db, sc, sh = rnd((D,), 52, 0.1), 1 + 0.2 * rnd((D,), 53), rnd((D,), 54, 0.1)
+    y = cfm.dwconv_bn_silu(x, w, db, sc, sh)
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w[:, None, :], db, padding=(K - 1) // 2, groups=D)
+    ref = torch.nn.functional.silu(ref * sc[None, :, None] + sh[None, :, None]).transpose(1, 2)
+    tol = {torch.bfloat16: 1e-2, torch.float16: 2e-3, torch.float32: 1e-5}[dt]
+    assert y.dtype == dt and relerr(y.float(), ref) < tol
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 200, 144), (3, 83, 256), (1, 7, 8)])
+def test_conv1_relu(cfm, B, T, C):
+    x = rnd((B, T, 80), 60)
+    w = rnd((C, 1, 3, 3), 61, 1 / 3)
+    b = rnd((C,), 62, 0.1)
+    w9c = w.reshape(C, 9).t().contiguous()
+    ref = torch.relu(torch.nn.functional.conv2d(x[:, None], w, b, stride=2)).permute(0, 2, 3, 1)
+    y = cfm.conv1_relu(x, w9c, b, torch.float32)
+    assert relerr(y, ref) < 2e-6
+    y = cfm.conv1_relu(x, w9c, b, torch.bfloat16)
+    assert relerr(y.float(), ref.bfloat16().float()) < 1e-2
+
+
+def test_masks_bit_exact(cfm):
+    from oracle import conformer_oracle as O
+    lens = torch.tensor([200, 163, 7, 0, 1000], dtype=torch.int32, device="cuda")
+    for T in (9, 200, 1000):
+        got = cfm.valid_mask(lens, T).cpu().numpy()
+        assert np.array_equal(got, ~O.pad_mask(lens.cpu().numpy(), T))
+        tp = O.subsampled_len(T)
+        if tp > 0:
+            sub = cfm.valid_mask(lens.long(), tp, first=6, stride=4).cpu().numpy()
+            assert np.array_equal(sub, O.subsample_mask((~O.pad_mask(lens.cpu().numpy(), T))[:, None, :])[:, 0, :])
+    for size, c, left in [(17, 4, -1), (17, 4, 2), (16, 16, 0), (9, 1, 0), (9, 3, 1), (5, 8, -1), (49, 4, 2), (1, 1, 0), (249, 16, 4)]:
+        assert np.array_equal(cfm.chunk_mask(size, c, left, "cuda").cpu().numpy(), O.chunk_mask(size, c, left)), (size, c, left)
+    valid = cfm.valid_mask(torch.tensor([13, 8], dtype=torch.int32, device="cuda"), 13).unsqueeze(1)
+    ch = cfm.chunk_mask(13, 3, 1, "cuda")
+    assert np.array_equal(cfm.attn_mask_combine(valid, ch).cpu().numpy(), valid.cpu().numpy() & O.chunk_mask(13, 3, 1)[None])
+
+
+def test_cast_and_add_rows(cfm):
+    x = rnd((5, 7, 16), 70)
+    assert torch.equal(cfm.cast(x, torch.bfloat16), x.bfloat16())
+    assert torch.equal(cfm.cast(x.half(), torch.float32), x.half().float())
+    y = rnd((6, 16), 71)
+    add = rnd((2, 16), 72)
+    ref = y + add.repeat_interleave(3, 0)
+    assert torch.equal(cfm.add_rows(y, add, 3), ref)
+
+
+def test_profiling_table(cfm):
+    a = rnd((512, 256), 80).bfloat16()
+    w = rnd((256, 256), 81).bfloat16()
+    cfm.prof_reset()
+    cfm.prof_enable(True)
+    for _ in range(5):
+        cfm.gemm(a, w)
+    cfm.prof_enable(False)
+    tab = cfm.prof_table()
+    (name, e), = tab.items()
+    assert name.startswith("gemm_bf16") and e["calls"] == 5 and e["ms"] > 0 and e["flops"] == 5 * 2.0 * 512 * 256 * 256
+    cfm.prof_reset()
