@@ -1,0 +1,138 @@
+"""One conformer block, MI355X-native.
+
+Drop-in for the reference's ``src/encoder_layer.py`` (constructor arguments, child-module and parameter names, and the
+``forward(inputs, inputs_attn_mask, pos_embed, inputs_pad_mask, attn_cache, cnn_cache)`` ->
+``(out, inputs_attn_mask, new_attn_cache, new_cnn_cache)`` contract of encoder_layer.py:11-71).
+
+The whole block -- LN, 1/2 macaron FFN, LN, MHSA, LN, convolution module, LN, 1/2 FFN, final LN with every residual -- is
+ONE call into libconformer_gfx950 (``cfm_encoder_layer_forward``): 17 kernel launches enqueued from C++ with no host
+synchronisation, the residual stream in f32, every bias / activation / GLU / mask / residual add fused into a GEMM
+epilogue, and LayerNorm writing the next GEMM's operand dtype directly.  The child modules (feedforward / attention /
+convolution) only own the parameters here; called on their own they run the same kernels op by op.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+import cfm
+from cfm import packing
+from attention import MultiHeadSelfAttentionModule, RelativeMultiHeadSelfAttentionModule, _mask_args
+from convolution import ConvolutionModule
+from feedforward import PositionwiseFeedForwardModule, _inference_only
+
+_ABSENT = torch.ones((0, 0, 0), dtype=torch.bool)
+
+
+class ConformerEncoderLayer(nn.Module):
+
+    def __init__(self, encoder_dim, kernel_size, feedforward_dropout, attention_dropout, hidden_dim, num_heads, use_relative):
+        super().__init__()
+        self.feed_forward = PositionwiseFeedForwardModule(encoder_dim, feedforward_dropout, hidden_dim)
+        attn_cls = RelativeMultiHeadSelfAttentionModule if use_relative else MultiHeadSelfAttentionModule
+        self.self_attn = attn_cls(encoder_dim, num_heads, attention_dropout)
+        self.conv_module = ConvolutionModule(encoder_dim, kernel_size, hidden_dim)     # sic: lands in `bias` (quirk Q1)
+        self.feed_forward_macaron = PositionwiseFeedForwardModule(encoder_dim, feedforward_dropout, hidden_dim)
+        self.norm_ff = nn.LayerNorm(encoder_dim, eps=1e-5)
+        self.norm_ff_macaron = nn.LayerNorm(encoder_dim, eps=1e-5)
+        self.norm_mha = nn.LayerNorm(encoder_dim, eps=1e-5)
+        self.norm_conv = nn.LayerNorm(encoder_dim, eps=1e-5)
+        self.norm_final = nn.LayerNorm(encoder_dim, eps=1e-5)
+        self.dropout = nn.Dropout(feedforward_dropout)
+        self.use_relative = bool(use_relative)
+        self.encoder_dim, self.hidden_dim, self.num_heads, self.kernel_size = encoder_dim, hidden_dim, num_heads, kernel_size
+        self.return_cache = True           # the reference always materialises cat(k,v) (attention.py:76)
+        self._fused = None                 # (key, LayerWeights, keepalive)
+        self._plist = None
+
+    def _apply(self, fn, *a, **kw):        # .to() / .cuda() / .half(): drop every packed copy
+        self._fused = None
+        self._plist = None
+        return super()._apply(fn, *a, **kw)
+
+    def _weights(self, prec):
+        if self._plist is None:
+            self._plist = [t for t in list(self.parameters()) + list(self.buffers())]
+        key = (prec.name,) + tuple(t._version for t in self._plist)
+        if self._fused is None or self._fused[0] != key:
+            struct, keep = packing.layer_weight_struct(self, prec)
+            self._fused = (key, struct, keep)
+        return self._fused[1]
+
+    def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
+                      want_cache=True):
+        """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified."""
+        _inference_only(self, "ConformerEncoderLayer")
+        if self.training:
+            raise NotImplementedError("ConformerEncoderLayer: train-mode (dropout, BatchNorm batch statistics) is not built yet")
+        cfm.require_hip(x)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        prec = cfm.get_precision()
+        w = self._weights(prec)
+        B, T, D = x.shape
+        H, FF = self.num_heads, self.hidden_dim
+        dk = D // H
+        dev = x.device
+        M = B * T
+
+        have_cache = attn_cache is not None and attn_cache.dim() == 4 and attn_cache.size(0) > 0
+        cache = attn_cache.to(device=dev, dtype=torch.float32).contiguous() if have_cache else None
+        Tc = cache.size(2) if have_cache else 0
+        Tk = Tc + T
+        if have_cache and tuple(cache.shape) != (B, H, Tc, 2 * dk):
+            raise RuntimeError("attn_cache of shape %s, expected (%d,%d,Tc,%d)" % (tuple(cache.shape), B, H, 2 * dk))
+        new_cache = torch.empty((B, H, Tk, 2 * dk), dtype=torch.float32, device=dev) if (have_cache or want_cache) else None
+
+        pos = None
+        R = 0
+        if self.use_relative:
+            pos = pos_embed.reshape(-1, D)
+            pos = (pos if pos.dtype == torch.float32 else pos.float()).contiguous()
+            cfm.require_hip(pos)
+            R = pos.size(0)
+
+        m8, (m_sb, m_sq) = _mask_args(attn_mask, B, T, Tk)
+        keep = None
+        if pad_mask is not None and pad_mask.dim() >= 3 and pad_mask.size(2) > 0:
+            keep = cfm.as_u8_mask(pad_mask).reshape(-1)
+            if keep.numel() != M:
+                raise RuntimeError("pad mask %s does not match inputs %s" % (tuple(pad_mask.shape), tuple(x.shape)))
+        cfm.require_hip(m8, keep)
+
+        adt = prec.act_dtype
+        s = cfm.LayerScratch()
+        s.xn = cfm.scratch("xn", M * D, adt, dev).data_ptr()
+        s.hid = cfm.scratch("hid", M * FF, adt, dev).data_ptr()
+        s.qkv = cfm.scratch("qkv", M * 3 * D, adt, dev).data_ptr()
+        s.pos = cfm.scratch("pos", max(R, 1) * D, adt, dev).data_ptr()
+        s.ctx = cfm.scratch("ctx", M * D, adt, dev).data_ptr()
+        s.glu = cfm.scratch("glu", M * D, adt, dev).data_ptr()
+        s.dw = cfm.scratch("dw", M * D, adt, dev).data_ptr()
+
+        io = cfm.LayerIO()
+        io.B, io.T, io.D, io.H, io.FF, io.ktaps = B, T, D, H, FF, self.kernel_size
+        io.act_dtype, io.w_dtype = prec.act_code, prec.w_code
+        io.attn_mask, io.am_sb, io.am_sq = cfm.ptr(m8), m_sb, m_sq
+        io.pad_valid = cfm.ptr(keep)
+        io.pos_embed, io.pos_rows = cfm.ptr(pos), R
+        io.attn_cache, io.cache_T = cfm.ptr(cache), Tc
+        io.new_cache = cfm.ptr(new_cache)
+
+        if out is None:
+            out = torch.empty_like(x)
+        ng = nb = None
+        if next_norm is not None:
+            ng, nb = next_norm.weight.data_ptr(), next_norm.bias.data_ptr()
+        cfm.check(cfm.lib().cfm_encoder_layer_forward(ctypes.byref(w), ctypes.byref(s), ctypes.byref(io), x.data_ptr(),
+                                                      out.data_ptr(), 1 if xn_ready else 0, ng, nb, cfm.stream()),
+                  "cfm_encoder_layer_forward")
+        return out, new_cache
+
+    def forward(self, inputs, inputs_attn_mask, pos_embed, inputs_pad_mask=_ABSENT, attn_cache=_ABSENT, cnn_cache=_ABSENT):
+        out, new_attn_cache = self.fused_forward(inputs, inputs_attn_mask, pos_embed, inputs_pad_mask, attn_cache,
+                                                 want_cache=self.return_cache)
+        if new_attn_cache is None:
+            new_attn_cache = torch.zeros((0, 0, 0, 0), dtype=torch.float32, device=inputs.device)
+        new_cnn_cache = torch.zeros((0, 0, 0), dtype=inputs.dtype, device=inputs.device)    # convolution.py:39
+        return out.to(inputs.dtype), inputs_attn_mask, new_attn_cache, new_cnn_cache

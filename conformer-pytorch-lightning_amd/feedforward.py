@@ -1,0 +1,47 @@
+"""Position-wise feed-forward block of the conformer, MI355X-native.
+
+Drop-in for the reference's ``src/feedforward.py`` (class name, constructor arguments, parameter names
+``w_1.{weight,bias}`` / ``w_2.{weight,bias}`` and ``forward(inputs)`` are the reference's, feedforward.py:4-21).
+The arithmetic is two calls into libconformer_gfx950: an MFMA GEMM whose epilogue adds the bias and applies
+SiLU/ReLU and writes the 16-bit hidden activation, and a second GEMM whose epilogue adds the output bias.
+"""
+import torch
+import torch.nn as nn
+
+import cfm
+from cfm import packing
+
+
+def _inference_only(module, what):
+    if module.training and torch.is_grad_enabled():
+        raise NotImplementedError(
+            "%s: this build ships forward (inference) kernels only; call .eval() / torch.no_grad(). "
+            "Backward kernels are the next row of the scope table (SURVEY 8f)." % what)
+
+
+class PositionwiseFeedForwardModule(nn.Module):
+
+    def __init__(self, input_dim, dropout, hidden_dim, activation='swish'):
+        super().__init__()
+        self.w_1 = nn.Linear(input_dim, hidden_dim)
+        self.activation = nn.SiLU() if activation == 'swish' else nn.ReLU()
+        self.dropout = nn.Dropout(dropout)
+        self.w_2 = nn.Linear(hidden_dim, input_dim)
+        self._pack = packing.PackCache()
+
+    def forward(self, inputs):
+        _inference_only(self, "PositionwiseFeedForwardModule")
+        cfm.require_hip(inputs)
+        prec = cfm.get_precision()
+        pk = packing.pack_ffn(self, prec)
+        d_in = inputs.shape[-1]
+        x = inputs.reshape(-1, d_in)
+        if x.dtype != torch.float32 and x.dtype != prec.w_dtype:
+            x = x.float()
+        if prec.split and x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        act = cfm.ACT_SILU if isinstance(self.activation, nn.SiLU) else cfm.ACT_RELU
+        hid = cfm.gemm(x, pk.w1, bias=pk.b1, w_lo=pk.w1_lo, act=act, out_dtype=prec.act_dtype)
+        out = cfm.gemm(hid, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, out_dtype=torch.float32)
+        return out.view(*inputs.shape[:-1], out.shape[-1]).to(inputs.dtype)
