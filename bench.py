@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- encoder-forward throughput of the MI355X-native conformer encoder (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 100 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE ConformerEncoder.forward (front-end + 12 blocks + after_norm) over one batch of 32 x (80 x 1000)
+synthetic fbank already resident in HBM.  Utterances are independent, so N GPUs run N batch-sharded replicas with NO
+data-path collective ("weak" scaling: per-GPU batch fixed); the only collectives are the barrier that brackets the
+timed region and the MAX-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+
+Besides the headline value the line carries
+  roofline      the dominant kernel (largest share of device time) from a second, instrumented pass over the same
+                K steps: every launch bracketed by HIP events on its own stream (cfm_prof_*), algorithmic FLOPs per launch
+                / average launch duration, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch CPU path, oracle/conformer_oracle.py) timed on the host
+                cores of the same box on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "conformer-pytorch-lightning_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CFG2 = dict(input_dim=80, kernel_size=15, encoder_dim=256, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+            hidden_dim=2048, num_heads=4, encoder_num_layers=12, max_len=5000, use_relative=True)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 2500.0 / 3.0}   # dense MFMA (MI355X_MICROARCH.md); fp32 mode = 3 bf16 passes
+HBM_PEAK_GBS = 8000.0
+
+
+def build_encoder(device, seed=0):
+    import encoder as enc_mod
+    torch.manual_seed(seed)
+    enc = enc_mod.ConformerEncoder(cmvn=None, **CFG2).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():                       # BatchNorm must not be the identity
+        for layer in enc.encoders:
+            bn = layer.conv_module.norm
+            bn.running_mean.copy_(0.1 * torch.randn(bn.running_mean.shape, generator=g))
+            bn.running_var.copy_(0.5 + torch.rand(bn.running_var.shape, generator=g))
+    return enc.to(device)
+
+
+def cpu_baseline(enc, frames, sample_batch, iters):
+    """Time the CPU oracle (port of the reference CPU path) on `sample_batch` utterances; returns frames/s."""
+    from oracle import conformer_oracle as O
+    P = {k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
+    cfg = O.Config(**CFG2)
+    x = torch.from_numpy(np.random.RandomState(1234).standard_normal((sample_batch, frames, 80)).astype(np.float32))
+    lens = [frames] * sample_batch
+    with torch.no_grad():
+        O.encoder_forward(P, cfg, x, lens)                  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.encoder_forward(P, cfg, x, lens)
+        dt = (time.perf_counter() - t0) / iters
+    return sample_batch * frames / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--graph", type=int, default=1, help="replay the forward from a captured HIP graph (1) or launch eagerly (0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--all-kernels", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+    else:
+        dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    import cfm
+    from oracle import conformer_oracle as O
+    if cfm.lib().cfm_device_ok() != 1:
+        raise SystemExit("bench.py: " + cfm.lib().cfm_last_error().decode())
+    cfm.set_precision(args.precision)
+
+    enc = build_encoder(device)
+    B, T = args.batch, args.frames
+    x = torch.from_numpy(np.random.RandomState(1234 + rank).standard_normal((B, T, 80)).astype(np.float32)).to(device)
+    lens = torch.full((B,), T, dtype=torch.int32, device=device)
+
+    stream = torch.cuda.Stream(device=device)
+    graph = None
+    with torch.no_grad(), torch.cuda.stream(stream):
+        for _ in range(3):
+            y, m = enc(x, lens)
+        stream.synchronize()
+        if args.graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    y, m = enc(x, lens)
+                graph.replay()
+                stream.synchronize()
+            except Exception as e:                      # noqa: BLE001
+                print("[bench] graph capture unavailable (%s); launching eagerly" % (str(e).splitlines()[0],), file=sys.stderr)
+                graph = None
+
+        def step():
+            if graph is not None:
+                graph.replay()
+            else:
+                enc(x, lens)
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(device)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        # ---- instrumented pass: per-kernel HIP events on the launch stream (eager launches, same K steps) ----------
+        roofline = None
+        table = {}
+        if rank == 0:
+            cfm.prof_reset()
+            cfm.prof_enable(True)
+            for _ in range(args.steps):
+                enc(x, lens)
+            stream.synchronize()
+            cfm.prof_enable(False)
+            table = cfm.prof_table()
+            cfm.prof_reset()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = world * B * T * args.steps / elapsed
+
+    if rank == 0:
+        total_ms = sum(e["ms"] for e in table.values()) or 1.0
+        mfma = {k: e for k, e in table.items() if e["flops"] > 0 and k.split("_")[0] in ("gemm", "attn", "ffn")}
+        if mfma:
+            name, e = max(mfma.items(), key=lambda kv: kv[1]["ms"])
+            avg_ms = e["ms"] / e["calls"]
+            achieved = e["flops"] / e["calls"] / (avg_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.precision]
+            roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "launches_per_step": e["calls"] // args.steps, "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "share_of_device_time": round(e["ms"] / total_ms, 4),
+                        "algorithmic_gflop_per_launch": round(e["flops"] / e["calls"] / 1e9, 3)}
+        flops_step = O.encoder_flops_per_utt(T, 80, CFG2["encoder_dim"], CFG2["hidden_dim"], CFG2["kernel_size"],
+                                             CFG2["encoder_num_layers"]) * B
+        if args.all_kernels:
+            for k, e in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["flops"] else 0.0
+                gb = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+                print("[bench] %-28s calls/step %4d  avg %8.2f us  share %5.1f%%  %8.1f TFLOP/s  %8.1f GB/s(alg)" % (
+                    k, e["calls"] // args.steps, e["ms"] / e["calls"] * 1e3, 100 * e["ms"] / total_ms, tf, gb), file=sys.stderr)
+            print("[bench] instrumented device time per step: %.3f ms" % (total_ms / args.steps), file=sys.stderr)
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            fps, dt = cpu_baseline(enc, T, args.cpu_sample, args.cpu_iters)
+            cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": "oracle/conformer_oracle.py encoder_forward (f32 torch CPU), %d x (80 x %d) of the same workload, "
+                             "1 warm-up + %d timed forwards, %.2f s each" % (args.cpu_sample, T, args.cpu_iters, dt)}
+
+        line = {
+            "metric": "encoder frames/sec (80-d fbank, T=%d), whole job" % T,
+            "value": round(frames_per_s, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "12-layer d=256 h=4 ff=2048 k=15 rel-pos conformer encoder forward (front-end + blocks + after_norm), "
+                                   "batch %d x (80 x %d) synthetic fbank per GPU, random-init weights" % (B, T),
+                       "batch_per_gpu": B, "frames": T, "frames_per_s_per_gpu": round(frames_per_s / world, 1),
+                       "parallelism": "replicas x%d (batch-sharded, no data-path collective)" % world,
+                       "launch": "hip graph replay" if graph is not None else "eager",
+                       "whole_encoder_tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
+                       "whole_encoder_frac_of_mfma_peak": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

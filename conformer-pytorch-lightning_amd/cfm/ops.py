@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "valid_mask", "chunk_mask",
+__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -75,6 +75,37 @@ def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, 
     d.act, d.alpha, d.tile, d.mask_mode = act, alpha, tile, mask_mode
     _c.check(_c.lib().cfm_gemm(ctypes.byref(d), _c.stream()), "cfm_gemm")
     return out
+
+
+def ffn_fused_supported(D, FF, prec):
+    return (not prec.split) and D in (144, 256) and FF % 32 == 0 and FF <= 2048
+
+
+def ffn_fused(x, w1f, w2f, b1, b2, FF, act=_c.ACT_SILU, ln=None, alpha=1.0, add_x=False, ln1=None, ln2=None, out_f32=None,
+              want_f32=True, out16_dtype=None, eps=1e-5):
+    """One-launch feed-forward block (include/cfm.h cfm_ffn_fused).  x f32 [M,D]; ln/ln1/ln2 are (gain, bias) pairs or None.
+    Returns (out_f32 | None, out16 | None)."""
+    _c.require_hip(x, w1f, w2f, b1, b2, out_f32)
+    x = _rows2d(x, "ffn_fused(x)")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("cfm.ffn_fused: x must be contiguous float32 [M,D]")
+    M, D = x.shape
+    d = _c.FfnDesc()
+    d.x, d.w1f, d.w2f, d.b1, d.b2 = _c.ptr(x), _c.ptr(w1f), _c.ptr(w2f), _c.ptr(b1), _c.ptr(b2)
+    for name, pair in (("ln", ln), ("ln1", ln1), ("ln2", ln2)):
+        if pair is not None:
+            setattr(d, name + "_g", _c.ptr(pair[0]))
+            setattr(d, name + "_b", _c.ptr(pair[1]))
+    if want_f32 and out_f32 is None:
+        out_f32 = torch.empty((M, D), dtype=torch.float32, device=x.device)
+    out16 = torch.empty((M, D), dtype=out16_dtype, device=x.device) if out16_dtype is not None else None
+    d.out_f32, d.out16 = _c.ptr(out_f32), _c.ptr(out16)
+    d.M, d.D, d.FF = M, D, FF
+    d.w_dtype = _c.dt_code(w1f)
+    d.out16_dtype = _c.dt_code(out16) if out16 is not None else 0
+    d.act, d.add_x, d.alpha, d.eps = act, 1 if add_x else 0, alpha, eps
+    _c.check(_c.lib().cfm_ffn_fused(ctypes.byref(d), _c.stream()), "cfm_ffn_fused")
+    return out_f32, out16
 
 
 def layernorm(x, g1, b1, out1=None, out1_dtype=None, g2=None, b2=None, out2=None, out2_dtype=None, row_mask=None, eps=1e-5,

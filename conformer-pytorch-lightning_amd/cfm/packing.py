@@ -56,11 +56,34 @@ def glu_interleave_index(D, device):
     return ((idx % 32) // 16) * D + (idx // 32) * 16 + (idx % 16)
 
 
+def pack_ffn_fragments(w1, w2, dtype):
+    """Fragment-major packs for the fused FFN kernel (include/cfm.h cfm_ffn_fused, csrc/ffn.hip).
+
+    w1 [FF,D] -> w1f[ffb][kk][lane][j] = w1[ffb*16 + (lane&15)][kk*32 + 8*(lane>>4) + j]           (K zero-padded to 32)
+    w2 [D,FF] -> w2f[fs][nf][lane][j]  = w2[nf*16 + (lane&15)][fs*32 + (j<4 ? 0 : 16) + 4*(lane>>4) + (j&3)]
+    so that one wavefront-load (lane*16 bytes) is one MFMA A-operand fragment, and the second product's k order is the
+    order in which the first product's accumulators hold the hidden activation.
+    """
+    FF, D = w1.shape
+    ks1 = (D + 31) // 32
+    w1p = torch.zeros((FF, ks1 * 32), dtype=torch.float32, device=w1.device)
+    w1p[:, :D] = w1.detach().float()
+    # [ffb, l15, kk, g, j] -> [ffb, kk, g, l15, j]   (lane = g*16 + l15)
+    w1f = w1p.view(FF // 16, 16, ks1, 4, 8).permute(0, 2, 3, 1, 4).contiguous().to(dtype)
+    # ff = fs*32 + hi*16 + g*4 + r ;  j = hi*4 + r :  [nf, l15, fs, hi, g, r] -> [fs, nf, g, l15, hi, r]
+    w2f = w2.detach().float().view(D // 16, 16, FF // 32, 2, 4, 4).permute(2, 0, 4, 1, 3, 5).contiguous().to(dtype)
+    return w1f.view(-1), w2f.view(-1)
+
+
 def pack_ffn(mod, prec):
     def build():
         w1, w1l = matrix(mod.w_1.weight, prec)
         w2, w2l = matrix(mod.w_2.weight, prec)
-        return Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias))
+        pk = Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias), w1f=None, w2f=None)
+        FF, D = mod.w_1.weight.shape
+        if _c.ffn_fused_supported(D, FF, prec):
+            pk.w1f, pk.w2f = pack_ffn_fragments(mod.w_1.weight, mod.w_2.weight, prec.w_dtype)
+        return pk
     return mod._pack.get([mod.w_1.weight, mod.w_1.bias, mod.w_2.weight, mod.w_2.bias], prec, build)
 
 
@@ -152,6 +175,8 @@ def layer_weight_struct(layer, prec):
         setattr(w, pre + "_w2_lo", _c.ptr(pk.w2_lo))
         setattr(w, pre + "_b1", pk.b1.data_ptr())
         setattr(w, pre + "_b2", pk.b2.data_ptr())
+        setattr(w, pre + "_w1f", _c.ptr(pk.w1f))
+        setattr(w, pre + "_w2f", _c.ptr(pk.w2f))
     w.qkv_w, w.qkv_w_lo, w.qkv_b = att.qkv_w.data_ptr(), _c.ptr(att.qkv_w_lo), att.qkv_b.data_ptr()
     w.pos_w, w.pos_w_lo = _c.ptr(att.pos_w), _c.ptr(att.pos_w_lo)
     w.out_w, w.out_w_lo, w.out_b = att.out_w.data_ptr(), _c.ptr(att.out_w_lo), att.out_b.data_ptr()

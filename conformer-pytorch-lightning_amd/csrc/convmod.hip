@@ -4,9 +4,9 @@
 //                       BatchNorm(eval) affine, SiLU  (convolution.py:43-45).  The GLU in front of it
 //                       is the epilogue of the pointwise-conv-1 GEMM, so the chain GLU->dw->BN->SiLU
 //                       costs one read and one write of [B,T,D].
-//                       A lane owns 2 adjacent channels (coalesced 256 B per wavefront per frame) and a
-//                       32-frame segment; the 32+k-1 input frames are loaded up front (all loads in
-//                       flight together) and the FIR runs out of registers.
+//                       A lane owns 2 adjacent channels (coalesced 256 B per wavefront per frame) and an
+//                       8-frame segment; the 8+k-1 input frames are loaded up front (all loads in flight
+//                       together, the halo re-reads are L2 hits) and the FIR runs out of registers.
 //  cfm_conv1_relu     : Conv2d(1,C,3,stride 2)+ReLU of the fbank image (convolution.py:60-61), written
 //                       channels-last [B,T1,F1,C] so that the second conv is an implicit GEMM whose
 //                       A fragments are contiguous 16-byte loads.
@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int TSEG = 32;
+constexpr int TSEG = 8;  // frames per lane: 32 gave only B*T/32*D/512 = 128 workgroups at config 2 (half the CUs idle)
 
 template <int KTAPS, bool IN_F32>
 __global__ __launch_bounds__(256) void cfm_dwconv_kernel(const void* __restrict__ x, const float* __restrict__ w,
@@ -102,41 +102,61 @@ __global__ __launch_bounds__(256) void cfm_dwconv_generic_kernel(const void* x, 
     }
 }
 
-// one thread: 8 output channels of one (b,t1,f1) position
+// Block = 256 threads = 32 channel-octets x 8 position slots; a thread keeps its 8 channels' 72 weights in registers and
+// walks CONV1_PPT positions, so the weights are fetched once per thread instead of once per output position (the first
+// version re-read them from L1 for every position and was L1-bound at 1.4 TB/s of output).  The 9 fbank taps of a
+// position are the same address for the 32 lanes that share it (one broadcast load each); the 16-byte stores of those
+// lanes are 512 contiguous bytes of the channels-last image.
+constexpr int CONV1_PPT = 8;
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void cfm_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, void* __restrict__ y, int y_dt, int B,
                                                         int T, int F, int T1, int F1, int C) {
-    const int c8n = C >> 3;
-    const int64_t total = (int64_t)B * T1 * F1 * c8n;
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= total) return;
-    const int c0 = (int)(id % c8n) * 8;
-    int64_t pos = id / c8n;
-    const int f1 = (int)(pos % F1);
-    pos /= F1;
-    const int t1 = (int)(pos % T1);
-    const int b = (int)(pos / T1);
-    f32x4 a0 = *(const f32x4*)(bias + c0), a1 = *(const f32x4*)(bias + c0 + 4);
-    const float* xp = x + ((int64_t)b * T + 2 * t1) * F + 2 * f1;
+    const int c8n = C >> 3;                      // channel octets; blockDim.x = 256 covers 256/c8n position slots ... see host
+    const int oct = threadIdx.x % c8n;
+    const int slot = threadIdx.x / c8n;
+    const int slots = 256 / c8n;
+    const int c0 = oct * 8;
+    const int64_t npos = (int64_t)B * T1 * F1;
+    f32x4 w0[9], w1[9];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
+    for (int k = 0; k < 9; ++k) {
+        w0[k] = *(const f32x4*)(w + k * C + c0);
+        w1[k] = *(const f32x4*)(w + k * C + c0 + 4);
+    }
+    const f32x4 b0 = *(const f32x4*)(bias + c0), b1 = *(const f32x4*)(bias + c0 + 4);
+    const int64_t first = ((int64_t)blockIdx.x * CONV1_PPT) * slots + slot;
 #pragma unroll
-        for (int kf = 0; kf < 3; ++kf) {
-            const float xv = xp[kt * F + kf];
-            const float* wp = w + (kt * 3 + kf) * C + c0;
-            a0 += xv * *(const f32x4*)wp;
-            a1 += xv * *(const f32x4*)(wp + 4);
+    for (int it = 0; it < CONV1_PPT; ++it) {
+        const int64_t pos = first + (int64_t)it * slots;
+        if (pos >= npos) break;
+        const int f1 = (int)(pos % F1);
+        const int64_t bt = pos / F1;
+        const int t1 = (int)(bt % T1);
+        const int b = (int)(bt / T1);
+        const float* xp = x + ((int64_t)b * T + 2 * t1) * F + 2 * f1;
+        float xv[9];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) xv[kt * 3 + kf] = xp[kt * F + kf];
+        f32x4 a0 = b0, a1 = b1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            a0 += xv[k] * w0[k];
+            a1 += xv[k] * w1[k];
         }
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    a0 = __builtin_elementwise_max(a0, z);
-    a1 = __builtin_elementwise_max(a1, z);
-    const int64_t o = (((int64_t)b * T1 + t1) * F1 + f1) * C + c0;
-    if constexpr (OUT_F32) {
-        *(f32x4*)((float*)y + o) = a0;
-        *(f32x4*)((float*)y + o + 4) = a1;
-    } else {
-        *(u32x4*)((u16*)y + o) = y_dt == CFM_BF16 ? pack8<BF16>(a0, a1) : pack8<F16>(a0, a1);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        a0 = __builtin_elementwise_max(a0, z);
+        a1 = __builtin_elementwise_max(a1, z);
+        const int64_t o = pos * C + c0;
+        if constexpr (OUT_F32) {
+            *(f32x4*)((float*)y + o) = a0;
+            *(f32x4*)((float*)y + o + 4) = a1;
+        } else {
+            *(u32x4*)((u16*)y + o) = y_dt == CFM_BF16 ? pack8<BF16>(a0, a1) : pack8<F16>(a0, a1);
+        }
     }
 }
 
@@ -198,12 +218,16 @@ extern "C" int cfm_conv1_relu(const float* x, const float* w, const float* bias,
                               int32_t F, int32_t C, cfm_stream_t stream) {
     CFM_CHECK_ARG(x && w && bias && y, "cfm_conv1_relu: null pointer");
     CFM_CHECK_ARG(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 8 == 0, "cfm_conv1_relu: bad shape B=%d T=%d F=%d C=%d", B, T, F, C);
+    CFM_CHECK_ARG(C / 8 <= 256, "cfm_conv1_relu: C=%d too wide (max 2048)", C);
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
     const int64_t total = (int64_t)B * T1 * F1 * (C / 8);
+    const int slots = 256 / (C / 8);                         // position slots per block (threads beyond slots*C/8 idle)
+    const int64_t npos = (int64_t)B * T1 * F1;
+    const int64_t nblocks = (npos + (int64_t)slots * CONV1_PPT - 1) / ((int64_t)slots * CONV1_PPT);
     hipStream_t s = (hipStream_t)stream;
     const double bytes = (double)B * T * F * 4 + (double)total * 8 * cfm_elt_size(y_dtype);
     CfmProfScope prof("conv1_relu", s, 2.0 * 9 * (double)total * 8, bytes);
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const dim3 grid((unsigned)nblocks), block((unsigned)(slots * (C / 8)));
     if (y_dtype == CFM_F32)
         hipLaunchKernelGGL((cfm_conv1_kernel<true>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
     else

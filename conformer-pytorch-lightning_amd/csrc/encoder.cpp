@@ -1,4 +1,4 @@
-// encoder.cpp -- composite: one conformer block enqueued from C++ (17 launches, no host sync).
+// encoder.cpp -- composite: one conformer block enqueued from C++ (10 launches with the fused FFN, no host sync).
 //
 // Mirrors reference src/encoder_layer.py:49-71:
 //   x = x + 1/2 FFNm(LN(x)); x = x + MHSA(LN(x)); x = x + Conv(LN(x)); x = x + 1/2 FFN(LN(x)); out = LN(x)
@@ -27,6 +27,17 @@ int gemm(const Ctx& c, const void* A, int a_dt, int64_t lda, const void* W, cons
     d.a_dtype = a_dt; d.w_dtype = c.w_dt; d.c_dtype = c_dt; d.act = act; d.alpha = alpha;
     if (c.split && !Wlo) return cfm_fail(CFM_ERR_ARG, "encoder layer: split mode needs the *_lo weight planes");
     return cfm_gemm(&d, c.st);
+}
+
+int ffn_fused(const Ctx& c, const float* x, const float* ln_g, const float* ln_b, const void* w1f, const void* w2f, const float* b1,
+              const float* b2, const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float* out_f32,
+              void* out16) {
+    cfm_ffn_desc d = {};
+    d.x = x; d.ln_g = ln_g; d.ln_b = ln_b; d.w1f = w1f; d.w2f = w2f; d.b1 = b1; d.b2 = b2;
+    d.ln1_g = ln1_g; d.ln1_b = ln1_b; d.ln2_g = ln2_g; d.ln2_b = ln2_b; d.out_f32 = out_f32; d.out16 = out16;
+    d.M = c.M; d.D = c.D; d.FF = c.FF; d.w_dtype = c.w_dt; d.out16_dtype = c.act_dt; d.act = CFM_ACT_SILU; d.add_x = 1;
+    d.alpha = 0.5f; d.eps = 1e-5f;
+    return cfm_ffn_fused(&d, c.st);
 }
 
 #define CFM_TRY(expr)            \
@@ -63,13 +74,22 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     }
     CFM_CHECK_ARG(Tc == 0 || io->new_cache, "encoder layer: a KV cache input needs new_cache storage");
 
-    // (1) macaron feed-forward: x1 = x + 1/2 W2 silu(W1 LN(x))
-    if (!xn_ready) CFM_TRY(cfm_layernorm(x_in, w->ln_ffm_g, w->ln_ffm_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
-    CFM_TRY(gemm(c, s->xn, adt, D, w->ffm_w1, w->ffm_w1_lo, w->ffm_b1, s->hid, adt, FF, M, FF, D, CFM_ACT_SILU, nullptr, 0.f, nullptr));
-    CFM_TRY(gemm(c, s->hid, adt, FF, w->ffm_w2, w->ffm_w2_lo, w->ffm_b2, x_out, CFM_F32, D, M, D, FF, CFM_ACT_NONE, x_in, 0.5f, nullptr));
+    // The fused feed-forward kernel (ffn.hip) covers LN + W1 + SiLU + W2 + residual (+ the following norms) in one launch.
+    const bool fused_ffn = !c.split && w->ffm_w1f && w->ffm_w2f && w->ff_w1f && w->ff_w2f && (D == 144 || D == 256) &&
+                           FF % 32 == 0 && FF <= 2048;
+
+    // (1) macaron feed-forward: x1 = x + 1/2 W2 silu(W1 LN(x));  (2a) norm_mha
+    if (fused_ffn) {
+        CFM_TRY(ffn_fused(c, x_in, w->ln_ffm_g, w->ln_ffm_b, w->ffm_w1f, w->ffm_w2f, w->ffm_b1, w->ffm_b2, nullptr, nullptr,
+                          w->ln_mha_g, w->ln_mha_b, x_out, s->xn));
+    } else {
+        if (!xn_ready) CFM_TRY(cfm_layernorm(x_in, w->ln_ffm_g, w->ln_ffm_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
+        CFM_TRY(gemm(c, s->xn, adt, D, w->ffm_w1, w->ffm_w1_lo, w->ffm_b1, s->hid, adt, FF, M, FF, D, CFM_ACT_SILU, nullptr, 0.f, nullptr));
+        CFM_TRY(gemm(c, s->hid, adt, FF, w->ffm_w2, w->ffm_w2_lo, w->ffm_b2, x_out, CFM_F32, D, M, D, FF, CFM_ACT_NONE, x_in, 0.5f, nullptr));
+        CFM_TRY(cfm_layernorm(x_out, w->ln_mha_g, w->ln_mha_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
+    }
 
     // (2) self-attention
-    CFM_TRY(cfm_layernorm(x_out, w->ln_mha_g, w->ln_mha_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
     CFM_TRY(gemm(c, s->xn, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, s->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr));
     if (has_pos)
         CFM_TRY(gemm(c, io->pos_embed, CFM_F32, D, w->pos_w, w->pos_w_lo, nullptr, s->pos, adt, D, io->pos_rows, D, D, CFM_ACT_NONE,
@@ -106,7 +126,10 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
     CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, io->pad_valid));
 
-    // (4) feed-forward
+    // (4) feed-forward + (5) norm_final: in place on x_out (a workgroup reads its 32 rows completely before writing them)
+    if (fused_ffn)
+        return ffn_fused(c, x_out, w->ln_ff_g, w->ln_ff_b, w->ff_w1f, w->ff_w2f, w->ff_b1, w->ff_b2, w->ln_final_g, w->ln_final_b,
+                         nullptr, nullptr, x_out, nullptr);
     CFM_TRY(cfm_layernorm(x_out, w->ln_ff_g, w->ln_ff_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
     CFM_TRY(gemm(c, s->xn, adt, D, w->ff_w1, w->ff_w1_lo, w->ff_b1, s->hid, adt, FF, M, FF, D, CFM_ACT_SILU, nullptr, 0.f, nullptr));
     CFM_TRY(gemm(c, s->hid, adt, FF, w->ff_w2, w->ff_w2_lo, w->ff_b2, x_out, CFM_F32, D, M, D, FF, CFM_ACT_NONE, x_out, 0.5f, nullptr));

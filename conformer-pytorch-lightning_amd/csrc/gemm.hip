@@ -16,6 +16,7 @@
 //     hi/lo planes, 3 MFMAs per fragment pair (hi*lo + lo*hi + hi*hi): ~16 mantissa bits.
 //   * every edge is predicated: rows clamp on load / predicate on store, K tail chunks load zeros.
 #include <string>
+#include <type_traits>
 
 #include "cfm_common.h"
 
@@ -87,14 +88,18 @@ __global__ __launch_bounds__(256) void cfm_gemm_kernel(const GemmArgs g) {
         w_off[j] = (int64_t)n * g.K;
     }
 
-    u32x4 ra[A_F32 ? 1 : ACH];
-    f32x4 fa[A_F32 ? ACH : 1][2];
-    u32x4 rw[WCH];
-    u32x4 rwl[SPLIT ? WCH : 1];
+    // register prefetch ring: PF K-tiles in flight per workgroup.  The K loops here are SHORT (4 tiles at K=256) and the
+    // grids small (250-1000 workgroups on 256 CUs), so occupancy cannot hide global-load latency; depth has to.
+    constexpr int PF = A_F32 ? 2 : 3;
+    u32x4 ra[PF][A_F32 ? 1 : ACH];
+    f32x4 fa[PF][A_F32 ? ACH : 1][2];
+    u32x4 rw[PF][WCH];
+    u32x4 rwl[PF][SPLIT ? WCH : 1];
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
 
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
         const int k0 = kt * BK + kc * 8;
         const bool kv = k0 < g.K;
         int64_t koff = k0;
@@ -109,20 +114,21 @@ __global__ __launch_bounds__(256) void cfm_gemm_kernel(const GemmArgs g) {
         for (int i = 0; i < ACH; ++i) {
             if constexpr (A_F32) {
                 const f32x4* p = (const f32x4*)((const float*)g.A + a_off[i] + koff);
-                fa[i][0] = kv ? p[0] : zf;
-                fa[i][1] = kv ? p[1] : zf;
+                fa[S][i][0] = kv ? p[0] : zf;
+                fa[S][i][1] = kv ? p[1] : zf;
             } else {
-                ra[i] = kv ? *(const u32x4*)((const u16*)g.A + a_off[i] + koff) : z4;
+                ra[S][i] = kv ? *(const u32x4*)((const u16*)g.A + a_off[i] + koff) : z4;
             }
         }
 #pragma unroll
         for (int j = 0; j < WCH; ++j) {
-            rw[j] = kv ? *(const u32x4*)(g.W + w_off[j] + k0) : z4;
-            if constexpr (SPLIT) rwl[j] = kv ? *(const u32x4*)(g.Wlo + w_off[j] + k0) : z4;
+            rw[S][j] = kv ? *(const u32x4*)(g.W + w_off[j] + k0) : z4;
+            if constexpr (SPLIT) rwl[S][j] = kv ? *(const u32x4*)(g.Wlo + w_off[j] + k0) : z4;
         }
     };
 
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
         u32x4* As = smem + buf * BUF;
         u32x4* Ws = As + A_PLANE * NPL;
 #pragma unroll
@@ -130,20 +136,20 @@ __global__ __launch_bounds__(256) void cfm_gemm_kernel(const GemmArgs g) {
             const int idx = lds_idx(i * RPP + rl, kc);
             if constexpr (SPLIT) {
                 u32x4 hi, lo;
-                split8(fa[i][0], fa[i][1], hi, lo);
+                split8(fa[S][i][0], fa[S][i][1], hi, lo);
                 As[idx] = hi;
                 As[A_PLANE + idx] = lo;
             } else if constexpr (A_F32) {
-                As[idx] = pack8<HT>(fa[i][0], fa[i][1]);
+                As[idx] = pack8<HT>(fa[S][i][0], fa[S][i][1]);
             } else {
-                As[idx] = ra[i];
+                As[idx] = ra[S][i];
             }
         }
 #pragma unroll
         for (int j = 0; j < WCH; ++j) {
             const int idx = lds_idx(j * RPP + rl, kc);
-            Ws[idx] = rw[j];
-            if constexpr (SPLIT) Ws[W_PLANE + idx] = rwl[j];
+            Ws[idx] = rw[S][j];
+            if constexpr (SPLIT) Ws[W_PLANE + idx] = rwl[S][j];
         }
     };
 
@@ -186,51 +192,78 @@ __global__ __launch_bounds__(256) void cfm_gemm_kernel(const GemmArgs g) {
         }
     };
 
-    // ---- main loop ----------------------------------------------------------------------------
+    // ---- main loop: 2 LDS buffers, 1 barrier per K tile, PF tiles of global loads in flight ------------------
     const int nkt = (g.K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) gload(kt + 1);
-        compute(kt & 1);
-        if (more) lstore((kt + 1) & 1);
+    auto prologue = [&](auto s) {
+        if (decltype(s)::value < nkt) gload(decltype(s)::value, s);
+    };
+    auto body = [&](int kt, auto s) {           // tile kt lives in register slot s = kt % PF
+        lstore(kt & 1, s);                       // waits (compiler-counted vmcnt) for tile kt only
+        if (kt + PF < nkt) gload(kt + PF, s);    // refill the slot that was just drained
         __syncthreads();
+        compute(kt & 1);
+    };
+    prologue(std::integral_constant<int, 0>{});
+    prologue(std::integral_constant<int, 1>{});
+    if constexpr (PF > 2) prologue(std::integral_constant<int, 2>{});
+    for (int kt0 = 0; kt0 < nkt; kt0 += PF) {
+        body(kt0, std::integral_constant<int, 0>{});
+        if (kt0 + 1 < nkt) body(kt0 + 1, std::integral_constant<int, 1>{});
+        if constexpr (PF > 2) {
+            if (kt0 + 2 < nkt) body(kt0 + 2, std::integral_constant<int, 2>{});
+        }
     }
 
-    // ---- epilogue -----------------------------------------------------------------------------
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // All global READS of the epilogue are issued in one batch before the first store: C may alias `residual`
+    // (in-place accumulate) and the compiler cannot prove it does not alias `bias`, so a load placed after a store is
+    // serialised behind it -- 16 fragments x one exposed L2 latency each (measured: +6 us per launch for the bias alone).
     const bool glu = g.act == CFM_ACT_GLU;
+    const int q4 = (lane >> 4) * 4;
+    f32x4 bias_r[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wc * (BN / 2) + j * 16 + q4;
+        bias_r[j] = (g.bias && col < g.N) ? *(const f32x4*)(g.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bool keep_r[FM];
+    f32x4 res_r[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
+        keep_r[i] = (g.mask && row < g.M) ? (g.mask[row] != 0) : true;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int cb = n0 + wc * (BN / 2) + j * 16;
+            const int col = cb + q4;
+            const int ocol = glu ? (cb >> 1) + q4 : col;
+            const bool live = g.res && row < g.M && col < g.N && !(glu && (j & 1));
+            res_r[i][j] = live ? *(const f32x4*)(g.res + (int64_t)row * g.ldr + ocol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
         if (row >= g.M) continue;
-        const bool keep = g.mask ? (g.mask[row] != 0) : true;
+        const bool keep = keep_r[i];
+        const bool in_dead = !keep && g.mask_mode == 1;  // masked INPUT row: x.W = 0, bias/act still apply
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             if (glu && (j & 1)) continue;
             const int cb = n0 + wc * (BN / 2) + j * 16;  // first GEMM column of this fragment
-            const int col = cb + (lane >> 4) * 4;
+            const int col = cb + q4;
             if (col >= g.N) continue;
-            const bool in_dead = !keep && g.mask_mode == 1;  // masked INPUT row: x.W = 0, bias/act still apply
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (in_dead) v[0] = v[1] = v[2] = v[3] = 0.f;
-            if (g.bias) {
-                const f32x4 b = *(const f32x4*)(g.bias + col);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
+            f32x4 v = in_dead ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j];
+            v += bias_r[j];
             int ocol = col;
             if (glu) {
-                const int jn = (j + 1 < FN) ? j + 1 : j;  // FN is even; keeps the index static
-                float gt[4] = {acc[i][jn][0], acc[i][jn][1], acc[i][jn][2], acc[i][jn][3]};
-                if (in_dead) gt[0] = gt[1] = gt[2] = gt[3] = 0.f;
-                if (g.bias) {
-                    const f32x4 b = *(const f32x4*)(g.bias + col + 16);
-                    gt[0] += b.x; gt[1] += b.y; gt[2] += b.z; gt[3] += b.w;
-                }
+                constexpr int JN_MAX = FN - 1;
+                const int jn = j + 1 <= JN_MAX ? j + 1 : JN_MAX;  // FN is even; keeps the index static
+                f32x4 gt = in_dead ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][jn];
+                gt += bias_r[jn];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= sigmoidf_(gt[r]);
-                ocol = (cb >> 1) + (lane >> 4) * 4;
+                ocol = (cb >> 1) + q4;
             } else if (g.act == CFM_ACT_SILU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = siluf_(v[r]);
@@ -238,17 +271,11 @@ __global__ __launch_bounds__(256) void cfm_gemm_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (!keep && g.mask_mode == 0) v[0] = v[1] = v[2] = v[3] = 0.f;
-            if (g.res) {
-                const f32x4 rr = *(const f32x4*)(g.res + (int64_t)row * g.ldr + ocol);
-                v[0] = rr.x + g.alpha * v[0];
-                v[1] = rr.y + g.alpha * v[1];
-                v[2] = rr.z + g.alpha * v[2];
-                v[3] = rr.w + g.alpha * v[3];
-            }
+            if (!keep && g.mask_mode == 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (g.res) v = res_r[i][j] + g.alpha * v;
             const int64_t o = (int64_t)row * g.ldc + ocol;
             if (g.c_dtype == CFM_F32) {
-                *(f32x4*)((float*)g.C + o) = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)((float*)g.C + o) = v;
             } else if (g.c_dtype == CFM_BF16) {
                 *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])};
             } else {
@@ -288,8 +315,12 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
         case 1: return launch<HT, 128, 128, BK, A_F32, SPLIT, CONV>(a, s, base);
         case 2: return launch<HT, 64, 128, BK, A_F32, SPLIT, CONV>(a, s, base);
         case 3: return launch<HT, 64, 64, BK, A_F32, SPLIT, CONV>(a, s, base);
-        default: return cfm_fail(CFM_ERR_ARG, "cfm_gemm: unknown tile id %d", tile);
+        case 4: return launch<HT, 128, 64, BK, A_F32, SPLIT, CONV>(a, s, base);
+        case 5: if constexpr (!SPLIT) return launch<HT, 32, 64, BK, A_F32, SPLIT, CONV>(a, s, base); else break;
+        case 6: if constexpr (!SPLIT) return launch<HT, 32, 128, BK, A_F32, SPLIT, CONV>(a, s, base); else break;
+        default: break;
     }
+    return cfm_fail(CFM_ERR_ARG, "cfm_gemm: unknown tile id %d", tile);
 }
 
 }  // namespace

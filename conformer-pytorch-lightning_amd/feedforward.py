@@ -2,8 +2,9 @@
 
 Drop-in for the reference's ``src/feedforward.py`` (class name, constructor arguments, parameter names
 ``w_1.{weight,bias}`` / ``w_2.{weight,bias}`` and ``forward(inputs)`` are the reference's, feedforward.py:4-21).
-The arithmetic is two calls into libconformer_gfx950: an MFMA GEMM whose epilogue adds the bias and applies
-SiLU/ReLU and writes the 16-bit hidden activation, and a second GEMM whose epilogue adds the output bias.
+The arithmetic is ONE launch of the fused feed-forward kernel of libconformer_gfx950 (csrc/ffn.hip: W1, bias, SiLU/ReLU, W2,
+bias with the hidden activation kept in registers) when the shape has a fused instance, otherwise two MFMA GEMMs whose
+epilogues carry the bias / activation.
 """
 import torch
 import torch.nn as nn
@@ -42,6 +43,9 @@ class PositionwiseFeedForwardModule(nn.Module):
             x = x.float()
         x = x.contiguous()
         act = cfm.ACT_SILU if isinstance(self.activation, nn.SiLU) else cfm.ACT_RELU
+        if pk.w1f is not None and x.dtype == torch.float32:
+            out, _ = cfm.ffn_fused(x, pk.w1f, pk.w2f, pk.b1, pk.b2, self.w_1.weight.shape[0], act=act)
+            return out.view(*inputs.shape[:-1], out.shape[-1]).to(inputs.dtype)
         hid = cfm.gemm(x, pk.w1, bias=pk.b1, w_lo=pk.w1_lo, act=act, out_dtype=prec.act_dtype)
         out = cfm.gemm(hid, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, out_dtype=torch.float32)
         return out.view(*inputs.shape[:-1], out.shape[-1]).to(inputs.dtype)

@@ -91,6 +91,37 @@ typedef struct {
 int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused feed-forward block (one launch; the [M,FF] hidden activation never reaches memory):
+ *     y  = (add_x ? x : 0) + alpha * ( W2 . act( W1 . LN(x; ln_g, ln_b) + b1 ) + b2 )
+ *     y1 = ln1_g ? LN(y; ln1_g, ln1_b) : y        -> out_f32 (if non-NULL)
+ *     y2 = ln2_g ? LN(y1; ln2_g, ln2_b) : y1      -> out16   (if non-NULL, 16-bit)
+ * replaces norm + feed_forward(_macaron) + the residual add of encoder_layer.py:56-58 / :67-69 (and :70 through ln1,
+ * the next sub-block's norm through ln2).  ln_g == NULL: no input LayerNorm (feedforward.py:16-21 on its own).
+ *  x     f32 [M,D];  D in {144, 256};  FF % 32 == 0, FF <= 2048
+ *  w1f   W1 [FF,D] packed fragment-major (see cfm/packing.py pack_ffn_fragments): 16-bit
+ *        w1f[((ffb*KS1 + kk)*64 + lane)*8 + j] = W1[ffb*16 + (lane&15)][kk*32 + 8*(lane>>4) + j]   (0 for k >= D)
+ *  w2f   W2 [D,FF] packed fragment-major with the k order of each 32-block permuted to accumulator order:
+ *        w2f[((fs*(D/16) + nf)*64 + lane)*8 + j] = W2[nf*16 + (lane&15)][fs*32 + (j<4 ? 0 : 16) + 4*(lane>>4) + (j&3)]
+ */
+typedef struct {
+    const float* x;
+    const float *ln_g, *ln_b;
+    const void *w1f, *w2f;
+    const float *b1, *b2;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float* out_f32;
+    void* out16;
+    int64_t M;
+    int32_t D, FF;
+    int32_t w_dtype, out16_dtype;
+    int32_t act;   /* CFM_ACT_SILU | CFM_ACT_RELU */
+    int32_t add_x;
+    float alpha, eps;
+} cfm_ffn_desc;
+
+int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LayerNorm (eps inside sqrt, biased variance), optionally two chained norms in one pass:
  *   y1 = LN(x; g1, b1);  if out1: out1 = y1 (out1_dtype)
  *   if g2:  y2 = LN(y1; g2, b2) else y2 = y1;  if out2: out2 = row_mask[m] ? y2 : 0  (out2_dtype)
@@ -188,6 +219,8 @@ typedef struct {
     const float *ffm_b1, *ffm_b2;
     const void *ff_w1, *ff_w1_lo, *ff_w2, *ff_w2_lo;
     const float *ff_b1, *ff_b2;
+    /* optional fragment-major packs for cfm_ffn_fused (NULL: the two-GEMM path is used) */
+    const void *ffm_w1f, *ffm_w2f, *ff_w1f, *ff_w2f;
     /* attention: fused qkv [3D,D], pos [D,D] (NULL for plain MHSA), out [D,D] */
     const void *qkv_w, *qkv_w_lo, *pos_w, *pos_w_lo, *out_w, *out_w_lo;
     const float *qkv_b, *out_b, *bias_u, *bias_v;

@@ -306,3 +306,50 @@ def test_profiling_table(cfm):
     (name, e), = tab.items()
     assert name.startswith("gemm_bf16") and e["calls"] == 5 and e["ms"] > 0 and e["flops"] == 5 * 2.0 * 512 * 256 * 256
     cfm.prof_reset()
+
+
+@pytest.mark.parametrize("M,D,FF", [(7968, 256, 2048), (98, 144, 576), (33, 256, 2048), (5, 144, 64), (64, 256, 160)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+@pytest.mark.parametrize("act", ["silu", "relu"])
+def test_ffn_fused(cfm, M, D, FF, wdt, act):
+    """One-launch LN -> W1 -> act -> W2 -> residual -> LN -> LN against the same chain in torch f32."""
+    from cfm import packing
+    dt = W_DT[wdt]
+    x = rnd((M, D), 90, 1.5) + 0.3
+    w1 = rnd((FF, D), 91, D ** -0.5)
+    w2 = rnd((D, FF), 92, FF ** -0.5)
+    b1, b2 = rnd((FF,), 93, 0.1), rnd((D,), 94, 0.1)
+    lns = [(1 + 0.1 * rnd((D,), 95 + i), 0.1 * rnd((D,), 98 + i)) for i in range(3)]
+    w1f, w2f = packing.pack_ffn_fragments(w1, w2, dt)
+    actf = torch.nn.functional.silu if act == "silu" else torch.relu
+    code = cfm.ACT_SILU if act == "silu" else cfm.ACT_RELU
+
+    def ref(x, ln, alpha, add_x, ln1, ln2):
+        a = torch.nn.functional.layer_norm(x, (D,), ln[0], ln[1], 1e-5) if ln else x
+        h = actf(a.to(dt).float() @ w1.to(dt).float().t() + b1)
+        y = alpha * (h.to(dt).float() @ w2.to(dt).float().t() + b2)
+        if add_x:
+            y = y + x
+        y1 = torch.nn.functional.layer_norm(y, (D,), ln1[0], ln1[1], 1e-5) if ln1 else y
+        y2 = torch.nn.functional.layer_norm(y1, (D,), ln2[0], ln2[1], 1e-5) if ln2 else y1
+        return y1, y2
+
+    tol = 6e-3 if wdt == "bf16" else 8e-4          # the hidden activation is rounded to 16 bit before the second product
+    # macaron form: LN in, residual, second norm to a 16-bit operand
+    x0 = x.clone()
+    o32, o16 = cfm.ffn_fused(x, w1f, w2f, b1, b2, FF, act=code, ln=lns[0], alpha=0.5, add_x=True, ln2=lns[2], out16_dtype=dt)
+    r1, r2 = ref(x, lns[0], 0.5, True, None, lns[2])
+    assert torch.equal(x, x0)
+    assert relerr(o32, r1) < tol and relerr(o16.float(), r2) < tol + (1e-2 if wdt == "bf16" else 2e-3)
+    # final form: LN in, residual, norm_final, IN PLACE
+    xi = x.clone()
+    cfm.ffn_fused(xi, w1f, w2f, b1, b2, FF, act=code, ln=lns[0], alpha=0.5, add_x=True, ln1=lns[1], out_f32=xi)
+    r1, _ = ref(x, lns[0], 0.5, True, lns[1], None)
+    assert relerr(xi, r1) < tol
+    # bare module form: no norms, no residual
+    o32, _ = cfm.ffn_fused(x, w1f, w2f, b1, b2, FF, act=code)
+    r1, _ = ref(x, None, 1.0, False, None, None)
+    assert relerr(o32, r1) < tol
+    # bitwise reproducible
+    o32b, _ = cfm.ffn_fused(x, w1f, w2f, b1, b2, FF, act=code)
+    assert torch.equal(o32, o32b)
