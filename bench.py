@@ -66,6 +66,57 @@ def cpu_baseline(enc, frames, sample_batch, iters):
     return sample_batch * frames / dt, dt
 
 
+def timed_region(step, steps, warmup, dist, sync):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides; MAX over ranks."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        if torch.cuda.is_available() and dist.get_backend() == "nccl":
+            tmax = tmax.cuda()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed
+
+
+def selftest_cpu(args):
+    """gloo / CPU rehearsal of the multi-process harness (no HIP call): same barrier, MAX-over-ranks and aggregation
+    code as the real run, with a dummy step.  Used by tests/test_bench_multiproc.py."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    a = torch.randn(64, 64)
+
+    def step():
+        time.sleep(0.002 * (rank + 1))          # ranks deliberately unequal: the MAX must win
+        (a @ a).sum().item()
+
+    elapsed = timed_region(step, args.steps, args.warmup, dist, lambda: None)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": world * args.batch * args.frames * args.steps / elapsed, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "selftest",
+                          "config": {"workload": "cpu selftest of the launch/timing harness"}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +130,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8, help="utterances in the CPU-baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--all-kernels", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--selftest-cpu", action="store_true", help="gloo/CPU rehearsal of the multi-process harness (tests only)")
     args = ap.parse_args()
+    if args.selftest_cpu:
+        return selftest_cpu(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,23 +185,7 @@ def main():
             else:
                 enc(x, lens)
 
-        def barrier():
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize(device)
-
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+        elapsed = timed_region(step, args.steps, args.warmup, dist, lambda: torch.cuda.synchronize(device))
 
         # ---- instrumented pass: per-kernel HIP events on the launch stream (eager launches, same K steps) ----------
         roofline = None

@@ -1,0 +1,31 @@
+"""CPU, world_size 2, gloo: the multi-process launch path of bench.py (one process per rank via torch.distributed.run,
+barrier + MAX-over-ranks timing, rank 0 prints exactly one JSON line, whole-job aggregate)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def test_bench_harness_two_ranks_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-cpu"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    # rank 1 sleeps 4 ms per step, rank 0 only 2 ms: the MAX over ranks must be what is reported
+    assert rec["ms_per_step"] >= 3.9
+    assert abs(rec["value"] - 2 * 32 * 1000 * 5 / (rec["ms_per_step"] * 5 / 1e3)) / rec["value"] < 1e-6
+
+
+def test_bench_harness_single_process():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--selftest-cpu"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["ms_per_step"] >= 1.9
