@@ -17,6 +17,8 @@
 // conflict-free); V is staged transposed with a padded row stride (ds_read_b64, conflict-free).
 //
 // SPLIT evaluates every product as hi*hi + lo*hi + hi*lo on bf16 hi/lo planes (f32-accurate mode).
+#include <stdlib.h>
+
 #include "cfm_common.h"
 
 struct AttnArgs {
@@ -257,6 +259,241 @@ __global__ __launch_bounds__(256) void cfm_attn_kernel(const AttnArgs a) {
     }
 }
 
+// =============================================================================================
+// v2: d_k == 64, 16-bit q/p, non-split.  Same maths and the same swapped MFMA orientation as cfm_attn_kernel, but
+//   * K, V (and the per-key positional rows) of up to 256 keys are staged ONCE into LDS with 16-byte copies and one
+//     barrier; the 4 wavefronts then walk the key tiles independently (v1: restage + 2 barriers per 64 keys);
+//   * V stays ROW-major in LDS and is consumed column-wise with ds_read_b64_tr_b16 (the hardware transpose read) --
+//     v1 transposed it with 2-byte LDS writes;
+//   * the batch path's positional term (one p row per utterance) is a per-query constant:
+//     bd_i = round(q_i + v) . p_b is one 64-long dot product per query, not an MFMA against a broadcast tile;
+//   * masks are staged into LDS once (a key-validity row when there is no mask / a (B,1,Tk) mask; 64 rows for (B,Tq,Tk)).
+// =============================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SK = 256;        // keys resident per super-tile
+constexpr int V2STR = 72;      // V row stride in 16-bit elements (144 B)
+constexpr int MLSTR = SK + 4;  // mask row stride in bytes
+
+template <typename HT>
+__device__ __forceinline__ u32x4 load_row8(const void* base, int dt, int64_t off) {  // 8 consecutive elements -> 16-bit x8
+    if (dt == CFM_F32) {
+        const f32x4 a = *(const f32x4*)((const float*)base + off);
+        const f32x4 b = *(const f32x4*)((const float*)base + off + 4);
+        return pack8<HT>(a, b);
+    }
+    return *(const u32x4*)((const u16*)base + off);
+}
+
+template <typename HT, int PMODE, bool MFULL>
+__global__ __launch_bounds__(256) void cfm_attn2_kernel(const AttnArgs a) {
+    __shared__ u32x4 Kl[SK * 8];
+    __shared__ u32x4 Pl[PMODE == 2 ? SK * 8 : 1];
+    __shared__ __attribute__((aligned(16))) u16 Vl[SK * V2STR];
+    __shared__ __attribute__((aligned(16))) uint8_t Ml[(MFULL ? QT : 1) * MLSTR];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * QT;
+    const int qi = q0 + wave * 16 + l15;
+    const int qc = qi < a.Tq ? qi : a.Tq - 1;
+    constexpr int dk = 64;
+
+    // ---- Q~ fragments: q + u (and q + v) rounded to the MFMA operand type ----------------------------------------
+    u32x4 qu[2], qv[2];
+    float bd = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int d0 = kk * 32 + g * 8;
+        const u32x4 raw = *(const u32x4*)((const u16*)a.q + (int64_t)b * a.q_sb + (int64_t)qc * a.q_st + h * dk + d0);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = HT::to_f32((u16)(w[i] & 0xffffu));
+            f[2 * i + 1] = HT::to_f32((u16)(w[i] >> 16));
+        }
+        if constexpr (PMODE == 0) {
+            qu[kk] = raw;
+        } else {
+            const f32x4 u0 = *(const f32x4*)(a.bias_u + h * dk + d0), u1 = *(const f32x4*)(a.bias_u + h * dk + d0 + 4);
+            const f32x4 v0 = *(const f32x4*)(a.bias_v + h * dk + d0), v1 = *(const f32x4*)(a.bias_v + h * dk + d0 + 4);
+            const f32x4 fa = {f[0], f[1], f[2], f[3]}, fb = {f[4], f[5], f[6], f[7]};
+            qu[kk] = pack8<HT>(fa + u0, fb + u1);
+            qv[kk] = pack8<HT>(fa + v0, fb + v1);
+            if constexpr (PMODE == 1) {   // bd_i = (q_i + v) . p_b : the lane's 8 d-values of this kk
+                const u32x4 pr = *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + h * dk + d0);
+                const unsigned pw[4] = {pr.x, pr.y, pr.z, pr.w}, qw[4] = {qv[kk].x, qv[kk].y, qv[kk].z, qv[kk].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bd = fmaf(HT::to_f32((u16)(qw[i] & 0xffffu)), HT::to_f32((u16)(pw[i] & 0xffffu)), bd);
+                    bd = fmaf(HT::to_f32((u16)(qw[i] >> 16)), HT::to_f32((u16)(pw[i] >> 16)), bd);
+                }
+            }
+        }
+    }
+    if constexpr (PMODE == 1) {
+        bd += __shfl_xor(bd, 16, 64);
+        bd += __shfl_xor(bd, 32, 64);
+    }
+
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int ks = 0; ks < a.Tk; ks += SK) {
+        if (ks) __syncthreads();  // everyone is done with the previous super-tile
+        // ---- stage up to 256 keys: 16-byte copies, all loads issued before the first LDS write -------------------
+        {
+            u32x4 kr[8], vr[8], pr[PMODE == 2 ? 8 : 1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = i * 256 + tid;
+                const int key = id >> 3, c = id & 7;
+                const int kj = ks + key;
+                const bool ok = kj < a.Tk;
+                const int64_t kc = ok ? kj : 0;
+                kr[i] = ok ? load_row8<HT>(a.k, a.kv_dtype, (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + kc * a.k_st + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+                vr[i] = ok ? load_row8<HT>(a.v, a.kv_dtype, (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + kc * a.v_st + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+                if constexpr (PMODE == 2)
+                    pr[i] = ok ? *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + kc * a.p_st + h * dk + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+            }
+            // mask bytes: a validity row (no mask / broadcast mask) or 64 query rows
+            if constexpr (!MFULL) {
+                const int kj = ks + tid;
+                uint8_t mv = kj < a.Tk ? 1 : 0;
+                if (mv && a.mask) mv = a.mask[(int64_t)b * a.m_sb + kj] != 0;
+                Ml[tid] = mv;
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < QT; ++i) {
+                    const int kj = ks + tid;
+                    const int qr = q0 + i < a.Tq ? q0 + i : a.Tq - 1;
+                    Ml[i * MLSTR + tid] = kj < a.Tk ? (a.mask[(int64_t)b * a.m_sb + (int64_t)qr * a.m_sq + kj] != 0) : 0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = i * 256 + tid;
+                const int key = id >> 3, c = id & 7;
+                Kl[k_swz(key, c)] = kr[i];
+                *(u32x4*)(Vl + key * V2STR + c * 8) = vr[i];
+                if constexpr (PMODE == 2) Pl[k_swz(key, c)] = pr[i];
+            }
+        }
+        __syncthreads();
+
+        const int ntile = (min(a.Tk - ks, SK) + KT - 1) / KT;
+        for (int t = 0; t < ntile; ++t) {
+            // ---- S^T tile ----------------------------------------------------------------------------------
+            f32x4 s[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int idx = k_swz(t * 64 + f * 16 + l15, kk * 4 + g);
+                    s[f] = HT::mfma(Kl[idx], qu[kk], s[f]);
+                    if constexpr (PMODE == 2) s[f] = HT::mfma(Pl[idx], qv[kk], s[f]);
+                }
+            }
+            // ---- scale, mask, online softmax ---------------------------------------------------------------------
+            float tmax = -INFINITY;
+            float sv[4][4];
+            const uint8_t* mrow = Ml + (MFULL ? (wave * 16 + l15) * MLSTR : 0) + t * 64 + 4 * g;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const unsigned mb = *(const unsigned*)(mrow + f * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = ((mb >> (8 * r)) & 0xffu) != 0;
+                    const float x = ok ? (s[f][r] + bd) * a.scale : -INFINITY;
+                    sv[f][r] = x;
+                    tmax = fmaxf(tmax, x);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            float alpha = 1.f;
+            if (m_new != -INFINITY) alpha = __expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = (m_new == -INFINITY) ? 0.f : __expf(sv[f][r] - m_new);
+                    sv[f][r] = pv;
+                    psum += pv;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc_o[i] *= alpha;
+            // ---- O^T += V^T . P^T ; V fragments by transposed LDS reads ------------------------------------------------
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const f32x4 p0 = {sv[2 * k2][0], sv[2 * k2][1], sv[2 * k2][2], sv[2 * k2][3]};
+                const f32x4 p1 = {sv[2 * k2 + 1][0], sv[2 * k2 + 1][1], sv[2 * k2 + 1][2], sv[2 * k2 + 1][3]};
+                const u32x4 ph = pack8<HT>(p0, p1);
+                const int key0 = t * 64 + (2 * k2) * 16 + 4 * g;
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) {
+                    // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the 4x16 block; it receives column
+                    // (lane & 15) of the 4 rows, i.e. V[key0 + 0..3][fd*16 + l15]
+                    const u16* pa = Vl + (key0 + (l15 >> 2)) * V2STR + fd * 16 + (l15 & 3) * 4;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 16 * V2STR));
+                    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+                    const u32x4 vf = {lo2.x, lo2.y, hi2.x, hi2.y};
+                    acc_o[fd] = HT::mfma(vf, ph, acc_o[fd]);
+                }
+            }
+        }
+    }
+
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (qi < a.Tq) {
+        const int64_t ob = ((int64_t)b * a.Tq + qi) * ((int64_t)a.H * dk) + (int64_t)h * dk;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            const int d = fd * 16 + g * 4;
+            const f32x4 o = acc_o[fd] * inv;
+            if (a.out_dtype == CFM_F32)
+                *(f32x4*)((float*)a.out + ob + d) = o;
+            else if (a.out_dtype == CFM_BF16)
+                *(u32x2*)((u16*)a.out + ob + d) = (u32x2){pack2<BF16>(o.x, o.y), pack2<BF16>(o.z, o.w)};
+            else
+                *(u32x2*)((u16*)a.out + ob + d) = (u32x2){pack2<F16>(o.x, o.y), pack2<F16>(o.z, o.w)};
+        }
+    }
+}
+
+template <typename HT>
+int launch_attn2(const AttnArgs& a, hipStream_t s, const char* name) {
+    const dim3 grid((a.Tq + QT - 1) / QT, a.H, a.B), block(256);
+    const double flops = 4.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
+    const double bytes = 2.0 * a.B * a.H * ((double)a.Tq * 2 + (double)a.Tk * 2) * a.dk;
+    CfmProfScope prof(name, s, flops, bytes);
+    const int pmode = a.p ? (a.p_st == 0 ? 1 : 2) : 0;
+    const bool mfull = a.mask && a.m_sq != 0;
+#define CFM_A2(PM)                                                                                       \
+    do {                                                                                                 \
+        if (mfull) hipLaunchKernelGGL((cfm_attn2_kernel<HT, PM, true>), grid, block, 0, s, a);            \
+        else hipLaunchKernelGGL((cfm_attn2_kernel<HT, PM, false>), grid, block, 0, s, a);                 \
+    } while (0)
+    if (pmode == 0) CFM_A2(0);
+    else if (pmode == 1) CFM_A2(1);
+    else CFM_A2(2);
+#undef CFM_A2
+    return cfm_launch_status(name);
+}
+
 // new_cache[b,h,t,:] = [K_t | V_t]  (f32), rows t < Tc from the old cache, the rest from the new k/v.
 __global__ void cfm_kv_pack_kernel(const float* old_cache, int Tc, const void* k, const void* v, int dt, int64_t k_sb,
                                    int64_t k_st, int64_t v_sb, int64_t v_st, float* out, int B, int H, int Tn, int dk) {
@@ -313,6 +550,15 @@ extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
     a.q_dtype = d->q_dtype; a.kv_dtype = d->kv_dtype; a.p_dtype = d->p_dtype; a.out_dtype = d->out_dtype; a.scale = d->scale;
     hipStream_t s = (hipStream_t)stream;
     const bool pos = d->p != nullptr;
+    // v2 fast path: d_k = 64, 16-bit q (and p) of the MFMA type, K/V either that type or f32 (streaming cache), 16-byte
+    // aligned rows; everything else (f32-accurate split mode, d_k = 36 ...) runs the general v1 kernel.
+    const bool al8 = (d->q_sb % 8 == 0) && (d->q_st % 8 == 0) && (d->k_sb % 4 == 0) && (d->k_st % 8 == 0) && (d->k_sh % 8 == 0) &&
+                     (d->v_sb % 4 == 0) && (d->v_st % 8 == 0) && (d->v_sh % 8 == 0) && (!pos || ((d->p_sb % 8 == 0) && (d->p_st % 8 == 0)));
+    if (!d->split && d->dk == 64 && d->q_dtype == d->mma_dtype && (!pos || d->p_dtype == d->mma_dtype) &&
+        (d->kv_dtype == d->mma_dtype || d->kv_dtype == CFM_F32) && al8 && !getenv("CFM_ATTN_V1")) {
+        if (d->mma_dtype == CFM_BF16) return launch_attn2<BF16>(a, s, pos ? "attn2_rel_bf16" : "attn2_bf16");
+        return launch_attn2<F16>(a, s, pos ? "attn2_rel_f16" : "attn2_f16");
+    }
     if (d->split) return launch_attn<BF16, true>(a, pos, s, pos ? "attn_rel_bf16x3" : "attn_bf16x3");
     if (d->mma_dtype == CFM_BF16) return launch_attn<BF16, false>(a, pos, s, pos ? "attn_rel_bf16" : "attn_bf16");
     return launch_attn<F16, false>(a, pos, s, pos ? "attn_rel_f16" : "attn_f16");
