@@ -52,10 +52,18 @@ class FfnDesc(ctypes.Structure):
                 ("add_x", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
+class RowChainDesc(ctypes.Structure):
+    _fields_ = [("x", c_p), ("head_a", c_p), ("head_w", c_p), ("head_b", c_p), ("head_res", c_p), ("head_mask", c_p),
+                ("ln_g", c_p), ("ln_b", c_p), ("ln_mask", c_p), ("w1f", c_p), ("w2f", c_p), ("b1", c_p), ("b2", c_p),
+                ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p), ("ln2_b", c_p), ("out_f32", c_p), ("out16", c_p),
+                ("tail_w", c_p), ("tail_b", c_p), ("tail_out", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32),
+                ("tail_N", c_i32), ("tail_glu", c_i32), ("w_dtype", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
 _LAYER_W_FIELDS = [
     "ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "ln_conv_b", "ln_ff_g", "ln_ff_b", "ln_final_g", "ln_final_b",
     "ffm_w1", "ffm_w1_lo", "ffm_w2", "ffm_w2_lo", "ffm_b1", "ffm_b2",
-    "ff_w1", "ff_w1_lo", "ff_w2", "ff_w2_lo", "ff_b1", "ff_b2", "ffm_w1f", "ffm_w2f", "ff_w1f", "ff_w2f",
+    "ff_w1", "ff_w1_lo", "ff_w2", "ff_w2_lo", "ff_b1", "ff_b2", "ffm_w1f", "ffm_w2f", "ff_w1f", "ff_w2f", "qkv_wf", "out_wf", "pw1_wf", "pw2_wf",
     "qkv_w", "qkv_w_lo", "pos_w", "pos_w_lo", "out_w", "out_w_lo", "qkv_b", "out_b", "bias_u", "bias_v",
     "pw1_w", "pw1_w_lo", "pw2_w", "pw2_w_lo", "pw1_b", "pw2_b", "dw_w", "dw_b", "bn_scale", "bn_shift"]
 
@@ -99,6 +107,8 @@ def lib():
         L.cfm_gemm.argtypes = [ctypes.POINTER(GemmDesc), c_p]
         L.cfm_attention.argtypes = [ctypes.POINTER(AttnDesc), c_p]
         L.cfm_ffn_fused.argtypes = [ctypes.POINTER(FfnDesc), c_p]
+        L.cfm_rowchain.argtypes = [ctypes.POINTER(RowChainDesc), c_p]
+        L.cfm_rowchain_supported.argtypes = [c_i32, c_i32]
         L.cfm_layernorm.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, ctypes.c_float, c_i64, c_i32, c_p]
         L.cfm_kv_cache_pack.argtypes = [c_p, c_i32, c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_dwconv_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
@@ -116,7 +126,7 @@ def lib():
         L.cfm_prof_collect.restype = ctypes.c_int
         L.cfm_prof_entry.argtypes = [c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu",
+        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_prof_entry"):
             getattr(L, name).restype = ctypes.c_int

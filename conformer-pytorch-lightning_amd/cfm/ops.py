@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "valid_mask", "chunk_mask",
+__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -106,6 +106,36 @@ def ffn_fused(x, w1f, w2f, b1, b2, FF, act=_c.ACT_SILU, ln=None, alpha=1.0, add_
     d.act, d.add_x, d.alpha, d.eps = act, 1 if add_x else 0, alpha, eps
     _c.check(_c.lib().cfm_ffn_fused(ctypes.byref(d), _c.stream()), "cfm_ffn_fused")
     return out_f32, out16
+
+
+def rowchain_supported(D, FF, prec):
+    return (not prec.split) and bool(_c.lib().cfm_rowchain_supported(D, FF))
+
+
+def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, alpha=1.0, ln1=None, ln2=None, out_f32=None, out16=None,
+             tail=None, eps=1e-5):
+    """One-launch row-local chain (include/cfm.h cfm_rowchain).
+    head = (a16 [M,D], w_frag, bias, residual f32 [M,D], out_mask u8 [M] | None);  ffn = (w1f, w2f, b1, b2, FF);
+    tail = (w_frag, bias, N, glu, out 16-bit [M, N or N/2]);  ln/ln1/ln2 = (gain, bias)."""
+    d = _c.RowChainDesc()
+    keep = [x, out_f32, out16, ln_mask]
+    d.x, d.out_f32, d.out16, d.ln_mask = _c.ptr(x), _c.ptr(out_f32), _c.ptr(out16), _c.ptr(ln_mask)
+    if head is not None:
+        a16, hw, hb, res, hm = head
+        _c.require_hip(a16, hw, hb, res, hm)
+        d.head_a, d.head_w, d.head_b, d.head_res, d.head_mask = _c.ptr(a16), _c.ptr(hw), _c.ptr(hb), _c.ptr(res), _c.ptr(hm)
+        keep += list(head)
+    for name, pair in (("ln", ln), ("ln1", ln1), ("ln2", ln2)):
+        if pair is not None:
+            setattr(d, name + "_g", _c.ptr(pair[0]))
+            setattr(d, name + "_b", _c.ptr(pair[1]))
+    if ffn is not None:
+        d.w1f, d.w2f, d.b1, d.b2, d.FF = _c.ptr(ffn[0]), _c.ptr(ffn[1]), _c.ptr(ffn[2]), _c.ptr(ffn[3]), ffn[4]
+    if tail is not None:
+        d.tail_w, d.tail_b, d.tail_N, d.tail_glu, d.tail_out = _c.ptr(tail[0]), _c.ptr(tail[1]), tail[2], 1 if tail[3] else 0, _c.ptr(tail[4])
+    _c.require_hip(x, out_f32, out16)
+    d.M, d.D, d.w_dtype, d.alpha, d.eps = M, D, w_code, alpha, eps
+    _c.check(_c.lib().cfm_rowchain(ctypes.byref(d), _c.stream()), "cfm_rowchain")
 
 
 def layernorm(x, g1, b1, out1=None, out1_dtype=None, g2=None, b2=None, out2=None, out2_dtype=None, row_mask=None, eps=1e-5,

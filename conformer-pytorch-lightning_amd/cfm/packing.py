@@ -75,6 +75,16 @@ def pack_ffn_fragments(w1, w2, dtype):
     return w1f.view(-1), w2f.view(-1)
 
 
+def pack_frag_major(w, dtype):
+    """[N,K] -> 16-bit fragment-major w[nfrag][kk][lane][j] = W[nfrag*16 + (lane&15)][kk*32 + 8*(lane>>4) + j], K zero-padded to a
+    multiple of 32 (the operand layout of the row-chain kernels: one wavefront-load of lane*16 B = one MFMA A fragment)."""
+    N, K = w.shape
+    ks = (K + 31) // 32
+    wp = torch.zeros((N, ks * 32), dtype=torch.float32, device=w.device)
+    wp[:, :K] = w.detach().float()
+    return wp.view(N // 16, 16, ks, 4, 8).permute(0, 2, 3, 1, 4).contiguous().to(dtype).view(-1)
+
+
 def pack_ffn(mod, prec):
     def build():
         w1, w1l = matrix(mod.w_1.weight, prec)
@@ -106,6 +116,10 @@ def pack_mhsa(mod, prec, relative):
         if relative:
             p.pos_w, p.pos_w_lo = matrix(mod.linear_pos.weight, prec)
             p.bias_u, p.bias_v = f32(mod.pos_bias_u), f32(mod.pos_bias_v)
+        p.qkv_wf = p.out_wf = None
+        if not prec.split and D % 16 == 0:
+            p.qkv_wf = pack_frag_major(torch.cat([mod.linear_q.weight, mod.linear_k.weight, mod.linear_v.weight], 0), prec.w_dtype)
+            p.out_wf = pack_frag_major(mod.linear_out.weight, prec.w_dtype)
         return p
     return mod._pack.get(srcs, prec, build)
 
@@ -129,8 +143,13 @@ def pack_conv_module(mod, prec):
         beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros(D, device=dev)
         scale = gamma / torch.sqrt(bn.running_var.detach().float() + bn.eps)
         shift = beta - bn.running_mean.detach().float() * scale
-        return Packed(pw1_w=pw1, pw1_w_lo=pw1l, pw1_b=f32(b1[idx]), pw2_w=pw2, pw2_w_lo=pw2l, pw2_b=f32(mod.pointwise_conv2.bias),
-                      dw_w=f32(mod.depthwise_conv.weight.detach()[:, 0, :]), dw_b=f32(dwb), bn_scale=f32(scale), bn_shift=f32(shift))
+        pk = Packed(pw1_w=pw1, pw1_w_lo=pw1l, pw1_b=f32(b1[idx]), pw2_w=pw2, pw2_w_lo=pw2l, pw2_b=f32(mod.pointwise_conv2.bias),
+                    dw_w=f32(mod.depthwise_conv.weight.detach()[:, 0, :]), dw_b=f32(dwb), bn_scale=f32(scale), bn_shift=f32(shift),
+                    pw1_wf=None, pw2_wf=None)
+        if not prec.split and D % 16 == 0:
+            pk.pw1_wf = pack_frag_major(w1[idx], prec.w_dtype)          # same value/gate interleave as the GEMM path
+            pk.pw2_wf = pack_frag_major(mod.pointwise_conv2.weight.detach()[:, :, 0], prec.w_dtype)
+        return pk
     return mod._pack.get(srcs, prec, build)
 
 
@@ -177,6 +196,7 @@ def layer_weight_struct(layer, prec):
         setattr(w, pre + "_b2", pk.b2.data_ptr())
         setattr(w, pre + "_w1f", _c.ptr(pk.w1f))
         setattr(w, pre + "_w2f", _c.ptr(pk.w2f))
+    w.qkv_wf, w.out_wf, w.pw1_wf, w.pw2_wf = _c.ptr(att.qkv_wf), _c.ptr(att.out_wf), _c.ptr(cv.pw1_wf), _c.ptr(cv.pw2_wf)
     w.qkv_w, w.qkv_w_lo, w.qkv_b = att.qkv_w.data_ptr(), _c.ptr(att.qkv_w_lo), att.qkv_b.data_ptr()
     w.pos_w, w.pos_w_lo = _c.ptr(att.pos_w), _c.ptr(att.pos_w_lo)
     w.out_w, w.out_w_lo, w.out_b = att.out_w.data_ptr(), _c.ptr(att.out_w_lo), att.out_b.data_ptr()

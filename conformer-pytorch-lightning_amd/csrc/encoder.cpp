@@ -1,4 +1,4 @@
-// encoder.cpp -- composite: one conformer block enqueued from C++ (10 launches with the fused FFN, no host sync).
+// encoder.cpp -- composite: one conformer block enqueued from C++ (6 launches with the row-local chains of rowchain.hip, no host sync).
 //
 // Mirrors reference src/encoder_layer.py:49-71:
 //   x = x + 1/2 FFNm(LN(x)); x = x + MHSA(LN(x)); x = x + Conv(LN(x)); x = x + 1/2 FFN(LN(x)); out = LN(x)
@@ -74,12 +74,24 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     }
     CFM_CHECK_ARG(Tc == 0 || io->new_cache, "encoder layer: a KV cache input needs new_cache storage");
 
+    // ---- 6-launch path: the three row-local chains of rowchain.hip -----------------------------------------------------
+    const bool chains = !c.split && w->ffm_w1f && w->ffm_w2f && w->ff_w1f && w->ff_w2f && w->qkv_wf && w->out_wf && w->pw1_wf &&
+                        w->pw2_wf && cfm_rowchain_supported(D, FF);
+    if (chains) {
+        cfm_rowchain_desc m = {};
+        m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2f = w->ffm_w2f; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
+        m.ln2_g = w->ln_mha_g; m.ln2_b = w->ln_mha_b; m.out_f32 = x_out; m.tail_w = w->qkv_wf; m.tail_b = w->qkv_b; m.tail_out = s->qkv;
+        m.M = M; m.D = D; m.FF = FF; m.tail_N = 3 * D; m.tail_glu = 0; m.w_dtype = c.w_dt; m.alpha = 0.5f; m.eps = eps;
+        CFM_TRY(cfm_rowchain(&m, stream));
+    }
     // The fused feed-forward kernel (ffn.hip) covers LN + W1 + SiLU + W2 + residual (+ the following norms) in one launch.
-    const bool fused_ffn = !c.split && w->ffm_w1f && w->ffm_w2f && w->ff_w1f && w->ff_w2f && (D == 144 || D == 256) &&
+    const bool fused_ffn = !chains && !c.split && w->ffm_w1f && w->ffm_w2f && w->ff_w1f && w->ff_w2f && (D == 144 || D == 256) &&
                            FF % 32 == 0 && FF <= 2048;
 
     // (1) macaron feed-forward: x1 = x + 1/2 W2 silu(W1 LN(x));  (2a) norm_mha
-    if (fused_ffn) {
+    if (chains) {
+        // done above, together with the QKV projection
+    } else if (fused_ffn) {
         CFM_TRY(ffn_fused(c, x_in, w->ln_ffm_g, w->ln_ffm_b, w->ffm_w1f, w->ffm_w2f, w->ffm_b1, w->ffm_b2, nullptr, nullptr,
                           w->ln_mha_g, w->ln_mha_b, x_out, s->xn));
     } else {
@@ -90,7 +102,8 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     }
 
     // (2) self-attention
-    CFM_TRY(gemm(c, s->xn, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, s->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr));
+    if (!chains)
+        CFM_TRY(gemm(c, s->xn, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, s->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr));
     if (has_pos)
         CFM_TRY(gemm(c, io->pos_embed, CFM_F32, D, w->pos_w, w->pos_w_lo, nullptr, s->pos, adt, D, io->pos_rows, D, D, CFM_ACT_NONE,
                      nullptr, 0.f, nullptr));
@@ -118,6 +131,22 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     a.mma_dtype = c.w_dt; a.split = c.split ? 1 : 0;
     a.scale = 1.0f / sqrtf((float)dk);
     CFM_TRY(cfm_attention(&a, stream));
+    if (chains) {
+        // conv-in chain: out-proj + residual -> LN_conv (pad mask) -> pointwise-conv-1 + GLU
+        cfm_rowchain_desc ci = {};
+        ci.head_a = s->ctx; ci.head_w = w->out_wf; ci.head_b = w->out_b; ci.head_res = x_out; ci.ln_g = w->ln_conv_g; ci.ln_b = w->ln_conv_b;
+        ci.ln_mask = io->pad_valid; ci.out_f32 = x_out; ci.tail_w = w->pw1_wf; ci.tail_b = w->pw1_b; ci.tail_out = s->glu;
+        ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
+        CFM_TRY(cfm_rowchain(&ci, stream));
+        CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+        // final chain: pointwise-conv-2 + pad mask + residual -> LN_ff -> FFN -> +res -> LN_final, in place on x_out
+        cfm_rowchain_desc fi = {};
+        fi.head_a = s->dw; fi.head_w = w->pw2_wf; fi.head_b = w->pw2_b; fi.head_res = x_out; fi.head_mask = io->pad_valid;
+        fi.ln_g = w->ln_ff_g; fi.ln_b = w->ln_ff_b; fi.w1f = w->ff_w1f; fi.w2f = w->ff_w2f; fi.b1 = w->ff_b1; fi.b2 = w->ff_b2;
+        fi.ln1_g = w->ln_final_g; fi.ln1_b = w->ln_final_b; fi.out_f32 = x_out;
+        fi.M = M; fi.D = D; fi.FF = FF; fi.w_dtype = c.w_dt; fi.alpha = 0.5f; fi.eps = eps;
+        return cfm_rowchain(&fi, stream);
+    }
     CFM_TRY(gemm(c, s->ctx, adt, D, w->out_w, w->out_w_lo, w->out_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, nullptr));
 
     // (3) convolution module: mask -> pw1+GLU -> depthwise+BN+SiLU -> pw2 -> mask

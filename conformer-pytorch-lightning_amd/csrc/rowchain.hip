@@ -1,0 +1,473 @@
+// rowchain.hip -- row-local chains of the conformer block in ONE launch per chain (gfx950).
+//
+// Everything in a conformer block except attention (mixes frames of an utterance) and the depthwise conv (15-frame
+// halo) is ROW-LOCAL: it maps one frame's D-vector to another.  At config 2 there are ~31 rows per CU, so a separate
+// launch per linear layer is dominated by its prologue/epilogue.  This kernel runs a whole row-local chain on a
+// 32-row tile that never leaves the CU:
+//
+//     [HEAD]  x  = residual + mask( A16 . Wh^T + bh )          A16 = 16-bit tile from the previous kernel
+//      else   x  = rows of the f32 residual stream
+//             xn = LN(x; ln)  (optionally zeroing padded rows)                      -> LDS, 16 bit
+//     [MID]   y  = x + alpha * ( W2 . act( W1 . xn + b1 ) + b2 )                    (the fused FFN of ffn.hip)
+//      else   y  = x
+//             y1 = LN1(y) -> out_f32 ;   y2 = LN2(y1) -> LDS / out16
+//     [TAIL]  t  = y2 . Wt^T + bt   (optionally GLU: a * sigmoid(g))               -> tail_out, 16 bit
+//
+// used three times per block (encoder_layer.py:56-70):
+//     macaron  : MID + TAIL           LN_ffm -> FFN_m -> +res -> LN_mha -> fused QKV projection
+//     conv-in  : HEAD + TAIL(GLU)     out-proj + res -> LN_conv (pad mask) -> pointwise-conv-1 + GLU
+//     final    : HEAD + MID           pointwise-conv-2 + mask + res -> LN_ff -> FFN -> +res -> LN_final
+// so a block is 6 launches: macaron, pos-projection, attention, conv-in, depthwise, final.
+//
+// All linears use the machinery proven in ffn.hip: fragment-major weights (one wavefront-load = 1 KB = one MFMA A
+// fragment), streamed L2 -> VGPR by a pinned rolling ring, straight-line unrolled steps (no branches: see ffn.hip for
+// why), swapped MFMA roles (a lane owns 4 consecutive output columns of one row), 4 wavefronts that each own distinct
+// output columns (HEAD/TAIL: no cross-wavefront reduction) or distinct FF slices (MID: fixed-order LDS reduction).
+#include <string>
+#include <type_traits>
+
+#include "cfm_common.h"
+
+struct ChainArgs {
+    const float* x;           // f32 rows (no HEAD)
+    const u16* head_a;        // 16-bit [M,D] (HEAD)
+    const u16* head_w;        // fragment-major [D/16][KS][64][8]
+    const float* head_b;
+    const float* head_res;    // f32 [M,D]
+    const uint8_t* head_mask; // zero the head OUTPUT row where 0 (before the residual add)
+    const float *ln_g, *ln_b;
+    const uint8_t* ln_mask;   // zero the normalised row where 0
+    const u16 *w1f, *w2f;
+    const float *b1, *b2;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float* out_f32;
+    void* out16;
+    const u16* tail_w;        // fragment-major [tail_N/16][KS][64][8]
+    const float* tail_b;
+    void* tail_out;           // 16-bit [M, tail_N] (GLU: [M, tail_N/2])
+    int64_t M;
+    int FF, tail_N;
+    int out16_dtype;
+    float alpha, eps;
+};
+
+namespace {
+
+constexpr int RBM = 32;
+
+// One "linear step": this wavefront's two 16-column fragments (n-fragments f0, f0+1) over the whole K of the LDS tile.
+// Weights for the NEXT step (n-fragments nxa, nxb -- clamped by the caller when out of range) are refilled into the ring as
+// the current ones are consumed.
+template <typename HT, int KS1, int XN_STRIDE>
+__device__ __forceinline__ void linear_step(const u16* xn, const u32x4* wp, int nxa, int nxb, u32x4 (&wr)[2 * KS1],
+                                            f32x4 (&acc)[2][2], int g, int l15) {
+    u32x4 xf[2][KS1];
+#pragma unroll
+    for (int kk = 0; kk < KS1; ++kk)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) xf[mf][kk] = *(const u32x4*)(xn + (mf * 16 + l15) * XN_STRIDE + kk * 32 + 8 * g);
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KS1; ++kk) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) acc[mf][nf] = HT::mfma(wr[nf * KS1 + kk], xf[mf][kk], acc[mf][nf]);
+        wr[kk] = wp[((int64_t)nxa * KS1 + kk) * 64];
+        wr[KS1 + kk] = wp[((int64_t)nxb * KS1 + kk) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename HT, int D, int HSTEPS, int FSTEPS, int TSTEPS, bool TGLU>
+__global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
+    constexpr bool HEAD = HSTEPS > 0, MID = FSTEPS > 0, TAIL = TSTEPS > 0;
+    constexpr int KS1 = (D + 31) / 32;
+    constexpr int KP = KS1 * 32;
+    constexpr int NF2 = D / 16;
+    constexpr int MF = RBM / 16;
+    constexpr int XS_STRIDE = D + 4;
+    constexpr int XN_STRIDE = KP + 8;
+    constexpr int VPL = (D + 255) / 256;
+    static_assert(D % 16 == 0 && D <= 256 && MF == 2, "row chain supports D % 16 == 0, D <= 256");
+
+    __shared__ __attribute__((aligned(16))) float xs[RBM * XS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float slab[(MID ? 2 : 0) * RBM * XS_STRIDE + 4];
+    __shared__ __attribute__((aligned(16))) u16 xn[RBM * XN_STRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * RBM;
+
+    // ================= HEAD: x = res + mask(A . Wh^T + bh) =====================================================
+    if constexpr (HEAD) {
+        // stage the 16-bit input tile (rows clamped), zero-padded to KP columns
+        constexpr int CPRW = KP / 8;                       // 16-byte chunks per row
+        for (int id = tid; id < RBM * CPRW; id += 256) {
+            const int r = id / CPRW, c = id % CPRW;
+            int64_t grow = row0 + r;
+            grow = grow < a.M ? grow : a.M - 1;
+            const u32x4 v = c * 8 < D ? *(const u32x4*)(a.head_a + grow * D + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+            *(u32x4*)(xn + r * XN_STRIDE + c * 8) = v;
+        }
+        __syncthreads();
+        const u32x4* wp = (const u32x4*)a.head_w + lane;
+        auto frag0 = [&](int s) { return (s * 4 + wave) * 2; };
+        auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
+        u32x4 wr[2 * KS1];
+#pragma unroll
+        for (int kk = 0; kk < KS1; ++kk) {
+            wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
+            wr[KS1 + kk] = wp[((int64_t)clampf(frag0(0) + 1) * KS1 + kk) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < HSTEPS; ++s) {
+            const int f = frag0(s);
+            const int fn = frag0(s + 1 < HSTEPS ? s + 1 : s);
+            f32x4 acc[2][2];
+            linear_step<HT, KS1, XN_STRIDE>(xn, wp, clampf(fn), clampf(fn + 1), wr, acc, g, l15);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const int col = (f + nf) * 16 + 4 * g;
+                if (f + nf < NF2) {
+                    const f32x4 bb = *(const f32x4*)(a.head_b + col);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) {
+                        const int r = mf * 16 + l15;
+                        int64_t grow = row0 + r;
+                        grow = grow < a.M ? grow : a.M - 1;
+                        f32x4 v = acc[mf][nf] + bb;
+                        if (a.head_mask && a.head_mask[grow] == 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        v += *(const f32x4*)(a.head_res + grow * D + col);
+                        *(f32x4*)(xs + r * XS_STRIDE + col) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ================= rows -> (x in LDS,) LN_in -> xn ===========================================================
+#pragma unroll
+    for (int rr = 0; rr < RBM / 4; ++rr) {
+        const int r = wave * (RBM / 4) + rr;
+        int64_t grow = row0 + r;
+        grow = grow < a.M ? grow : a.M - 1;
+        f32x4 v[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if constexpr (HEAD) {
+                v[it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+                v[it] = c < D ? *(const f32x4*)(a.x + grow * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (c < D) *(f32x4*)(xs + r * XS_STRIDE + c) = v[it];
+            }
+            if (c < D) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        }
+        if constexpr (HEAD && !MID) {                      // conv-in: the head result IS the new residual stream
+            if (row0 + r < a.M && a.out_f32) {
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    if (c < D) *(f32x4*)(a.out_f32 + (row0 + r) * D + c) = v[it];
+                }
+            }
+        }
+        if (a.ln_g) {
+            const float mean = wave_sum(s) / (float)D;
+            float q = 0.f;
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                if (c < D) {
+                    const f32x4 d = v[it] - mean;
+                    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                if (c < D) v[it] = (v[it] - mean) * rstd * *(const f32x4*)(a.ln_g + c) + *(const f32x4*)(a.ln_b + c);
+            }
+        }
+        const bool keep = a.ln_mask ? a.ln_mask[grow] != 0 : true;
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < KP) {
+                const f32x4 o = (c < D && keep) ? v[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                *(u32x2*)(xn + r * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= MID: fused feed-forward (see ffn.hip for the design notes) ================================
+    if constexpr (MID) {
+        auto xfrag = [&](int mf, int kk) { return *(const u32x4*)(xn + (mf * 16 + l15) * XN_STRIDE + kk * 32 + 8 * g); };
+        const int nsteps_total = a.FF / 32;
+        f32x4 acc2[MF][NF2];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const u32x4* w1p = (const u32x4*)a.w1f + lane;
+        const u32x4* w2p = (const u32x4*)a.w2f + lane;
+        u32x4 w1r[2 * KS1], w2r[NF2];
+        f32x4 b1r[2];
+        auto w1_addr = [&](int fs, int i) { return w1p + ((int64_t)(2 * fs) * KS1 + i) * 64; };
+        auto w2_addr = [&](int fs, int i) { return w2p + ((int64_t)fs * NF2 + i) * 64; };
+        const int rot = (int)(blockIdx.x % FSTEPS);
+        auto step_of = [&](int s) { int q = s + rot; q = q >= FSTEPS ? q - FSTEPS : q; return q * 4 + wave; };
+        auto step = [&](int s) {
+            const int fs_raw = step_of(s);
+            const bool valid = fs_raw < nsteps_total;
+            const int last = nsteps_total - 1;
+            const int nx_raw = step_of(s + 1 < FSTEPS ? s + 1 : s);
+            const int nx = nx_raw < nsteps_total ? nx_raw : last;
+            f32x4 acc1[MF][2];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) acc1[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            u32x4 xf[MF][KS1];
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) xf[mf][kk] = xfrag(mf, kk);
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk) {
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) acc1[mf][nf] = HT::mfma(w1r[nf * KS1 + kk], xf[mf][kk], acc1[mf][nf]);
+                w1r[kk] = *w1_addr(nx, kk);
+                w1r[KS1 + kk] = *w1_addr(nx, KS1 + kk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const f32x4 bb0 = b1r[0], bb1 = b1r[1];
+            b1r[0] = *(const f32x4*)(a.b1 + nx * 32 + 4 * g);
+            b1r[1] = *(const f32x4*)(a.b1 + nx * 32 + 16 + 4 * g);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 hf[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                f32x4 h0 = acc1[mf][0] + bb0, h1 = acc1[mf][1] + bb1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h0[r] = siluf_(h0[r]);
+                    h1[r] = siluf_(h1[r]);
+                }
+                hf[mf] = pack8<HT>(h0, h1);
+                if (!valid) hf[mf] = (u32x4){0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int nf = 0; nf < NF2; ++nf) {
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) acc2[mf][nf] = HT::mfma(w2r[nf], hf[mf], acc2[mf][nf]);
+                w2r[nf] = *w2_addr(nx, nf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {
+            const int f00 = step_of(0);
+            const int f0 = f00 < nsteps_total ? f00 : nsteps_total - 1;
+#pragma unroll
+            for (int i = 0; i < 2 * KS1; ++i) w1r[i] = *w1_addr(f0, i);
+            b1r[0] = *(const f32x4*)(a.b1 + f0 * 32 + 4 * g);
+            b1r[1] = *(const f32x4*)(a.b1 + f0 * 32 + 16 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < NF2; ++i) w2r[i] = *w2_addr(f0, i);
+        }
+#pragma unroll
+        for (int s = 0; s < FSTEPS; ++s) step(s);
+
+        // cross-wavefront reduction, fixed order ((w0 + w2) + (w1 + w3))
+        auto slab_ptr = [&](int which, int mf, int nf) { return slab + which * RBM * XS_STRIDE + (mf * 16 + l15) * XS_STRIDE + nf * 16 + 4 * g; };
+        if (wave >= 2) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf) *(f32x4*)slab_ptr(wave - 2, mf, nf) = acc2[mf][nf];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] += *(const f32x4*)slab_ptr(wave, mf, nf);
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf) *(f32x4*)slab_ptr(wave, mf, nf) = acc2[mf][nf];
+        }
+        __syncthreads();
+    }
+
+    // ================= post norms: y1 -> out_f32, y2 -> out16 / next LDS tile =====================================
+    if constexpr (MID) {
+#pragma unroll
+        for (int rr = 0; rr < RBM / 4; ++rr) {
+            const int r = wave * (RBM / 4) + rr;
+            const int64_t grow = row0 + r;
+            f32x4 v[VPL];
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (c < D) {
+                    const f32x4 y = *(const f32x4*)(slab + r * XS_STRIDE + c) + *(const f32x4*)(slab + RBM * XS_STRIDE + r * XS_STRIDE + c);
+                    v[it] = a.alpha * (y + *(const f32x4*)(a.b2 + c)) + *(const f32x4*)(xs + r * XS_STRIDE + c);
+                }
+            }
+            auto norm = [&](const float* gam, const float* bet) {
+                float s = 0.f;
+#pragma unroll
+                for (int it = 0; it < VPL; ++it)
+                    if ((lane + 64 * it) * 4 < D) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+                const float mean = wave_sum(s) / (float)D;
+                float q = 0.f;
+#pragma unroll
+                for (int it = 0; it < VPL; ++it)
+                    if ((lane + 64 * it) * 4 < D) {
+                        const f32x4 d = v[it] - mean;
+                        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                    }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    if (c < D) v[it] = (v[it] - mean) * rstd * *(const f32x4*)(gam + c) + *(const f32x4*)(bet + c);
+                }
+            };
+            if (a.ln1_g) norm(a.ln1_g, a.ln1_b);
+            if (grow < a.M && a.out_f32) {
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    if (c < D) *(f32x4*)(a.out_f32 + grow * D + c) = v[it];
+                }
+            }
+            if (a.ln2_g) {
+                norm(a.ln2_g, a.ln2_b);
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    if (c < KP) {
+                        const f32x4 o = c < D ? v[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        const u32x2 pk = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
+                        if constexpr (TAIL) *(u32x2*)(xn + r * XN_STRIDE + c) = pk;   // the tail's input tile
+                        if (c < D && grow < a.M && a.out16) *(u32x2*)((u16*)a.out16 + grow * D + c) = pk;
+                    }
+                }
+            }
+        }
+        if constexpr (TAIL) __syncthreads();
+    }
+
+    // ================= TAIL: t = xn . Wt^T + bt (GLU optional), 16-bit store ===================================
+    if constexpr (TAIL) {
+        const int nfrags = a.tail_N / 16;
+        const int ldo = TGLU ? a.tail_N / 2 : a.tail_N;
+        const u32x4* wp = (const u32x4*)a.tail_w + lane;
+        auto frag0 = [&](int s) { return (s * 4 + wave) * 2; };
+        auto clampf = [&](int f) { return f < nfrags ? f : nfrags - 1; };
+        u32x4 wr[2 * KS1];
+#pragma unroll
+        for (int kk = 0; kk < KS1; ++kk) {
+            wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
+            wr[KS1 + kk] = wp[((int64_t)clampf(frag0(0) + 1) * KS1 + kk) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < TSTEPS; ++s) {
+            const int f = frag0(s);
+            const int fn = frag0(s + 1 < TSTEPS ? s + 1 : s);
+            f32x4 acc[2][2];
+            linear_step<HT, KS1, XN_STRIDE>(xn, wp, clampf(fn), clampf(fn + 1), wr, acc, g, l15);
+            const bool v0ok = f < nfrags, v1ok = f + 1 < nfrags;
+            const f32x4 bb0 = *(const f32x4*)(a.tail_b + clampf(f) * 16 + 4 * g);
+            const f32x4 bb1 = *(const f32x4*)(a.tail_b + clampf(f + 1) * 16 + 4 * g);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int64_t grow = row0 + mf * 16 + l15;
+                if (grow >= a.M) continue;
+                f32x4 v0 = acc[mf][0] + bb0, v1 = acc[mf][1] + bb1;
+                if constexpr (TGLU) {
+                    if (v1ok) {                               // (value, gate) fragment pairs: tail_N % 32 == 0
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v0[r] *= sigmoidf_(v1[r]);
+                        const int64_t o = grow * ldo + (f >> 1) * 16 + 4 * g;
+                        *(u32x2*)((u16*)a.tail_out + o) = (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)};
+                    }
+                } else {
+                    const int64_t o = grow * ldo + f * 16 + 4 * g;
+                    if (v0ok) *(u32x2*)((u16*)a.tail_out + o) = (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)};
+                    if (v1ok) *(u32x2*)((u16*)a.tail_out + o + 16) = (u32x2){pack2<HT>(v1.x, v1.y), pack2<HT>(v1.z, v1.w)};
+                }
+            }
+        }
+    }
+}
+
+template <typename HT, int D, int HS, int FS, int TS, bool TGLU>
+int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
+    const unsigned grid = (unsigned)((a.M + RBM - 1) / RBM);
+    CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
+    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, HS, FS, TS, TGLU>), dim3(grid), dim3(256), 0, s, a);
+    return cfm_launch_status(name);
+}
+
+}  // namespace
+
+extern "C" int cfm_rowchain_supported(int32_t D, int32_t FF) { return (D == 256 && FF == 2048) || (D == 144 && FF == 576); }
+
+extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
+    CFM_CHECK_ARG(d, "cfm_rowchain: null descriptor");
+    const bool head = d->head_a != nullptr, mid = d->w1f != nullptr, tail = d->tail_w != nullptr;
+    CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256), "cfm_rowchain: D=%d has no instance (144, 256)", d->D);
+    CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_rowchain: w_dtype must be bf16 or fp16");
+    CFM_CHECK_ARG(head || d->x, "cfm_rowchain: need x or a head input");
+    CFM_CHECK_ARG(!head || (d->head_w && d->head_b && d->head_res), "cfm_rowchain: head needs weights, bias and residual");
+    CFM_CHECK_ARG(!mid || (d->w2f && d->b1 && d->b2 && d->FF > 0 && d->FF % 32 == 0 && d->FF <= 2048), "cfm_rowchain: bad FFN arguments");
+    CFM_CHECK_ARG(!tail || (d->tail_b && d->tail_out && d->tail_N % 16 == 0 && d->tail_N > 0 && (!d->tail_glu || d->tail_N % 32 == 0)),
+                  "cfm_rowchain: tail needs bias, output and N %% 16 == 0 (GLU: N %% 32 == 0)");
+    CFM_CHECK_ARG(!tail || (mid ? d->ln2_g != nullptr : true), "cfm_rowchain: a tail after the FFN takes its input from the second LayerNorm");
+    ChainArgs a;
+    a.x = d->x; a.head_a = (const u16*)d->head_a; a.head_w = (const u16*)d->head_w; a.head_b = d->head_b; a.head_res = d->head_res;
+    a.head_mask = d->head_mask; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_mask = d->ln_mask; a.w1f = (const u16*)d->w1f; a.w2f = (const u16*)d->w2f;
+    a.b1 = d->b1; a.b2 = d->b2; a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32;
+    a.out16 = d->out16; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M; a.FF = d->FF;
+    a.tail_N = d->tail_N; a.out16_dtype = d->w_dtype; a.alpha = d->alpha; a.eps = d->eps;
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = d->w_dtype == CFM_BF16;
+    const int fsteps = mid ? (d->FF / 32 + 3) / 4 : 0;
+    const int tsteps = tail ? (d->tail_N / 16 + 7) / 8 : 0;
+    const double M = (double)d->M;
+    const double fl_head = head ? 2.0 * M * d->D * d->D : 0.0, fl_mid = mid ? 4.0 * M * d->D * d->FF : 0.0,
+                 fl_tail = tail ? 2.0 * M * d->D * d->tail_N : 0.0;
+    const double fl = fl_head + fl_mid + fl_tail;
+#define CFM_RC(HT, DD, HS, FS, TS, GLU, NAME) return launch_chain<HT, DD, HS, FS, TS, GLU>(a, s, NAME, fl)
+    // the three roles of a conformer block, for D = 256 (ff 2048) and D = 144 (ff 576)
+    if (d->D == 256) {
+        if (!head && mid && tail && !d->tail_glu && fsteps == 16 && tsteps == 6) { if (bf) CFM_RC(BF16, 256, 0, 16, 6, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 0, 16, 6, false, "chain_macaron_f16_d256"); }
+        if (head && !mid && tail && d->tail_glu && tsteps == 4) { if (bf) CFM_RC(BF16, 256, 2, 0, 4, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 2, 0, 4, true, "chain_convin_f16_d256"); }
+        if (head && mid && !tail && fsteps == 16) { if (bf) CFM_RC(BF16, 256, 2, 16, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 2, 16, 0, false, "chain_final_f16_d256"); }
+    } else {
+        if (!head && mid && tail && !d->tail_glu && fsteps == 5 && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 0, 5, 4, false, "chain_macaron_bf16_d144"); else CFM_RC(F16, 144, 0, 5, 4, false, "chain_macaron_f16_d144"); }
+        if (head && !mid && tail && d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 144, 2, 0, 3, true, "chain_convin_bf16_d144"); else CFM_RC(F16, 144, 2, 0, 3, true, "chain_convin_f16_d144"); }
+        if (head && mid && !tail && fsteps == 5) { if (bf) CFM_RC(BF16, 144, 2, 5, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 2, 5, 0, false, "chain_final_f16_d144"); }
+    }
+#undef CFM_RC
+    return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: no instance for D=%d FF=%d tail_N=%d head=%d mid=%d tail=%d glu=%d", d->D, d->FF,
+                    d->tail_N, (int)head, (int)mid, (int)tail, d->tail_glu);
+}

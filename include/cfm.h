@@ -122,6 +122,48 @@ typedef struct {
 int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Row-local chain on 32-row tiles, one launch (csrc/rowchain.hip):
+ *     x  = head_a ? head_res + mask_out( head_a . Wh^T + head_b ) : x          (head_mask zeroes the product's row)
+ *     xn = LN(x; ln_g, ln_b), rows with ln_mask == 0 zeroed
+ *     y  = w1f ? x + alpha * FFN(xn) : x                                         (FFN as in cfm_ffn_fused, SiLU)
+ *     y1 = ln1_g ? LN(y) : y -> out_f32        (head without FFN: out_f32 receives x, the new residual stream)
+ *     y2 = ln2_g ? LN(y1) : xn -> out16 (optional) and the tail's input
+ *     t  = tail_w ? y2 . Wt^T + tail_b, tail_glu: value*sigmoid(gate) on 16-column fragment pairs -> tail_out (16 bit)
+ * The three chains of a conformer block (encoder_layer.py:56-70):
+ *     macaron : x, LN_ffm, FFN_m, ln2 = LN_mha, tail = fused QKV                       (no head)
+ *     conv-in : head = out-proj on the attention context + residual, LN_conv + pad mask, tail = pointwise-conv-1 + GLU
+ *     final   : head = pointwise-conv-2 (+ pad mask) + residual, LN_ff, FFN, ln1 = LN_final
+ * All matrices are 16-bit FRAGMENT-MAJOR: w[((nfrag*KS + kk)*64 + lane)*8 + j] = W[nfrag*16 + (lane&15)][kk*32 + 8*(lane>>4) + j]
+ * (w2f additionally k-permuted, see cfm_ffn_desc).  Instances: D in {144, 256} with the FF / tail sizes of those configs.
+ */
+typedef struct {
+    const float* x;
+    const void* head_a;
+    const void* head_w;
+    const float* head_b;
+    const float* head_res;
+    const uint8_t* head_mask;
+    const float *ln_g, *ln_b;
+    const uint8_t* ln_mask;
+    const void *w1f, *w2f;
+    const float *b1, *b2;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float* out_f32;
+    void* out16;
+    const void* tail_w;
+    const float* tail_b;
+    void* tail_out;
+    int64_t M;
+    int32_t D, FF, tail_N, tail_glu;
+    int32_t w_dtype;
+    float alpha, eps;
+} cfm_rowchain_desc;
+
+int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
+/* 1 when cfm_rowchain has instances for all three chains of a block with these sizes (host query) */
+int cfm_rowchain_supported(int32_t D, int32_t FF);
+
+/* ------------------------------------------------------------------------------------------------
  * LayerNorm (eps inside sqrt, biased variance), optionally two chained norms in one pass:
  *   y1 = LN(x; g1, b1);  if out1: out1 = y1 (out1_dtype)
  *   if g2:  y2 = LN(y1; g2, b2) else y2 = y1;  if out2: out2 = row_mask[m] ? y2 : 0  (out2_dtype)
@@ -219,8 +261,9 @@ typedef struct {
     const float *ffm_b1, *ffm_b2;
     const void *ff_w1, *ff_w1_lo, *ff_w2, *ff_w2_lo;
     const float *ff_b1, *ff_b2;
-    /* optional fragment-major packs for cfm_ffn_fused (NULL: the two-GEMM path is used) */
+    /* optional fragment-major packs for cfm_ffn_fused / cfm_rowchain (NULL: the separate-GEMM path is used) */
     const void *ffm_w1f, *ffm_w2f, *ff_w1f, *ff_w2f;
+    const void *qkv_wf, *out_wf, *pw1_wf, *pw2_wf;
     /* attention: fused qkv [3D,D], pos [D,D] (NULL for plain MHSA), out [D,D] */
     const void *qkv_w, *qkv_w_lo, *pos_w, *pos_w_lo, *out_w, *out_w_lo;
     const float *qkv_b, *out_b, *bias_u, *bias_v;

@@ -353,3 +353,60 @@ def test_ffn_fused(cfm, M, D, FF, wdt, act):
     # bitwise reproducible
     o32b, _ = cfm.ffn_fused(x, w1f, w2f, b1, b2, FF, act=code)
     assert torch.equal(o32, o32b)
+
+
+@pytest.mark.parametrize("M,D,FF", [(7968, 256, 2048), (98, 144, 576), (33, 256, 2048)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+def test_rowchain_three_roles(cfm, M, D, FF, wdt):
+    """The macaron / conv-in / final chains of a conformer block, each one launch, against the same chain in torch."""
+    from cfm import packing
+    dt = W_DT[wdt]
+    code = cfm.BF16 if wdt == "bf16" else cfm.F16
+    F = torch.nn.functional
+    x = rnd((M, D), 100, 1.5) + 0.3
+    a16 = rnd((M, D), 101).to(dt)
+    w1, w2 = rnd((FF, D), 102, D ** -0.5), rnd((D, FF), 103, FF ** -0.5)
+    b1, b2 = rnd((FF,), 104, 0.1), rnd((D,), 105, 0.1)
+    wh, bh = rnd((D, D), 106, D ** -0.5), rnd((D,), 107, 0.1)
+    wq, bq = rnd((3 * D, D), 108, D ** -0.5), rnd((3 * D,), 109, 0.1)
+    wg, bg = rnd((2 * D, D), 110, D ** -0.5), rnd((2 * D,), 111, 0.2)
+    lns = [(1 + 0.1 * rnd((D,), 112 + i), 0.1 * rnd((D,), 116 + i)) for i in range(3)]
+    mask = (torch.rand(M, device="cuda") > 0.3).to(torch.uint8)
+    w1f, w2f = packing.pack_ffn_fragments(w1, w2, dt)
+    r16 = lambda t: t.to(dt).float()
+    lin = lambda a, w, b: r16(a) @ r16(w).t() + b
+    ffn = lambda xn: lin(F.silu(lin(xn, w1, b1)), w2, b2)
+    ln = lambda t, p: F.layer_norm(t, (D,), p[0], p[1], 1e-5)
+    tol = 8e-3 if wdt == "bf16" else 1e-3
+
+    # macaron: x1 = x + 1/2 FFN(LN(x)); qkv = LN_mha(x1) . Wqkv^T + b
+    out = torch.empty_like(x)
+    qkv = torch.empty((M, 3 * D), dtype=dt, device="cuda")
+    cfm.rowchain(M, D, code, x=x, ln=lns[0], ffn=(w1f, w2f, b1, b2, FF), alpha=0.5, ln2=lns[1], out_f32=out,
+                 tail=(packing.pack_frag_major(wq, dt), bq, 3 * D, False, qkv))
+    x1 = x + 0.5 * ffn(ln(x, lns[0]))
+    assert relerr(out, x1) < tol
+    assert relerr(qkv.float(), lin(ln(x1, lns[1]), wq, bq)) < tol + (1e-2 if wdt == "bf16" else 2e-3)
+
+    # conv-in: x2 = x + a16 . Wo^T + b (in place); glu = GLU(mask(LN_conv(x2)) . Wpw1^T + b)
+    idx = packing.glu_interleave_index(D, "cuda")
+    xi = x.clone()
+    glu = torch.empty((M, D), dtype=dt, device="cuda")
+    cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xi, None), ln=lns[2], ln_mask=mask, out_f32=xi,
+                 tail=(packing.pack_frag_major(wg[idx], dt), bg[idx].contiguous(), 2 * D, True, glu))
+    x2 = x + lin(a16.float(), wh, bh)
+    assert relerr(xi, x2) < tol
+    pre = lin(ln(x2, lns[2]) * mask[:, None].float(), wg, bg)
+    assert relerr(glu.float(), pre[:, :D] * torch.sigmoid(pre[:, D:])) < tol + (1e-2 if wdt == "bf16" else 2e-3)
+
+    # final: x3 = x + mask(a16 . Wpw2^T + b); out = LN_final(x3 + 1/2 FFN(LN_ff(x3))), in place
+    xi = x.clone()
+    cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xi, mask), ln=lns[0], ffn=(w1f, w2f, b1, b2, FF), alpha=0.5,
+                 ln1=lns[1], out_f32=xi)
+    x3 = x + lin(a16.float(), wh, bh) * mask[:, None].float()
+    ref = ln(x3 + 0.5 * ffn(ln(x3, lns[0])), lns[1])
+    assert relerr(xi, ref) < tol
+    xj = x.clone()
+    cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xj, mask), ln=lns[0], ffn=(w1f, w2f, b1, b2, FF), alpha=0.5,
+                 ln1=lns[1], out_f32=xj)
+    assert torch.equal(xi, xj)          # bitwise reproducible
