@@ -80,7 +80,7 @@ class LayerIO(ctypes.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("FF", c_i32), ("ktaps", c_i32),
                 ("act_dtype", c_i32), ("w_dtype", c_i32),
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64),
-                ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32),
+                ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32), ("pos_proj", c_p), ("pos_proj_ld", c_i64),
                 ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p)]
 
 

@@ -82,6 +82,107 @@ __global__ __launch_bounds__(256) void cfm_dwconv_kernel(const void* __restrict_
     }
 }
 
+// LDS-tiled variant (the one used for k = 15): a block owns 16 frames x all D channels of one utterance.  The 16+14 input
+// frames are fetched with 16-byte loads into an f32 LDS tile, each thread runs the FIR for 2 adjacent channels over its
+// share of the frames out of a register window filled from LDS, results go back through LDS and leave as 16-byte stores.
+// (The register-only kernel above moves 4 bytes per lane per access: 13.8 us for 8 MB at config 2.)
+constexpr int DW_TS = 16;
+
+template <int KTAPS>
+__global__ __launch_bounds__(256) void cfm_dwconv_tiled_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ dwb, const float* __restrict__ sc,
+                                                               const float* __restrict__ sh, void* __restrict__ y, int x_dt, int y_dt,
+                                                               int T, int D) {
+    constexpr int HALF = (KTAPS - 1) / 2;
+    constexpr int NIN = DW_TS + KTAPS - 1;
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];   // [NIN][D] inputs, then [DW_TS][D] outputs
+    float* tin = dw_lds;
+    float* tout = dw_lds + NIN * D;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * DW_TS;
+    const int64_t ubase = (int64_t)b * T * D;
+    const int c8n = D >> 3;
+    for (int id = tid; id < NIN * c8n; id += 256) {
+        const int row = id / c8n, c = (id - row * c8n) * 8;
+        const int t = t0 - HALF + row;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        if (t >= 0 && t < T) {
+            const int64_t o = ubase + (int64_t)t * D + c;
+            if (x_dt == CFM_F32) {
+                a0 = *(const f32x4*)((const float*)x + o);
+                a1 = *(const f32x4*)((const float*)x + o + 4);
+            } else {
+                const u32x4 r = *(const u32x4*)((const u16*)x + o);
+                const unsigned wv[4] = {r.x, r.y, r.z, r.w};
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u16 lo = (u16)(wv[i] & 0xffffu), hi = (u16)(wv[i] >> 16);
+                    f[2 * i] = x_dt == CFM_BF16 ? BF16::to_f32(lo) : F16::to_f32(lo);
+                    f[2 * i + 1] = x_dt == CFM_BF16 ? BF16::to_f32(hi) : F16::to_f32(hi);
+                }
+                a0 = (f32x4){f[0], f[1], f[2], f[3]};
+                a1 = (f32x4){f[4], f[5], f[6], f[7]};
+            }
+        }
+        *(f32x4*)(tin + row * D + c) = a0;
+        *(f32x4*)(tin + row * D + c + 4) = a1;
+    }
+    __syncthreads();
+    const int pairs = D >> 1;
+    const int groups = 256 / pairs;                     // frame groups per block (D = 256: 2, D = 144: 3)
+    const int fpt = (DW_TS + groups - 1) / groups;      // frames per thread
+    const int pr = tid % pairs, grp = tid / pairs;
+    if (grp < groups) {
+        const int c = pr * 2;
+        float w0[KTAPS], w1[KTAPS];
+#pragma unroll
+        for (int k = 0; k < KTAPS; ++k) {
+            w0[k] = w[(int64_t)c * KTAPS + k];
+            w1[k] = w[(int64_t)(c + 1) * KTAPS + k];
+        }
+        const float b0 = dwb[c], b1 = dwb[c + 1], s0 = sc[c], s1 = sc[c + 1], h0 = sh[c], h1 = sh[c + 1];
+        const int f0 = grp * fpt;
+        constexpr int FMAX = 8;                         // fpt <= 8 for every supported D (pairs >= 32)
+        float xin0[FMAX + KTAPS - 1], xin1[FMAX + KTAPS - 1];
+#pragma unroll
+        for (int i = 0; i < FMAX + KTAPS - 1; ++i) {
+            const int row = f0 + i;
+            float2 v = make_float2(0.f, 0.f);
+            if (i < fpt + KTAPS - 1 && row < NIN) v = *(const float2*)(tin + row * D + c);
+            xin0[i] = v.x;
+            xin1[i] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < FMAX; ++i) {
+            if (i < fpt && f0 + i < DW_TS) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < KTAPS; ++k) {
+                    a0 = fmaf(w0[k], xin0[i + k], a0);
+                    a1 = fmaf(w1[k], xin1[i + k], a1);
+                }
+                *(float2*)(tout + (f0 + i) * D + c) = make_float2(siluf_((a0 + b0) * s0 + h0), siluf_((a1 + b1) * s1 + h1));
+            }
+        }
+    }
+    __syncthreads();
+    for (int id = tid; id < DW_TS * c8n; id += 256) {
+        const int row = id / c8n, c = (id - row * c8n) * 8;
+        const int t = t0 + row;
+        if (t >= T) continue;
+        const f32x4 a0 = *(const f32x4*)(tout + row * D + c), a1 = *(const f32x4*)(tout + row * D + c + 4);
+        const int64_t o = ubase + (int64_t)t * D + c;
+        if (y_dt == CFM_F32) {
+            *(f32x4*)((float*)y + o) = a0;
+            *(f32x4*)((float*)y + o + 4) = a1;
+        } else {
+            *(u32x4*)((u16*)y + o) = y_dt == CFM_BF16 ? pack8<BF16>(a0, a1) : pack8<F16>(a0, a1);
+        }
+    }
+}
+
 // generic tap count (no register window): re-reads inputs through L1/L2
 __global__ __launch_bounds__(256) void cfm_dwconv_generic_kernel(const void* x, const float* w, const float* dwb, const float* sc,
                                                                  const float* sh, void* y, int x_dt, int y_dt, int T, int D,
@@ -196,7 +297,11 @@ extern "C" int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, co
     hipStream_t s = (hipStream_t)stream;
     const double bytes = (double)B * T * D * (cfm_elt_size(x_dtype) + cfm_elt_size(y_dtype));
     CfmProfScope prof("dwconv_bn_silu", s, 2.0 * B * T * (double)D * ktaps, bytes);
-    if (ktaps == 15) {
+    if (ktaps == 15 && D % 8 == 0 && D >= 64 && D <= 512) {
+        const dim3 grid((unsigned)((T + DW_TS - 1) / DW_TS), B), block(256);
+        const size_t lds = (size_t)(DW_TS + 14 + DW_TS) * D * sizeof(float);
+        hipLaunchKernelGGL((cfm_dwconv_tiled_kernel<15>), grid, block, lds, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype, y_dtype, T, D);
+    } else if (ktaps == 15) {
         const int segs = (T + TSEG - 1) / TSEG;
         const dim3 grid((unsigned)(((int64_t)segs * (D / 2) + 255) / 256), B), block(256);
         if (x_dtype == CFM_F32)

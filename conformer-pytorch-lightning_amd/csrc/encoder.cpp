@@ -67,7 +67,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     const int Tk = Tc + io->T;
     int P = 0;
     if (has_pos) {
-        CFM_CHECK_ARG(io->pos_embed && io->pos_rows % io->B == 0, "encoder layer: pos_embed rows (%d) must be a multiple of B (%d)",
+        CFM_CHECK_ARG((io->pos_embed || io->pos_proj) && io->pos_rows % io->B == 0, "encoder layer: pos_embed rows (%d) must be a multiple of B (%d)",
                       io->pos_rows, io->B);
         P = io->pos_rows / io->B;
         CFM_CHECK_ARG(P == 1 || P == Tk, "encoder layer: pos_embed gives %d rows per item, need 1 or Tk=%d (attention.py:78-88)", P, Tk);
@@ -104,7 +104,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     // (2) self-attention
     if (!chains)
         CFM_TRY(gemm(c, s->xn, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, s->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr));
-    if (has_pos)
+    if (has_pos && !io->pos_proj)
         CFM_TRY(gemm(c, io->pos_embed, CFM_F32, D, w->pos_w, w->pos_w_lo, nullptr, s->pos, adt, D, io->pos_rows, D, D, CFM_ACT_NONE,
                      nullptr, 0.f, nullptr));
     const void* kq = eoff(s->qkv, D, adt);
@@ -122,7 +122,8 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         a.k_sb = a.v_sb = sb; a.k_sh = a.v_sh = dk; a.k_st = a.v_st = stt;
     }
     if (has_pos) {
-        a.p = s->pos; a.p_dtype = adt; a.p_sb = (int64_t)P * D; a.p_st = P == 1 ? 0 : D;
+        const int64_t pld = io->pos_proj ? io->pos_proj_ld : D;
+        a.p = io->pos_proj ? io->pos_proj : s->pos; a.p_dtype = adt; a.p_sb = (int64_t)P * pld; a.p_st = P == 1 ? 0 : pld;
         a.bias_u = w->bias_u; a.bias_v = w->bias_v;
     }
     a.mask = io->attn_mask; a.m_sb = io->am_sb; a.m_sq = io->am_sq;

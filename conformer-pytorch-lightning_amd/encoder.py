@@ -46,6 +46,7 @@ class ConformerEncoder(nn.Module):
     def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from):
         """x (B,T',D) f32 -> after_norm(blocks(x)); returns (y, [trimmed per-layer caches] | None)."""
         n = len(self.encoders)
+        proj = self._project_positions(pos_embed, x)
         bufs = [torch.empty_like(x), torch.empty_like(x)]
         new_caches = [] if caches is not None else None
         cur, ready = x, False
@@ -54,14 +55,30 @@ class ConformerEncoder(nn.Module):
             cache_i = None
             if caches is not None and caches.dim() == 4 and caches.size(0) > 0:
                 cache_i = caches[i:i + 1]
+            pp = None if proj is None else (proj[:, i * self.encoder_dim:], proj.stride(0))
             out, nc = block.fused_forward(cur, attn_mask, pos_embed, pad_mask, cache_i, xn_ready=ready, next_norm=nxt,
-                                          out=bufs[i & 1], want_cache=caches is not None)
+                                          out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp)
             if new_caches is not None:
                 new_caches.append(nc[:, :, keep_from:, :])
             cur, ready = out, nxt is not None
         y, _ = cfm.layernorm(cur.view(-1, cur.size(-1)), self.after_norm.weight.detach(), self.after_norm.bias.detach(),
                              eps=self.after_norm.eps)
         return y.view_as(cur), new_caches
+
+    def _project_positions(self, pos_embed, x):
+        """linear_pos of EVERY block applied to pos_embed in one GEMM: [R, D] . [L*D, D]^T -> [R, L*D] (block i reads columns
+        i*D .. (i+1)*D).  The per-block projections are 8 us launches of a 32-row GEMM in the batch path otherwise."""
+        if not isinstance(self.position_encoding, RelativePositionalEncoding) or pos_embed is None:
+            return None
+        from cfm import packing
+        prec = cfm.get_precision()
+        ws = [blk.self_attn.linear_pos.weight for blk in self.encoders]
+        if not hasattr(self, "_pos_pack"):
+            self._pos_pack = packing.PackCache()
+        pk = self._pos_pack.get(ws, prec, lambda: packing.Packed(w=packing.matrix(torch.cat([w.detach() for w in ws], 0), prec)))
+        pe = pos_embed.reshape(-1, self.encoder_dim)
+        pe = (pe if pe.dtype == torch.float32 else pe.float()).contiguous()
+        return cfm.gemm(pe, pk.w[0], w_lo=pk.w[1], out_dtype=prec.act_dtype)
 
     def forward(self, inputs, input_lengths, decoding_chunk_size=0, num_decoding_chunk_size=-1):
         if self.global_cmvn is not None:

@@ -60,7 +60,7 @@ class ConformerEncoderLayer(nn.Module):
         return self._fused[1]
 
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
-                      want_cache=True):
+                      want_cache=True, pos_proj=None):
         """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified."""
         _inference_only(self, "ConformerEncoderLayer")
         if self.training:
@@ -116,6 +116,8 @@ class ConformerEncoderLayer(nn.Module):
         io.attn_mask, io.am_sb, io.am_sq = cfm.ptr(m8), m_sb, m_sq
         io.pad_valid = cfm.ptr(keep)
         io.pos_embed, io.pos_rows = cfm.ptr(pos), R
+        if pos_proj is not None:                       # (tensor view [R, D] of the driver's all-blocks projection, row stride)
+            io.pos_proj, io.pos_proj_ld = pos_proj[0].data_ptr(), pos_proj[1]
         io.attn_cache, io.cache_T = cfm.ptr(cache), Tc
         io.new_cache = cfm.ptr(new_cache)
 

@@ -285,6 +285,9 @@ typedef struct {
     const uint8_t* pad_valid; /* [B*T] or NULL */
     const float* pos_embed;   /* f32 [R,D] rows, R = B*P */
     int32_t pos_rows;         /* R (0: plain MHSA) */
+    const void* pos_proj;     /* optional: linear_pos(pos_embed) already projected (act dtype), row stride pos_proj_ld;
+                                 lets the driver project the positions of ALL blocks with one GEMM */
+    int64_t pos_proj_ld;
     const float* attn_cache;  /* f32 [B,H,Tc,2dk] or NULL */
     int32_t cache_T;
     float* new_cache;         /* f32 [B,H,Tc+T,2dk] or NULL (not materialised) */
