@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "valid_mask", "chunk_mask",
+__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -112,8 +112,26 @@ def rowchain_supported(D, FF, prec):
     return (not prec.split) and bool(_c.lib().cfm_rowchain_supported(D, FF))
 
 
+def ffn_partial(x, ln, w1f, w2f, b1, FF, y0, y1, pending=None, head=None, x_out=None, eps=1e-5):
+    """Partial feed-forward over FF halves on 64-row tiles (include/cfm.h cfm_ffn_partial): writes y0, y1 (f32 [M,D]).
+    pending = (py0, py1, pb2, palpha, pln | None);  head = (a16, w_frag, bias, mask | None)."""
+    _c.require_hip(x, w1f, w2f, b1, y0, y1, x_out)
+    M, D = x.shape
+    d = _c.FfnPartialDesc()
+    d.x, d.ln_g, d.ln_b, d.w1f, d.w2f, d.b1, d.y0, d.y1, d.x_out = (_c.ptr(x), _c.ptr(ln[0]), _c.ptr(ln[1]), _c.ptr(w1f), _c.ptr(w2f),
+                                                                     _c.ptr(b1), _c.ptr(y0), _c.ptr(y1), _c.ptr(x_out))
+    if pending is not None:
+        d.py0, d.py1, d.pb2, d.palpha = _c.ptr(pending[0]), _c.ptr(pending[1]), _c.ptr(pending[2]), pending[3]
+        if pending[4] is not None:
+            d.pln_g, d.pln_b = _c.ptr(pending[4][0]), _c.ptr(pending[4][1])
+    if head is not None:
+        d.head_a, d.head_w, d.head_b, d.head_mask = _c.ptr(head[0]), _c.ptr(head[1]), _c.ptr(head[2]), _c.ptr(head[3])
+    d.M, d.D, d.FF, d.w_dtype, d.eps = M, D, FF, _c.dt_code(w1f), eps
+    _c.check(_c.lib().cfm_ffn_partial(ctypes.byref(d), _c.stream()), "cfm_ffn_partial")
+
+
 def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, alpha=1.0, ln1=None, ln2=None, out_f32=None, out16=None,
-             tail=None, eps=1e-5):
+             tail=None, eps=1e-5, pending=None):
     """One-launch row-local chain (include/cfm.h cfm_rowchain).
     head = (a16 [M,D], w_frag, bias, residual f32 [M,D], out_mask u8 [M] | None);  ffn = (w1f, w2f, b1, b2, FF);
     tail = (w_frag, bias, N, glu, out 16-bit [M, N or N/2]);  ln/ln1/ln2 = (gain, bias)."""
@@ -133,6 +151,10 @@ def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, a
         d.w1f, d.w2f, d.b1, d.b2, d.FF = _c.ptr(ffn[0]), _c.ptr(ffn[1]), _c.ptr(ffn[2]), _c.ptr(ffn[3]), ffn[4]
     if tail is not None:
         d.tail_w, d.tail_b, d.tail_N, d.tail_glu, d.tail_out = _c.ptr(tail[0]), _c.ptr(tail[1]), tail[2], 1 if tail[3] else 0, _c.ptr(tail[4])
+    if pending is not None:                     # (py0, py1, pb2, palpha, pln | None): finish a partial FFN while loading the rows
+        d.py0, d.py1, d.pb2, d.palpha = _c.ptr(pending[0]), _c.ptr(pending[1]), _c.ptr(pending[2]), pending[3]
+        if pending[4] is not None:
+            d.pln_g, d.pln_b = _c.ptr(pending[4][0]), _c.ptr(pending[4][1])
     _c.require_hip(x, out_f32, out16)
     d.M, d.D, d.w_dtype, d.alpha, d.eps = M, D, w_code, alpha, eps
     _c.check(_c.lib().cfm_rowchain(ctypes.byref(d), _c.stream()), "cfm_rowchain")

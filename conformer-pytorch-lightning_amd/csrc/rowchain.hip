@@ -30,6 +30,8 @@
 
 struct ChainArgs {
     const float* x;           // f32 rows (no HEAD)
+    const float *py0, *py1, *pb2, *pln_g, *pln_b;   // optional reduce input (pending partial FFN of the previous kernel)
+    float palpha;
     const u16* head_a;        // 16-bit [M,D] (HEAD)
     const u16* head_w;        // fragment-major [D/16][KS][64][8]
     const float* head_b;
@@ -166,11 +168,43 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
                 v[it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
             } else {
                 v[it] = c < D ? *(const f32x4*)(a.x + grow * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a.py0 && c < D) {
+                    const f32x4 y = *(const f32x4*)(a.py0 + grow * D + c) + *(const f32x4*)(a.py1 + grow * D + c);
+                    v[it] += a.palpha * (y + *(const f32x4*)(a.pb2 + c));
+                }
+            }
+        }
+        if constexpr (!HEAD) {
+            if (a.py0 && a.pln_g) {                        // norm_final of the block whose FFN was pending
+                float s1 = 0.f;
+#pragma unroll
+                for (int it = 0; it < VPL; ++it)
+                    if ((lane + 64 * it) * 4 < D) s1 += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+                const float mean = wave_sum(s1) / (float)D;
+                float q = 0.f;
+#pragma unroll
+                for (int it = 0; it < VPL; ++it)
+                    if ((lane + 64 * it) * 4 < D) {
+                        const f32x4 d = v[it] - mean;
+                        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                    }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    if (c < D) v[it] = (v[it] - mean) * rstd * *(const f32x4*)(a.pln_g + c) + *(const f32x4*)(a.pln_b + c);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
                 if (c < D) *(f32x4*)(xs + r * XS_STRIDE + c) = v[it];
             }
-            if (c < D) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
         }
-        if constexpr (HEAD && !MID) {                      // conv-in: the head result IS the new residual stream
+#pragma unroll
+        for (int it = 0; it < VPL; ++it)
+            if ((lane + 64 * it) * 4 < D) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        if constexpr (!MID) {                              // no FFN here: the rows ARE the new residual stream
             if (row0 + r < a.M && a.out_f32) {
 #pragma unroll
                 for (int it = 0; it < VPL; ++it) {
@@ -448,6 +482,8 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     a.b1 = d->b1; a.b2 = d->b2; a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32;
     a.out16 = d->out16; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M; a.FF = d->FF;
     a.tail_N = d->tail_N; a.out16_dtype = d->w_dtype; a.alpha = d->alpha; a.eps = d->eps;
+    a.py0 = d->py0; a.py1 = d->py1; a.pb2 = d->pb2; a.pln_g = d->pln_g; a.pln_b = d->pln_b; a.palpha = d->palpha;
+    CFM_CHECK_ARG(!d->py0 || (d->py1 && d->pb2 && !head), "cfm_rowchain: the reduce input needs both slabs and the bias, and no head");
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->w_dtype == CFM_BF16;
     const int fsteps = mid ? (d->FF / 32 + 3) / 4 : 0;
@@ -462,10 +498,14 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
         if (!head && mid && tail && !d->tail_glu && fsteps == 16 && tsteps == 6) { if (bf) CFM_RC(BF16, 256, 0, 16, 6, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 0, 16, 6, false, "chain_macaron_f16_d256"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 4) { if (bf) CFM_RC(BF16, 256, 2, 0, 4, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 2, 0, 4, true, "chain_convin_f16_d256"); }
         if (head && mid && !tail && fsteps == 16) { if (bf) CFM_RC(BF16, 256, 2, 16, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 2, 16, 0, false, "chain_final_f16_d256"); }
+        if (!head && !mid && tail && !d->tail_glu && tsteps == 6) { if (bf) CFM_RC(BF16, 256, 0, 0, 6, false, "chain_qkv_bf16_d256"); else CFM_RC(F16, 256, 0, 0, 6, false, "chain_qkv_f16_d256"); }
+        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 256, 0, 0, 0, false, "chain_rows_bf16_d256"); else CFM_RC(F16, 256, 0, 0, 0, false, "chain_rows_f16_d256"); }
     } else {
         if (!head && mid && tail && !d->tail_glu && fsteps == 5 && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 0, 5, 4, false, "chain_macaron_bf16_d144"); else CFM_RC(F16, 144, 0, 5, 4, false, "chain_macaron_f16_d144"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 144, 2, 0, 3, true, "chain_convin_bf16_d144"); else CFM_RC(F16, 144, 2, 0, 3, true, "chain_convin_f16_d144"); }
         if (head && mid && !tail && fsteps == 5) { if (bf) CFM_RC(BF16, 144, 2, 5, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 2, 5, 0, false, "chain_final_f16_d144"); }
+        if (!head && !mid && tail && !d->tail_glu && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 0, 0, 4, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 0, 0, 4, false, "chain_qkv_f16_d144"); }
+        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 0, 0, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 0, 0, 0, false, "chain_rows_f16_d144"); }
     }
 #undef CFM_RC
     return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: no instance for D=%d FF=%d tail_N=%d head=%d mid=%d tail=%d glu=%d", d->D, d->FF,

@@ -50,6 +50,10 @@ class ConformerEncoder(nn.Module):
         bufs = [torch.empty_like(x), torch.empty_like(x)]
         new_caches = [] if caches is not None else None
         cur, ready = x, False
+        prec = cfm.get_precision()
+        handover = (self.encoders[0]._use_partial_ffn and cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
+                    bool(cfm.lib().cfm_ffn_partial_supported(self.encoder_dim, self.encoders[0].hidden_dim)))
+        pending = None
         for i, block in enumerate(self.encoders):
             nxt = self.encoders[i + 1].norm_ff_macaron if i + 1 < n else None
             cache_i = None
@@ -57,7 +61,9 @@ class ConformerEncoder(nn.Module):
                 cache_i = caches[i:i + 1]
             pp = None if proj is None else (proj[:, i * self.encoder_dim:], proj.stride(0))
             out, nc = block.fused_forward(cur, attn_mask, pos_embed, pad_mask, cache_i, xn_ready=ready, next_norm=nxt,
-                                          out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp)
+                                          out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pending=pending,
+                                          defer_final=handover and i + 1 < n)
+            pending = block.pending_handover(prec) if handover and i + 1 < n else None
             if new_caches is not None:
                 new_caches.append(nc[:, :, keep_from:, :])
             cur, ready = out, nxt is not None

@@ -124,6 +124,7 @@ int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Row-local chain on 32-row tiles, one launch (csrc/rowchain.hip):
  *     x  = head_a ? head_res + mask_out( head_a . Wh^T + head_b ) : x          (head_mask zeroes the product's row)
+ *          or, with py0: x = LN?( x + palpha * (py0 + py1 + pb2) )  (a pending partial FFN, see cfm_ffn_partial)
  *     xn = LN(x; ln_g, ln_b), rows with ln_mask == 0 zeroed
  *     y  = w1f ? x + alpha * FFN(xn) : x                                         (FFN as in cfm_ffn_fused, SiLU)
  *     y1 = ln1_g ? LN(y) : y -> out_f32        (head without FFN: out_f32 receives x, the new residual stream)
@@ -138,6 +139,7 @@ int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
  */
 typedef struct {
     const float* x;
+    const float *py0, *py1, *pb2, *pln_g, *pln_b; /* optional reduce input: x = LN?(x + palpha*(py0+py1+pb2)), see cfm_ffn_partial */
     const void* head_a;
     const void* head_w;
     const float* head_b;
@@ -156,12 +158,44 @@ typedef struct {
     int64_t M;
     int32_t D, FF, tail_N, tail_glu;
     int32_t w_dtype;
-    float alpha, eps;
+    float alpha, eps, palpha;
 } cfm_rowchain_desc;
 
 int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
 /* 1 when cfm_rowchain has instances for all three chains of a block with these sizes (host query) */
 int cfm_rowchain_supported(int32_t D, int32_t FF);
+
+/* ------------------------------------------------------------------------------------------------
+ * Feed-forward block as PARTIAL sums (csrc/ffnpart.hip): 2 x ceil(M/64) workgroups, workgroup (tile, half) streams one
+ * half of W1/W2 for 64 rows and writes
+ *     y_half[M,D] = SiLU( LN(x; ln_g, ln_b) . W1[half]^T + b1[half] ) . W2[:, half]^T                     (f32, no bias)
+ * The consumer (this entry point's reduce input, or cfm_rowchain's) finishes  x + alpha * (y0 + y1 + b2).
+ * Input rows x are one of
+ *     plain     x (f32 [M,D])
+ *     reduce    x = LN?( x + palpha * (py0 + py1 + pb2); pln_g, pln_b )     -- the previous block's pending FFN + norm_final
+ *     head      x = x + mask( head_a . Wh^T + head_b )                      -- pointwise-conv-2 + pad mask + residual
+ * and for reduce/head the rows are written to x_out (which must NOT alias x: two workgroups read each row tile).
+ * Weights are the fragment-major packs of cfm_ffn_fused.  Instances: (D,FF) in {(256,2048), (144,576)}.
+ */
+typedef struct {
+    const float* x;
+    const float *py0, *py1, *pb2, *pln_g, *pln_b;
+    const void* head_a;
+    const void* head_w;
+    const float* head_b;
+    const uint8_t* head_mask;
+    float* x_out;
+    const float *ln_g, *ln_b;
+    const void *w1f, *w2f;
+    const float* b1;
+    float *y0, *y1;
+    int64_t M;
+    int32_t D, FF, w_dtype;
+    float palpha, eps;
+} cfm_ffn_partial_desc;
+
+int cfm_ffn_partial(const cfm_ffn_partial_desc* d, cfm_stream_t stream);
+int cfm_ffn_partial_supported(int32_t D, int32_t FF);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (eps inside sqrt, biased variance), optionally two chained norms in one pass:
@@ -274,6 +308,9 @@ typedef struct {
 
 typedef struct {
     void *xn, *hid, *qkv, *pos, *ctx, *glu, *dw; /* activation-dtype scratch: [M,D],[M,FF],[M,3D],[R,D],[M,D],[M,D],[M,D] */
+    /* optional f32 [M,D] buffers of the partial-FFN pipeline (all five or none): the rows entering the block's last FFN,
+     * and two pairs of partial slabs (pending-from-previous-block, macaron) */
+    float *xs2, *yp0, *yp1, *yq0, *yq1;
 } cfm_layer_scratch;
 
 typedef struct {
@@ -285,6 +322,12 @@ typedef struct {
     const uint8_t* pad_valid; /* [B*T] or NULL */
     const float* pos_embed;   /* f32 [R,D] rows, R = B*P */
     int32_t pos_rows;         /* R (0: plain MHSA) */
+    /* partial-FFN pipeline chaining between consecutive blocks (used by the encoder driver; 0 / NULL otherwise):
+     *   pending_in   the PREVIOUS block left its last feed-forward unfinished: scratch xs2 holds its input rows, yp0/yp1 the
+     *                partial sums; pend_b2 / pend_ln_* are that block's w_2.bias and norm_final.  x_in is ignored.
+     *   defer_final  leave THIS block's last feed-forward pending in the same way (x_out then is NOT the block output). */
+    int32_t pending_in, defer_final;
+    const float *pend_b2, *pend_ln_g, *pend_ln_b;
     const void* pos_proj;     /* optional: linear_pos(pos_embed) already projected (act dtype), row stride pos_proj_ld;
                                  lets the driver project the positions of ALL blocks with one GEMM */
     int64_t pos_proj_ld;

@@ -36,29 +36,30 @@ def run(name, M, N, K, act=0, res=False, out_dt=torch.bfloat16, tile=0, a_dt=tor
         name, M, N, K, tile, us, 2.0 * M * N * K / us / 1e6, out.numel() * out.element_size() / 1e6), flush=True)
 
 
-M = 7968
-print("--- empty-ish kernels: launch + epilogue floor")
-run("K=64 N=256 bf16 out", M, 256, 64)
-run("K=64 N=2048 bf16 out", M, 2048, 64)
-run("K=64 N=2048 f32 out", M, 2048, 64, out_dt=torch.float32)
-print("--- FFN1 variants")
-for t in (1, 2, 3, 4):
-    run("ffn1 silu", M, 2048, 256, cfm.ACT_SILU, tile=t)
-run("ffn1 no act", M, 2048, 256, 0, tile=1)
-run("ffn1 silu f32 out", M, 2048, 256, cfm.ACT_SILU, out_dt=torch.float32, tile=1)
-run("ffn1 K=128", M, 2048, 128, cfm.ACT_SILU, tile=1)
-run("ffn1 K=512", M, 2048, 512, cfm.ACT_SILU, tile=1)
-run("ffn1 K=1024", M, 2048, 1024, cfm.ACT_SILU, tile=1)
-print("--- FFN2 variants")
-for t in (1, 2, 3, 4, 5, 6):
-    run("ffn2 +res", M, 256, 2048, 0, True, tile=t)
-run("ffn2 no res bf16 out", M, 256, 2048, 0, False, tile=2)
-print("--- small ones")
-for t in (2, 3, 5):
-    run("out-proj +res", M, 256, 256, 0, True, tile=t)
-    run("qkv", M, 768, 256, 0, False, tile=t)
-    run("pw1 glu", M, 512, 256, cfm.ACT_GLU, False, tile=t)
-run("pos gemm (a f32)", 32, 256, 256, a_dt=torch.float32)
-print("--- square reference points")
-run("4096^3", 4096, 4096, 4096, tile=1)
-run("8192x8192x1024", 8192, 8192, 1024, tile=1)
+if __name__ == "__main__":
+    M = 7968
+    print("--- empty-ish kernels: launch + epilogue floor")
+    run("K=64 N=256 bf16 out", M, 256, 64)
+    run("K=64 N=2048 bf16 out", M, 2048, 64)
+    run("K=64 N=2048 f32 out", M, 2048, 64, out_dt=torch.float32)
+    print("--- FFN1 variants")
+    for t in (1, 2, 3, 4):
+        run("ffn1 silu", M, 2048, 256, cfm.ACT_SILU, tile=t)
+    run("ffn1 no act", M, 2048, 256, 0, tile=1)
+    run("ffn1 silu f32 out", M, 2048, 256, cfm.ACT_SILU, out_dt=torch.float32, tile=1)
+    run("ffn1 K=128", M, 2048, 128, cfm.ACT_SILU, tile=1)
+    run("ffn1 K=512", M, 2048, 512, cfm.ACT_SILU, tile=1)
+    run("ffn1 K=1024", M, 2048, 1024, cfm.ACT_SILU, tile=1)
+    print("--- FFN2 variants")
+    for t in (1, 2, 3, 4, 5, 6):
+        run("ffn2 +res", M, 256, 2048, 0, True, tile=t)
+    run("ffn2 no res bf16 out", M, 256, 2048, 0, False, tile=2)
+    print("--- small ones")
+    for t in (2, 3, 5):
+        run("out-proj +res", M, 256, 256, 0, True, tile=t)
+        run("qkv", M, 768, 256, 0, False, tile=t)
+        run("pw1 glu", M, 512, 256, cfm.ACT_GLU, False, tile=t)
+    run("pos gemm (a f32)", 32, 256, 256, a_dt=torch.float32)
+    print("--- square reference points")
+    run("4096^3", 4096, 4096, 4096, tile=1)
+    run("8192x8192x1024", 8192, 8192, 1024, tile=1)

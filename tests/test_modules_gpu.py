@@ -308,3 +308,22 @@ def test_cpu_tensors_fail_loudly(pkg):
     layer = pkg.encoder_layer.ConformerEncoderLayer(16, 15, 0.0, 0.0, 32, 2, True).to(DEV)      # train mode
     with pytest.raises(NotImplementedError):
         layer(torch.zeros(1, 4, 16, device=DEV), torch.ones((0, 0, 0)), torch.zeros(1, 1, 16, device=DEV))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_partial_ffn_pipeline_matches_reference(pkg, mode):
+    """The opt-in 64-row x FF-half feed-forward pipeline (ffnpart.hip, chained between blocks) on the 12-layer fixture and on
+    config 1, including the stand-alone block call (which must finish its own pending feed-forward)."""
+    pkg.cfm.set_precision(mode)
+    for name in ("enc_cfg2s", "enc_cfg1"):
+        g, meta = load_golden(name)
+        enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+        for blk in enc.encoders:
+            blk._use_partial_ffn = True
+        x = dev(synth.fbank(meta["xseed"], meta["batch"], meta["frames"]))
+        lens = torch.tensor(meta["lens"], dtype=torch.int32, device=DEV)
+        with torch.no_grad():
+            y, m = enc(x, lens)
+            y2, _ = reference_style_forward(pkg, enc, x, lens)          # blocks called one by one: no hand-over between them
+        check(name + " partial-FFN pipeline (chained)", y, g["y"], mode)
+        check(name + " partial-FFN pipeline (stand-alone blocks)", y2, g["y"], mode)

@@ -410,3 +410,64 @@ def test_rowchain_three_roles(cfm, M, D, FF, wdt):
     cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xj, mask), ln=lns[0], ffn=(w1f, w2f, b1, b2, FF), alpha=0.5,
                  ln1=lns[1], out_f32=xj)
     assert torch.equal(xi, xj)          # bitwise reproducible
+
+
+@pytest.mark.parametrize("M,D,FF", [(7968, 256, 2048), (98, 144, 576), (65, 256, 2048)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+def test_ffn_partial_and_reduce(cfm, M, D, FF, wdt):
+    """Partial FFN (64-row tiles x FF halves) in its three input modes, finished by the reduce input of the next kernel."""
+    from cfm import packing
+    dt = W_DT[wdt]
+    code = cfm.BF16 if wdt == "bf16" else cfm.F16
+    F = torch.nn.functional
+    x = rnd((M, D), 120, 1.5) + 0.3
+    w1, w2 = rnd((FF, D), 121, D ** -0.5), rnd((D, FF), 122, FF ** -0.5)
+    b1, b2 = rnd((FF,), 123, 0.1), rnd((D,), 124, 0.1)
+    lns = [(1 + 0.1 * rnd((D,), 125 + i), 0.1 * rnd((D,), 129 + i)) for i in range(3)]
+    w1f, w2f = packing.pack_ffn_fragments(w1, w2, dt)
+    r16 = lambda t: t.to(dt).float()
+    lin = lambda a, w, b: r16(a) @ r16(w).t() + b
+    ln = lambda t, p: F.layer_norm(t, (D,), p[0], p[1], 1e-5)
+    ffn_nobias = lambda xn: r16(F.silu(lin(xn, w1, b1))) @ r16(w2).t()
+    tol = 8e-3 if wdt == "bf16" else 1e-3
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+
+    # plain input; y0 + y1 == FFN without the second bias
+    x0 = x.clone()
+    cfm.ffn_partial(x, lns[0], w1f, w2f, b1, FF, y0, y1)
+    assert torch.equal(x, x0)
+    assert relerr(y0 + y1, ffn_nobias(ln(x, lns[0]))) < tol
+    ya, yb = y0.clone(), y1.clone()
+    cfm.ffn_partial(x, lns[0], w1f, w2f, b1, FF, y0, y1)
+    assert torch.equal(ya, y0) and torch.equal(yb, y1)                       # reproducible
+
+    # consumer 1: rowchain reduce + LN + QKV-shaped tail
+    wq, bq = rnd((3 * D, D), 133, D ** -0.5), rnd((3 * D,), 134, 0.1)
+    out = torch.empty_like(x)
+    qkv = torch.empty((M, 3 * D), dtype=dt, device="cuda")
+    cfm.rowchain(M, D, code, x=x, pending=(y0, y1, b2, 0.5, None), ln=lns[1], out_f32=out,
+                 tail=(packing.pack_frag_major(wq, dt), bq, 3 * D, False, qkv))
+    x1 = x + 0.5 * (ffn_nobias(ln(x, lns[0])) + b2)
+    assert relerr(out, x1) < tol
+    assert relerr(qkv.float(), lin(ln(x1, lns[1]), wq, bq)) < tol + (1e-2 if wdt == "bf16" else 2e-3)
+
+    # consumer 2: rows only (reduce + norm_final), no tail
+    fin = torch.empty_like(x)
+    cfm.rowchain(M, D, code, x=x, pending=(y0, y1, b2, 0.5, lns[2]), out_f32=fin)
+    assert relerr(fin, ln(x1, lns[2])) < tol
+
+    # consumer 3: the next partial FFN's own reduce input (+ norm_final), rows written back by the half-0 workgroups
+    z0, z1, xo = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    cfm.ffn_partial(x, lns[1], w1f, w2f, b1, FF, z0, z1, pending=(y0, y1, b2, 0.5, lns[2]), x_out=xo)
+    xin = ln(x1, lns[2])
+    assert relerr(xo, xin) < tol
+    assert relerr(z0 + z1, ffn_nobias(ln(xin, lns[1]))) < tol * 2
+
+    # head input: rows = x + mask(a16 . Wh^T + bh), written back
+    a16 = rnd((M, D), 135).to(dt)
+    wh, bh = rnd((D, D), 136, D ** -0.5), rnd((D,), 137, 0.1)
+    mask = (torch.rand(M, device="cuda") > 0.3).to(torch.uint8)
+    cfm.ffn_partial(x, lns[0], w1f, w2f, b1, FF, z0, z1, head=(a16, packing.pack_frag_major(wh, dt), bh, mask), x_out=xo)
+    x3 = x + lin(a16.float(), wh, bh) * mask[:, None].float()
+    assert relerr(xo, x3) < tol
+    assert relerr(z0 + z1, ffn_nobias(ln(x3, lns[0]))) < tol * 2
