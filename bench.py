@@ -117,6 +117,29 @@ def selftest_cpu(args):
         dist.destroy_process_group()
 
 
+KERNEL_SYMBOL = {"chain_macaron": "cfm_rowchain_kernel", "chain_final": "cfm_rowchain_kernel", "chain_convin": "cfm_rowchain_kernel",
+                 "chain_qkv": "cfm_rowchain_kernel", "ffn_fused": "cfm_ffn_kernel", "ffn_partial": "cfm_ffnpart_kernel",
+                 "gemm_conv": "cfm_gemm_kernel", "gemm": "cfm_gemm_kernel", "attn2": "cfm_attn2_kernel", "attn": "cfm_attn_kernel"}
+
+
+def measured_traffic(kernel_name, d_model):
+    """HBM bytes per launch of the dominant kernel from profiles/*_hbm_traffic.json (scripts/collect_traffic.py: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction), or None when no such profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    kernels = json.load(open(files[-1]))["kernels"]
+    role = {"chain_macaron": "0, 16, 6, false", "chain_final": "2, 16, 0, false", "chain_convin": "2, 0, 4, true"}
+    for prefix, sym in KERNEL_SYMBOL.items():
+        if kernel_name.startswith(prefix):
+            want = role.get(prefix)
+            for k, v in kernels.items():
+                if sym in k and (want is None or (want in k and ("%d," % d_model) in k)):
+                    return round(v["hbm_bytes_per_launch"], 1)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,14 +228,14 @@ def main():
 
     if rank == 0:
         total_ms = sum(e["ms"] for e in table.values()) or 1.0
-        mfma = {k: e for k, e in table.items() if e["flops"] > 0 and k.split("_")[0] in ("gemm", "attn", "ffn")}
+        mfma = {k: e for k, e in table.items() if e["flops"] > 0 and k.split("_")[0] in ("gemm", "attn", "attn2", "ffn", "chain")}
         if mfma:
             name, e = max(mfma.items(), key=lambda kv: kv[1]["ms"])
             avg_ms = e["ms"] / e["calls"]
             achieved = e["flops"] / e["calls"] / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.precision]
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "frac": round(achieved / peak, 4), "traffic": measured_traffic(name, CFG2["encoder_dim"]),
                         "launches_per_step": e["calls"] // args.steps, "avg_launch_us": round(avg_ms * 1e3, 2),
                         "share_of_device_time": round(e["ms"] / total_ms, 4),
                         "algorithmic_gflop_per_launch": round(e["flops"] / e["calls"] / 1e9, 3)}

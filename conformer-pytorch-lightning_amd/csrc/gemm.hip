@@ -56,9 +56,18 @@ __global__ __launch_bounds__(256) void cfm_gemm_kernel(const GemmArgs g) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so the N tiles
+    // of ONE M tile are given ids 8 apart: they re-read the same activation rows from the same L2 instead of each pulling
+    // them over the fabric (measured on the front-end conv: 1.49 GB of HBM traffic per launch for 0.34 GB of compulsory bytes).
+    // Speed only -- any placement computes the same result.
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM;
-    const int n0 = (blockIdx.x % tiles_n) * BN;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int per_group = 8 * tiles_n;
+    const int grp = blockIdx.x / per_group, rem = blockIdx.x % per_group;
+    const int tile_m = grp * 8 + (rem % 8);
+    if (tile_m >= tiles_m) return;                      // padding blocks of the last group (uniform: before any barrier)
+    const int m0 = tile_m * BM;
+    const int n0 = (rem / 8) * BN;
 
     auto lds_idx = [](int row, int c) { return row * CPR + (c ^ ((row / RPB) % CPR)); };
 
@@ -292,7 +301,7 @@ namespace {
 
 template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV>
 int launch(const GemmArgs& a, hipStream_t s, const char* name) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int tiles = (((a.M + BM - 1) / BM + 7) / 8) * 8 * ((a.N + BN - 1) / BN);   // M tiles padded to a multiple of 8 (XCD groups)
     static const std::string nm = std::string(name) + "_" + std::to_string(BM) + "x" + std::to_string(BN);
     const double flops = 2.0 * a.M * (double)a.N * a.K;  // algorithmic (the 3 passes of SPLIT are not counted)
     const double bytes = (double)a.M * a.K * (A_F32 ? 4 : 2) + (double)a.N * a.K * 2 * (SPLIT ? 2 : 1) +

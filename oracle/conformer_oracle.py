@@ -4,7 +4,7 @@ This file restates, as plain functions over a flat ``{name: tensor}`` weight
 table, the arithmetic of the reference hot path (Lingeng56/conformer-pytorch-
 lightning, files under ``src/``; every function cites the reference file:line
 it follows).  It is written independently of the reference's nn.Module code:
-convolutions are explicit tap sums, attention is einsum, masks are closed-form
+convolutions are explicit im2col / tap sums, attention is einsum, masks are closed-form
 index arithmetic (numpy), positional tables are built here.
 
 Status: PARITY PINNED.  ``tests/test_oracle_golden.py`` checks every function
@@ -248,16 +248,16 @@ def conv_module(P, prefix, x, valid_mask, bn_eps=1e-5):
 # Row F -- Conv2d subsampling front-end.  reference src/convolution.py:70-76
 # =============================================================================
 def _conv3x3_s2_relu(x, w, b):
-    """x (B,Ci,T,F), w (Co,Ci,3,3) -> relu(conv stride 2, no padding): explicit 9-tap sum."""
+    """x (B,Ci,T,F), w (Co,Ci,3,3) -> relu(conv stride 2, no padding), restated as im2col + one GEMM:
+    patches[b,t,f,(ci,kt,kf)] = x[b,ci,2t+kt,2f+kf];  out = patches . w.reshape(Co, Ci*9)^T + bias."""
     B, Ci, T, F = x.shape
+    Co = w.size(0)
     To, Fo = (T - 3) // 2 + 1, (F - 3) // 2 + 1
-    out = None
-    for kt in range(3):
-        for kf in range(3):
-            patch = x[:, :, kt:kt + 2 * To - 1:2, kf:kf + 2 * Fo - 1:2]       # (B,Ci,To,Fo)
-            term = torch.einsum("bcif,oc->boif", patch, w[:, :, kt, kf])
-            out = term if out is None else out + term
-    return torch.relu(out + b[None, :, None, None])
+    sb, sc, st, sf = x.stride()
+    patches = x.as_strided((B, To, Fo, Ci, 3, 3), (sb, 2 * st, 2 * sf, sc, st, sf))      # a view: no copy yet
+    cols = patches.reshape(B * To * Fo, Ci * 9)                                            # materialises the im2col matrix
+    out = cols @ w.reshape(Co, Ci * 9).transpose(0, 1) + b
+    return torch.relu(out).reshape(B, To, Fo, Co).permute(0, 3, 1, 2)
 
 
 def subsampling(P, prefix, x, valid_mask, pe_table, offset=0, relative=True):
