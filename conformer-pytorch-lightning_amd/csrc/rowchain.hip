@@ -21,8 +21,14 @@
 //
 // All linears use the machinery proven in ffn.hip: fragment-major weights (one wavefront-load = 1 KB = one MFMA A
 // fragment), streamed L2 -> VGPR by a pinned rolling ring, straight-line unrolled steps (no branches: see ffn.hip for
-// why), swapped MFMA roles (a lane owns 4 consecutive output columns of one row), 4 wavefronts that each own distinct
+// why), swapped MFMA roles (a lane owns 4 consecutive output columns of one row), NW wavefronts that each own distinct
 // output columns (HEAD/TAIL: no cross-wavefront reduction) or distinct FF slices (MID: fixed-order LDS reduction).
+//
+// NW = 8 (two wavefronts per SIMD) for D = 256.  A wavefront pays ~60-100 clk to ISSUE one 1 KB weight load and issues in
+// order, so with one wavefront per SIMD the 32 loads of an FFN step (~3 k clk) serialise with its 64 MFMAs (1 k clk) -- measured
+// 34 us for one workgroup alone, nowhere near either the L2 stream rate (scripts/ubench.hip: 57 B/clk/CU at 4 wavefronts,
+// 109 at 8) or the MFMA rate.  With two wavefronts per SIMD one issues loads while the other runs MFMAs, and each wavefront
+// has half as many loads to issue.  256 VGPRs per wavefront then: 128 accumulators + a 12-fragment unified weight ring.
 #include <string>
 #include <type_traits>
 
@@ -84,9 +90,12 @@ __device__ __forceinline__ void linear_step(const u16* xn, const u32x4* wp, int 
     }
 }
 
-template <typename HT, int D, int HSTEPS, int FSTEPS, int TSTEPS, bool TGLU>
-__global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
+template <typename HT, int D, int NW, int HSTEPS, int FSTEPS, int TSTEPS, bool TGLU>
+__global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr bool HEAD = HSTEPS > 0, MID = FSTEPS > 0, TAIL = TSTEPS > 0;
+    constexpr int NT = 64 * NW;
+    constexpr int RPW = RBM / NW;                          // rows per wavefront in the row-wise (LayerNorm) phases
+    static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts");
     constexpr int KS1 = (D + 31) / 32;
     constexpr int KP = KS1 * 32;
     constexpr int NF2 = D / 16;
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
     if constexpr (HEAD) {
         // stage the 16-bit input tile (rows clamped), zero-padded to KP columns
         constexpr int CPRW = KP / 8;                       // 16-byte chunks per row
-        for (int id = tid; id < RBM * CPRW; id += 256) {
+        for (int id = tid; id < RBM * CPRW; id += NT) {
             const int r = id / CPRW, c = id % CPRW;
             int64_t grow = row0 + r;
             grow = grow < a.M ? grow : a.M - 1;
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
         }
         __syncthreads();
         const u32x4* wp = (const u32x4*)a.head_w + lane;
-        auto frag0 = [&](int s) { return (s * 4 + wave) * 2; };
+        auto frag0 = [&](int s) { return (s * NW + wave) * 2; };
         auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
         u32x4 wr[2 * KS1];
 #pragma unroll
@@ -155,8 +164,8 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
 
     // ================= rows -> (x in LDS,) LN_in -> xn ===========================================================
 #pragma unroll
-    for (int rr = 0; rr < RBM / 4; ++rr) {
-        const int r = wave * (RBM / 4) + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
         int64_t grow = row0 + r;
         grow = grow < a.M ? grow : a.M - 1;
         f32x4 v[VPL];
@@ -254,36 +263,51 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
             for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const u32x4* w1p = (const u32x4*)a.w1f + lane;
         const u32x4* w2p = (const u32x4*)a.w2f + lane;
-        u32x4 w1r[2 * KS1], w2r[NF2];
+        // One weight STREAM per wavefront: step s consumes NW1 fragments of W1 (in (kk, nf) order) and then NF2 fragments of
+        // W2; a ring of RING registers holds the next RING fragments of that stream, slot = position % RING, and the slot
+        // just consumed is refilled with the fragment RING positions ahead.  Everything about a position is a compile-time
+        // constant after unrolling, so the ring lives in registers and the waits are exact vmcnt values.
+        constexpr int NW1 = 2 * KS1, NFR = NW1 + NF2;
+        constexpr int RING = NW == 4 ? 32 : 12;     // 16 spills at 256 VGPRs (128 of them accumulators)
+        u32x4 ring[RING];
         f32x4 b1r[2];
-        auto w1_addr = [&](int fs, int i) { return w1p + ((int64_t)(2 * fs) * KS1 + i) * 64; };
-        auto w2_addr = [&](int fs, int i) { return w2p + ((int64_t)fs * NF2 + i) * 64; };
         const int rot = (int)(blockIdx.x % FSTEPS);
-        auto step_of = [&](int s) { int q = s + rot; q = q >= FSTEPS ? q - FSTEPS : q; return q * 4 + wave; };
+        auto step_of = [&](int s) { int q = s + rot; q = q >= FSTEPS ? q - FSTEPS : q; return q * NW + wave; };
+        auto step_clamped = [&](int s) { const int f = step_of(s); return f < nsteps_total ? f : nsteps_total - 1; };
+        auto frag_ptr = [&](int fs, int p) {
+            if (p < NW1) return w1p + ((int64_t)(2 * fs) * KS1 + (p & 1) * KS1 + (p >> 1)) * 64;   // (kk, nf) = (p >> 1, p & 1)
+            return w2p + ((int64_t)fs * NF2 + (p - NW1)) * 64;
+        };
+        auto refill = [&](int s, int p) {                  // after consuming position (s, p)
+            const int t = s * NFR + p + RING;
+            const int s2 = t / NFR, p2 = t % NFR;
+            if (s2 < FSTEPS) ring[(s * NFR + p) % RING] = *frag_ptr(step_clamped(s2), p2);
+        };
         auto step = [&](int s) {
-            const int fs_raw = step_of(s);
-            const bool valid = fs_raw < nsteps_total;
-            const int last = nsteps_total - 1;
-            const int nx_raw = step_of(s + 1 < FSTEPS ? s + 1 : s);
-            const int nx = nx_raw < nsteps_total ? nx_raw : last;
+            const bool valid = step_of(s) < nsteps_total;
+            const int nx = step_clamped(s + 1 < FSTEPS ? s + 1 : s);
             f32x4 acc1[MF][2];
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) acc1[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            u32x4 xf[MF][KS1];
+            u32x4 xf[2][MF];                               // activation fragments: this kk and the next (one-ahead LDS reads)
 #pragma unroll
-            for (int kk = 0; kk < KS1; ++kk)
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) xf[mf][kk] = xfrag(mf, kk);
+            for (int mf = 0; mf < MF; ++mf) xf[0][mf] = xfrag(mf, 0);
 #pragma unroll
             for (int kk = 0; kk < KS1; ++kk) {
+                if (kk + 1 < KS1) {
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
+                    for (int mf = 0; mf < MF; ++mf) xf[(kk + 1) & 1][mf] = xfrag(mf, kk + 1);
+                }
 #pragma unroll
-                    for (int mf = 0; mf < MF; ++mf) acc1[mf][nf] = HT::mfma(w1r[nf * KS1 + kk], xf[mf][kk], acc1[mf][nf]);
-                w1r[kk] = *w1_addr(nx, kk);
-                w1r[KS1 + kk] = *w1_addr(nx, KS1 + kk);
+                for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+                        acc1[mf][nf] = HT::mfma(ring[(s * NFR + kk * 2 + nf) % RING], xf[kk & 1][mf], acc1[mf][nf]);
+                }
+                refill(s, kk * 2);
+                refill(s, kk * 2 + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const f32x4 bb0 = b1r[0], bb1 = b1r[1];
@@ -305,54 +329,60 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
             for (int nf = 0; nf < NF2; ++nf) {
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf) acc2[mf][nf] = HT::mfma(w2r[nf], hf[mf], acc2[mf][nf]);
-                w2r[nf] = *w2_addr(nx, nf);
+                for (int mf = 0; mf < MF; ++mf) acc2[mf][nf] = HT::mfma(ring[(s * NFR + NW1 + nf) % RING], hf[mf], acc2[mf][nf]);
+                refill(s, NW1 + nf);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         {
-            const int f00 = step_of(0);
-            const int f0 = f00 < nsteps_total ? f00 : nsteps_total - 1;
-#pragma unroll
-            for (int i = 0; i < 2 * KS1; ++i) w1r[i] = *w1_addr(f0, i);
+            const int f0 = step_clamped(0);
             b1r[0] = *(const f32x4*)(a.b1 + f0 * 32 + 4 * g);
             b1r[1] = *(const f32x4*)(a.b1 + f0 * 32 + 16 + 4 * g);
 #pragma unroll
-            for (int i = 0; i < NF2; ++i) w2r[i] = *w2_addr(f0, i);
+            for (int t = 0; t < RING; ++t)
+                if (t / NFR < FSTEPS) ring[t] = *frag_ptr(step_clamped(t / NFR), t % NFR);
         }
 #pragma unroll
         for (int s = 0; s < FSTEPS; ++s) step(s);
 
-        // cross-wavefront reduction, fixed order ((w0 + w2) + (w1 + w3))
+        // cross-wavefront reduction through two LDS slabs, fixed order:
+        //   NW = 4: (w0 + w2) + (w1 + w3)        NW = 8: ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
         auto slab_ptr = [&](int which, int mf, int nf) { return slab + which * RBM * XS_STRIDE + (mf * 16 + l15) * XS_STRIDE + nf * 16 + 4 * g; };
-        if (wave >= 2) {
+        auto dump = [&](int which) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                for (int nf = 0; nf < NF2; ++nf) *(f32x4*)slab_ptr(wave - 2, mf, nf) = acc2[mf][nf];
+                for (int nf = 0; nf < NF2; ++nf) *(f32x4*)slab_ptr(which, mf, nf) = acc2[mf][nf];
+        };
+        auto absorb = [&](int which) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] += *(const f32x4*)slab_ptr(which, mf, nf);
+        };
+        if constexpr (NW == 8) {
+            if (wave >= 6) dump(wave - 6);
+            __syncthreads();
+            if (wave == 2 || wave == 3) absorb(wave - 2);
+            __syncthreads();
+            if (wave == 4 || wave == 5) dump(wave - 4);
+            __syncthreads();
+            if (wave < 2) absorb(wave);
+            __syncthreads();
         }
+        if (wave == 2 || wave == 3) dump(wave - 2);
         __syncthreads();
-        if (wave < 2) {
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] += *(const f32x4*)slab_ptr(wave, mf, nf);
-        }
+        if (wave < 2) absorb(wave);
         __syncthreads();
-        if (wave < 2) {
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF2; ++nf) *(f32x4*)slab_ptr(wave, mf, nf) = acc2[mf][nf];
-        }
+        if (wave < 2) dump(wave);
         __syncthreads();
     }
 
     // ================= post norms: y1 -> out_f32, y2 -> out16 / next LDS tile =====================================
     if constexpr (MID) {
 #pragma unroll
-        for (int rr = 0; rr < RBM / 4; ++rr) {
-            const int r = wave * (RBM / 4) + rr;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
             const int64_t grow = row0 + r;
             f32x4 v[VPL];
 #pragma unroll
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
         const int nfrags = a.tail_N / 16;
         const int ldo = TGLU ? a.tail_N / 2 : a.tail_N;
         const u32x4* wp = (const u32x4*)a.tail_w + lane;
-        auto frag0 = [&](int s) { return (s * 4 + wave) * 2; };
+        auto frag0 = [&](int s) { return (s * NW + wave) * 2; };
         auto clampf = [&](int f) { return f < nfrags ? f : nfrags - 1; };
         u32x4 wr[2 * KS1];
 #pragma unroll
@@ -453,11 +483,11 @@ __global__ __launch_bounds__(256) void cfm_rowchain_kernel(const ChainArgs a) {
     }
 }
 
-template <typename HT, int D, int HS, int FS, int TS, bool TGLU>
+template <typename HT, int D, int NW, int HS, int FS, int TS, bool TGLU>
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
     const unsigned grid = (unsigned)((a.M + RBM - 1) / RBM);
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, HS, FS, TS, TGLU>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, NW, HS, FS, TS, TGLU>), dim3(grid), dim3(64 * NW), 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -486,26 +516,27 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(!d->py0 || (d->py1 && d->pb2 && !head), "cfm_rowchain: the reduce input needs both slabs and the bias, and no head");
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->w_dtype == CFM_BF16;
-    const int fsteps = mid ? (d->FF / 32 + 3) / 4 : 0;
-    const int tsteps = tail ? (d->tail_N / 16 + 7) / 8 : 0;
+    const int nw = d->D == 256 ? 8 : 4;                    // wavefronts per workgroup (see the header comment)
+    const int fsteps = mid ? (d->FF / 32 + nw - 1) / nw : 0;
+    const int tsteps = tail ? (d->tail_N / 16 + 2 * nw - 1) / (2 * nw) : 0;
     const double M = (double)d->M;
     const double fl_head = head ? 2.0 * M * d->D * d->D : 0.0, fl_mid = mid ? 4.0 * M * d->D * d->FF : 0.0,
                  fl_tail = tail ? 2.0 * M * d->D * d->tail_N : 0.0;
     const double fl = fl_head + fl_mid + fl_tail;
-#define CFM_RC(HT, DD, HS, FS, TS, GLU, NAME) return launch_chain<HT, DD, HS, FS, TS, GLU>(a, s, NAME, fl)
+#define CFM_RC(HT, DD, NWV, HS, FS, TS, GLU, NAME) return launch_chain<HT, DD, NWV, HS, FS, TS, GLU>(a, s, NAME, fl)
     // the three roles of a conformer block, for D = 256 (ff 2048) and D = 144 (ff 576)
     if (d->D == 256) {
-        if (!head && mid && tail && !d->tail_glu && fsteps == 16 && tsteps == 6) { if (bf) CFM_RC(BF16, 256, 0, 16, 6, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 0, 16, 6, false, "chain_macaron_f16_d256"); }
-        if (head && !mid && tail && d->tail_glu && tsteps == 4) { if (bf) CFM_RC(BF16, 256, 2, 0, 4, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 2, 0, 4, true, "chain_convin_f16_d256"); }
-        if (head && mid && !tail && fsteps == 16) { if (bf) CFM_RC(BF16, 256, 2, 16, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 2, 16, 0, false, "chain_final_f16_d256"); }
-        if (!head && !mid && tail && !d->tail_glu && tsteps == 6) { if (bf) CFM_RC(BF16, 256, 0, 0, 6, false, "chain_qkv_bf16_d256"); else CFM_RC(F16, 256, 0, 0, 6, false, "chain_qkv_f16_d256"); }
-        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 256, 0, 0, 0, false, "chain_rows_bf16_d256"); else CFM_RC(F16, 256, 0, 0, 0, false, "chain_rows_f16_d256"); }
+        if (!head && mid && tail && !d->tail_glu && fsteps == 8 && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 8, 0, 8, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 8, 0, 8, 3, false, "chain_macaron_f16_d256"); }
+        if (head && !mid && tail && d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 256, 8, 1, 0, 2, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 8, 1, 0, 2, true, "chain_convin_f16_d256"); }
+        if (head && mid && !tail && fsteps == 8) { if (bf) CFM_RC(BF16, 256, 8, 1, 8, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 8, 1, 8, 0, false, "chain_final_f16_d256"); }
+        if (!head && !mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 8, 0, 0, 3, false, "chain_qkv_bf16_d256"); else CFM_RC(F16, 256, 8, 0, 0, 3, false, "chain_qkv_f16_d256"); }
+        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 256, 8, 0, 0, 0, false, "chain_rows_bf16_d256"); else CFM_RC(F16, 256, 8, 0, 0, 0, false, "chain_rows_f16_d256"); }
     } else {
-        if (!head && mid && tail && !d->tail_glu && fsteps == 5 && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 0, 5, 4, false, "chain_macaron_bf16_d144"); else CFM_RC(F16, 144, 0, 5, 4, false, "chain_macaron_f16_d144"); }
-        if (head && !mid && tail && d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 144, 2, 0, 3, true, "chain_convin_bf16_d144"); else CFM_RC(F16, 144, 2, 0, 3, true, "chain_convin_f16_d144"); }
-        if (head && mid && !tail && fsteps == 5) { if (bf) CFM_RC(BF16, 144, 2, 5, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 2, 5, 0, false, "chain_final_f16_d144"); }
-        if (!head && !mid && tail && !d->tail_glu && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 0, 0, 4, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 0, 0, 4, false, "chain_qkv_f16_d144"); }
-        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 0, 0, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 0, 0, 0, false, "chain_rows_f16_d144"); }
+        if (!head && mid && tail && !d->tail_glu && fsteps == 5 && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 4, 0, 5, 4, false, "chain_macaron_bf16_d144"); else CFM_RC(F16, 144, 4, 0, 5, 4, false, "chain_macaron_f16_d144"); }
+        if (head && !mid && tail && d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 144, 4, 2, 0, 3, true, "chain_convin_bf16_d144"); else CFM_RC(F16, 144, 4, 2, 0, 3, true, "chain_convin_f16_d144"); }
+        if (head && mid && !tail && fsteps == 5) { if (bf) CFM_RC(BF16, 144, 4, 2, 5, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 4, 2, 5, 0, false, "chain_final_f16_d144"); }
+        if (!head && !mid && tail && !d->tail_glu && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 4, 0, 0, 4, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 4, 0, 0, 4, false, "chain_qkv_f16_d144"); }
+        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 4, 0, 0, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 4, 0, 0, 0, false, "chain_rows_f16_d144"); }
     }
 #undef CFM_RC
     return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: no instance for D=%d FF=%d tail_N=%d head=%d mid=%d tail=%d glu=%d", d->D, d->FF,

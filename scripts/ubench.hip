@@ -30,18 +30,20 @@ template <int NFL, int NW>
 __global__ __launch_bounds__(NW * 64) void k_stream(const u32x4* __restrict__ buf, size_t n16, unsigned* out, long long* t, int rounds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // every workgroup walks the same 2 MB (n16 16-byte elements), wavefront w takes every NW-th KB, rotated by block
-    const size_t nkb = n16 / 64;
-    size_t kb = (size_t)wave + NW * (blockIdx.x % 16);
+    // n16 is a power of two: index arithmetic is a 32-bit mask (an earlier version used a 64-bit '%' here, ~250 clk of software
+    // division per load, which capped every configuration at ~4 B/clk/wavefront and hid the memory system entirely)
+    const unsigned mask = (unsigned)(n16 / 64) - 1u;
+    unsigned kb = (unsigned)__builtin_amdgcn_readfirstlane(wave) + NW * (blockIdx.x % 16);
     u32x4 r[NFL];
     unsigned acc = 0;
     long long c0 = clock64(), w0 = wall_clock64();
 #pragma unroll
-    for (int i = 0; i < NFL; ++i) { r[i] = buf[(kb % nkb) * 64 + lane]; kb += NW; }
+    for (int i = 0; i < NFL; ++i) { r[i] = buf[(size_t)(kb & mask) * 64 + lane]; kb += NW; }
     for (int it = 0; it < rounds; ++it) {
 #pragma unroll
         for (int i = 0; i < NFL; ++i) {
             acc += r[i].x ^ r[i].w;
-            r[i] = buf[(kb % nkb) * 64 + lane];
+            r[i] = buf[(size_t)(kb & mask) * 64 + lane];
             kb += NW;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -76,11 +78,11 @@ int main() {
 #define STREAM(NFL, NW)                                                                                              \
     for (int grid : {1, 256}) {                                                                                      \
         for (int rep = 0; rep < 2; ++rep) {                                                                          \
-            hipLaunchKernelGGL((k_stream<NFL, NW>), dim3(grid), dim3(NW * 64), 0, 0, d_buf, bytes / 16, d_o2, d_t, 512 / NFL); \
+            hipLaunchKernelGGL((k_stream<NFL, NW>), dim3(grid), dim3(NW * 64), 0, 0, d_buf, bytes / 16, d_o2, d_t, 4096 / NFL); \
             hipDeviceSynchronize();                                                                                  \
         }                                                                                                            \
-        report("stream: in flight/wave=" #NFL " waves/CU=" #NW, d_t, grid, NW * 1024.0 * (512 / NFL * NFL + NFL), "B/clk/CU");   \
+        report("stream: in flight/wave=" #NFL " waves/CU=" #NW, d_t, grid, NW * 1024.0 * (4096 / NFL * NFL + NFL), "B/clk/CU");   \
     }
-    STREAM(8, 4) STREAM(32, 4) STREAM(8, 8) STREAM(16, 8) STREAM(32, 8) STREAM(8, 16) STREAM(16, 16)
+    STREAM(2, 4) STREAM(4, 4) STREAM(8, 4) STREAM(16, 4) STREAM(32, 4) STREAM(4, 8) STREAM(8, 8) STREAM(16, 8) STREAM(4, 16) STREAM(8, 16)
     return 0;
 }
