@@ -118,8 +118,20 @@ __device__ __forceinline__ void store_from_f32(void* p, int64_t i, int dt, float
         ((u16*)p)[i] = dt == CFM_BF16 ? BF16::from_f32(v) : F16::from_f32(v);
 }
 
+// Sum over the 64 lanes of a wavefront, result in every lane (EXEC must be all ones).  Four DPP adds fold each row of 16
+// lanes (quad swaps, then half-row and row mirrors), four v_readlane pick up the row totals: ~40 clk, against six dependent
+// ds_bpermute round trips (~60 clk each) for the shuffle version -- LayerNorm calls this twice per row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov_<0xB1>(v);                                // quad_perm [1,0,3,2]
+    v += dpp_mov_<0x4E>(v);                                // quad_perm [2,3,0,1]
+    v += dpp_mov_<0x141>(v);                               // row_half_mirror
+    v += dpp_mov_<0x140>(v);                               // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }

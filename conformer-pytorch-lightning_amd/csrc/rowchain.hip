@@ -59,15 +59,25 @@ struct ChainArgs {
     float alpha, eps;
 };
 
+// Phase stamps for scripts/probe_chain.hip (built with -DCFM_CHAIN_STAMPS; never defined in the product build): thread 0 of each
+// workgroup records the shader clock at every phase boundary.
+#ifdef CFM_CHAIN_STAMPS
+__device__ long long cfm_chain_stamps[1024 * 16];
+#define CFM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) cfm_chain_stamps[blockIdx.x * 16 + (i)] = clock64(); } while (0)
+#else
+#define CFM_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int RBM = 32;
 
 // One "linear step": this wavefront's two 16-column fragments (n-fragments f0, f0+1) over the whole K of the LDS tile.
-// Weights for the NEXT step (n-fragments nxa, nxb -- clamped by the caller when out of range) are refilled into the ring as
-// the current ones are consumed.
+// With `refill`, weights for the NEXT step (n-fragments nxa, nxb -- clamped by the caller when out of range) replace the
+// current ones in the ring as they are consumed; the last step of a phase passes false (a compile-time constant after
+// unrolling) and issues no loads.
 template <typename HT, int KS1, int XN_STRIDE>
-__device__ __forceinline__ void linear_step(const u16* xn, const u32x4* wp, int nxa, int nxb, u32x4 (&wr)[2 * KS1],
+__device__ __forceinline__ void linear_step(const u16* xn, const u32x4* wp, bool refill, int nxa, int nxb, u32x4 (&wr)[2 * KS1],
                                             f32x4 (&acc)[2][2], int g, int l15) {
     u32x4 xf[2][KS1];
 #pragma unroll
@@ -84,10 +94,52 @@ __device__ __forceinline__ void linear_step(const u16* xn, const u32x4* wp, int 
         for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) acc[mf][nf] = HT::mfma(wr[nf * KS1 + kk], xf[mf][kk], acc[mf][nf]);
-        wr[kk] = wp[((int64_t)nxa * KS1 + kk) * 64];
-        wr[KS1 + kk] = wp[((int64_t)nxb * KS1 + kk) * 64];
+        if (refill) {
+            wr[kk] = wp[((int64_t)nxa * KS1 + kk) * 64];
+            wr[KS1 + kk] = wp[((int64_t)nxb * KS1 + kk) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// s_setprio takes an immediate; the argument is a constant after unrolling and the switch folds away.
+__device__ __forceinline__ void set_wave_priority(int p) {
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
+// LayerNorm of ROWS rows held one row per wavefront pass (lane owns columns (lane + 64 it) * 4 ..+3), in place.
+template <int ROWS, int VPL, int D>
+__device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x4 (&gam)[VPL], const f32x4 (&bet)[VPL], float eps, int lane) {
+    float mean[ROWS], rstd[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < VPL; ++it)
+            if ((lane + 64 * it) * 4 < D) s += (v[rr][it].x + v[rr][it].y) + (v[rr][it].z + v[rr][it].w);
+        mean[rr] = wave_sum(s) / (float)D;
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < VPL; ++it)
+            if ((lane + 64 * it) * 4 < D) {
+                const f32x4 d = v[rr][it] - mean[rr];
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+        rstd[rr] = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+        for (int it = 0; it < VPL; ++it)
+            if ((lane + 64 * it) * 4 < D) v[rr][it] = (v[rr][it] - mean[rr]) * rstd[rr] * gam[it] + bet[it];
 }
 
 template <typename HT, int D, int NW, int HSTEPS, int FSTEPS, int TSTEPS, bool TGLU>
@@ -113,9 +165,36 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int64_t row0 = (int64_t)blockIdx.x * RBM;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    CFM_STAMP(0);
+
+    // The tail's weight ring is declared here so that its first fill can be issued a phase or two before the tail runs
+    // (with no FFN in between: at kernel start; otherwise right after the FFN steps, to land during the reduction).
+    const int t_nfrags = TAIL ? a.tail_N / 16 : 1;
+    auto t_frag0 = [&](int s) { return (s * NW + wave) * 2; };
+    auto t_clamp = [&](int f) { return f < t_nfrags ? f : t_nfrags - 1; };
+    const u32x4* twp = (const u32x4*)a.tail_w + lane;
+    u32x4 twr[2 * KS1];
+    auto tail_prefetch = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < KS1; ++kk) {
+            twr[kk] = twp[((int64_t)t_clamp(t_frag0(0)) * KS1 + kk) * 64];
+            twr[KS1 + kk] = twp[((int64_t)t_clamp(t_frag0(0) + 1) * KS1 + kk) * 64];
+        }
+    };
 
     // ================= HEAD: x = res + mask(A . Wh^T + bh) =====================================================
     if constexpr (HEAD) {
+        const u32x4* wp = (const u32x4*)a.head_w + lane;
+        auto frag0 = [&](int s) { return (s * NW + wave) * 2; };
+        auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
+        u32x4 wr[2 * KS1];
+#pragma unroll
+        for (int kk = 0; kk < KS1; ++kk) {                 // weights first: their latency overlaps the tile staging below
+            wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
+            wr[KS1 + kk] = wp[((int64_t)clampf(frag0(0) + 1) * KS1 + kk) * 64];
+        }
+        if constexpr (TAIL && !MID) tail_prefetch();
         // stage the 16-bit input tile (rows clamped), zero-padded to KP columns
         constexpr int CPRW = KP / 8;                       // 16-byte chunks per row
         for (int id = tid; id < RBM * CPRW; id += NT) {
@@ -126,131 +205,145 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
             *(u32x4*)(xn + r * XN_STRIDE + c * 8) = v;
         }
         __syncthreads();
-        const u32x4* wp = (const u32x4*)a.head_w + lane;
-        auto frag0 = [&](int s) { return (s * NW + wave) * 2; };
-        auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
-        u32x4 wr[2 * KS1];
-#pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) {
-            wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
-            wr[KS1 + kk] = wp[((int64_t)clampf(frag0(0) + 1) * KS1 + kk) * 64];
-        }
+        CFM_STAMP(1);
 #pragma unroll
         for (int s = 0; s < HSTEPS; ++s) {
             const int f = frag0(s);
             const int fn = frag0(s + 1 < HSTEPS ? s + 1 : s);
+            // epilogue operands of this step, issued before its MFMAs
+            f32x4 bb[2], rs[2][MF];
+            bool keep[MF];
+            int64_t grows[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int64_t gr = row0 + mf * 16 + l15;
+                grows[mf] = gr < a.M ? gr : a.M - 1;
+                keep[mf] = true;
+            }
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const int col = clampf(f + nf) * 16 + 4 * g;
+                bb[nf] = *(const f32x4*)(a.head_b + col);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) rs[nf][mf] = *(const f32x4*)(a.head_res + grows[mf] * D + col);
+            }
+            if (a.head_mask) {
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) keep[mf] = a.head_mask[grows[mf]] != 0;
+            }
             f32x4 acc[2][2];
-            linear_step<HT, KS1, XN_STRIDE>(xn, wp, clampf(fn), clampf(fn + 1), wr, acc, g, l15);
+            linear_step<HT, KS1, XN_STRIDE>(xn, wp, s + 1 < HSTEPS, clampf(fn), clampf(fn + 1), wr, acc, g, l15);
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
                 const int col = (f + nf) * 16 + 4 * g;
                 if (f + nf < NF2) {
-                    const f32x4 bb = *(const f32x4*)(a.head_b + col);
 #pragma unroll
                     for (int mf = 0; mf < MF; ++mf) {
-                        const int r = mf * 16 + l15;
-                        int64_t grow = row0 + r;
-                        grow = grow < a.M ? grow : a.M - 1;
-                        f32x4 v = acc[mf][nf] + bb;
-                        if (a.head_mask && a.head_mask[grow] == 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        v += *(const f32x4*)(a.head_res + grow * D + col);
-                        *(f32x4*)(xs + r * XS_STRIDE + col) = v;
+                        f32x4 v = acc[mf][nf] + bb[nf];
+                        if (!keep[mf]) v = zero4;
+                        v += rs[nf][mf];
+                        *(f32x4*)(xs + (mf * 16 + l15) * XS_STRIDE + col) = v;
                     }
                 }
             }
         }
         __syncthreads();
+    } else {
+        if constexpr (TAIL && !MID) tail_prefetch();
     }
+    CFM_STAMP(2);
 
     // ================= rows -> (x in LDS,) LN_in -> xn ===========================================================
+    {
+        f32x4 v[RPW][VPL];
+        int64_t grows[RPW];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave * RPW + rr;
-        int64_t grow = row0 + r;
-        grow = grow < a.M ? grow : a.M - 1;
-        f32x4 v[VPL];
-        float s = 0.f;
+        for (int rr = 0; rr < RPW; ++rr) {                 // all of this wavefront's rows are requested before any is used
+            const int r = wave * RPW + rr;
+            const int64_t gr = row0 + r;
+            grows[rr] = gr < a.M ? gr : a.M - 1;
 #pragma unroll
-        for (int it = 0; it < VPL; ++it) {
-            const int c = (lane + 64 * it) * 4;
-            if constexpr (HEAD) {
-                v[it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            } else {
-                v[it] = c < D ? *(const f32x4*)(a.x + grow * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (a.py0 && c < D) {
-                    const f32x4 y = *(const f32x4*)(a.py0 + grow * D + c) + *(const f32x4*)(a.py1 + grow * D + c);
-                    v[it] += a.palpha * (y + *(const f32x4*)(a.pb2 + c));
-                }
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                if constexpr (HEAD) v[rr][it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : zero4;
+                else v[rr][it] = c < D ? *(const f32x4*)(a.x + grows[rr] * D + c) : zero4;
             }
+        }
+        f32x4 gam[VPL], bet[VPL];
+        bool keep[RPW];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) keep[rr] = true;
+        if (a.ln_g) {
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                gam[it] = c < D ? *(const f32x4*)(a.ln_g + c) : zero4;
+                bet[it] = c < D ? *(const f32x4*)(a.ln_b + c) : zero4;
+            }
+        }
+        if (a.ln_mask) {
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) keep[rr] = a.ln_mask[grows[rr]] != 0;
         }
         if constexpr (!HEAD) {
-            if (a.py0 && a.pln_g) {                        // norm_final of the block whose FFN was pending
-                float s1 = 0.f;
+            if (a.py0) {                                   // pending partial FFN of the previous kernel (+ its norm_final)
 #pragma unroll
-                for (int it = 0; it < VPL; ++it)
-                    if ((lane + 64 * it) * 4 < D) s1 += (v[it].x + v[it].y) + (v[it].z + v[it].w);
-                const float mean = wave_sum(s1) / (float)D;
-                float q = 0.f;
+                for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-                for (int it = 0; it < VPL; ++it)
-                    if ((lane + 64 * it) * 4 < D) {
-                        const f32x4 d = v[it] - mean;
-                        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                    for (int it = 0; it < VPL; ++it) {
+                        const int c = (lane + 64 * it) * 4;
+                        if (c < D) {
+                            const f32x4 y = *(const f32x4*)(a.py0 + grows[rr] * D + c) + *(const f32x4*)(a.py1 + grows[rr] * D + c);
+                            v[rr][it] += a.palpha * (y + *(const f32x4*)(a.pb2 + c));
+                        }
                     }
-                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
+                if (a.pln_g) {
+                    f32x4 pg[VPL], pb[VPL];
 #pragma unroll
-                for (int it = 0; it < VPL; ++it) {
-                    const int c = (lane + 64 * it) * 4;
-                    if (c < D) v[it] = (v[it] - mean) * rstd * *(const f32x4*)(a.pln_g + c) + *(const f32x4*)(a.pln_b + c);
+                    for (int it = 0; it < VPL; ++it) {
+                        const int c = (lane + 64 * it) * 4;
+                        pg[it] = c < D ? *(const f32x4*)(a.pln_g + c) : zero4;
+                        pb[it] = c < D ? *(const f32x4*)(a.pln_b + c) : zero4;
+                    }
+                    rows_layernorm<RPW, VPL, D>(v, pg, pb, a.eps, lane);
                 }
             }
 #pragma unroll
-            for (int it = 0; it < VPL; ++it) {
-                const int c = (lane + 64 * it) * 4;
-                if (c < D) *(f32x4*)(xs + r * XS_STRIDE + c) = v[it];
-            }
-        }
+            for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-        for (int it = 0; it < VPL; ++it)
-            if ((lane + 64 * it) * 4 < D) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    if (c < D) *(f32x4*)(xs + (wave * RPW + rr) * XS_STRIDE + c) = v[rr][it];
+                }
+        }
         if constexpr (!MID) {                              // no FFN here: the rows ARE the new residual stream
-            if (row0 + r < a.M && a.out_f32) {
+            if (a.out_f32) {
 #pragma unroll
-                for (int it = 0; it < VPL; ++it) {
-                    const int c = (lane + 64 * it) * 4;
-                    if (c < D) *(f32x4*)(a.out_f32 + (row0 + r) * D + c) = v[it];
-                }
+                for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                    for (int it = 0; it < VPL; ++it) {
+                        const int c = (lane + 64 * it) * 4;
+                        if (c < D && row0 + wave * RPW + rr < a.M) *(f32x4*)(a.out_f32 + (row0 + wave * RPW + rr) * D + c) = v[rr][it];
+                    }
             }
         }
-        if (a.ln_g) {
-            const float mean = wave_sum(s) / (float)D;
-            float q = 0.f;
+        if (a.ln_g) rows_layernorm<RPW, VPL, D>(v, gam, bet, a.eps, lane);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
-                if (c < D) {
-                    const f32x4 d = v[it] - mean;
-                    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                if (c < KP) {
+                    const f32x4 o = (c < D && keep[rr]) ? v[rr][it] : zero4;
+                    *(u32x2*)(xn + (wave * RPW + rr) * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
                 }
             }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
-#pragma unroll
-            for (int it = 0; it < VPL; ++it) {
-                const int c = (lane + 64 * it) * 4;
-                if (c < D) v[it] = (v[it] - mean) * rstd * *(const f32x4*)(a.ln_g + c) + *(const f32x4*)(a.ln_b + c);
-            }
-        }
-        const bool keep = a.ln_mask ? a.ln_mask[grow] != 0 : true;
-#pragma unroll
-        for (int it = 0; it < VPL; ++it) {
-            const int c = (lane + 64 * it) * 4;
-            if (c < KP) {
-                const f32x4 o = (c < D && keep) ? v[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                *(u32x2*)(xn + r * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
-            }
-        }
     }
     __syncthreads();
+    CFM_STAMP(3);
+
+    // parameters of the post norms: requested after the FFN steps, used after the reduction
+    f32x4 pn_b2[VPL], pn_g1[VPL], pn_b1[VPL], pn_g2[VPL], pn_be2[VPL];
 
     // ================= MID: fused feed-forward (see ffn.hip for the design notes) ================================
     if constexpr (MID) {
@@ -260,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = zero4;
         const u32x4* w1p = (const u32x4*)a.w1f + lane;
         const u32x4* w2p = (const u32x4*)a.w2f + lane;
         // One weight STREAM per wavefront: step s consumes NW1 fragments of W1 (in (kk, nf) order) and then NF2 fragments of
@@ -268,7 +361,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
         // just consumed is refilled with the fragment RING positions ahead.  Everything about a position is a compile-time
         // constant after unrolling, so the ring lives in registers and the waits are exact vmcnt values.
         constexpr int NW1 = 2 * KS1, NFR = NW1 + NF2;
-        constexpr int RING = NW == 4 ? 32 : 12;     // 16 spills at 256 VGPRs (128 of them accumulators)
+        constexpr int RING = NW == 4 ? 32 : 12;            // 16 spills at 256 VGPRs (128 of them accumulators)
         u32x4 ring[RING];
         f32x4 b1r[2];
         const int rot = (int)(blockIdx.x % FSTEPS);
@@ -290,7 +383,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf) acc1[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int nf = 0; nf < 2; ++nf) acc1[mf][nf] = zero4;
             u32x4 xf[2][MF];                               // activation fragments: this kk and the next (one-ahead LDS reads)
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) xf[0][mf] = xfrag(mf, 0);
@@ -311,8 +404,10 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
                 __builtin_amdgcn_sched_barrier(0);
             }
             const f32x4 bb0 = b1r[0], bb1 = b1r[1];
-            b1r[0] = *(const f32x4*)(a.b1 + nx * 32 + 4 * g);
-            b1r[1] = *(const f32x4*)(a.b1 + nx * 32 + 16 + 4 * g);
+            if (s + 1 < FSTEPS) {
+                b1r[0] = *(const f32x4*)(a.b1 + nx * 32 + 4 * g);
+                b1r[1] = *(const f32x4*)(a.b1 + nx * 32 + 16 + 4 * g);
+            }
             __builtin_amdgcn_sched_barrier(0);
             u32x4 hf[MF];
 #pragma unroll
@@ -343,7 +438,38 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
                 if (t / NFR < FSTEPS) ring[t] = *frag_ptr(step_clamped(t / NFR), t % NFR);
         }
 #pragma unroll
-        for (int s = 0; s < FSTEPS; ++s) step(s);
+        for (int s = 0; s < FSTEPS; ++s) {
+            // the two wavefronts of a SIMD share its issue slots; the one that is behind gets priority, so that both finish
+            // together instead of the younger one running its last steps alone (loads and MFMAs serialised again)
+            if constexpr (NW == 8) set_wave_priority(3 - (s * 4) / FSTEPS);
+            step(s);
+        }
+        if constexpr (NW == 8) set_wave_priority(0);
+        CFM_STAMP(4);
+
+        // requests that land during the reduction: post-norm parameters and the tail's first weights
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            pn_b2[it] = c < D ? *(const f32x4*)(a.b2 + c) : zero4;
+        }
+        if (a.ln1_g) {
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                pn_g1[it] = c < D ? *(const f32x4*)(a.ln1_g + c) : zero4;
+                pn_b1[it] = c < D ? *(const f32x4*)(a.ln1_b + c) : zero4;
+            }
+        }
+        if (a.ln2_g) {
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                pn_g2[it] = c < D ? *(const f32x4*)(a.ln2_g + c) : zero4;
+                pn_be2[it] = c < D ? *(const f32x4*)(a.ln2_b + c) : zero4;
+            }
+        }
+        if constexpr (TAIL) tail_prefetch();
 
         // cross-wavefront reduction through two LDS slabs, fixed order:
         //   NW = 4: (w0 + w2) + (w1 + w3)        NW = 8: ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
@@ -377,90 +503,68 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
         if (wave < 2) dump(wave);
         __syncthreads();
     }
+    CFM_STAMP(5);
 
     // ================= post norms: y1 -> out_f32, y2 -> out16 / next LDS tile =====================================
     if constexpr (MID) {
+        f32x4 v[RPW][VPL];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
-            const int64_t grow = row0 + r;
-            f32x4 v[VPL];
 #pragma unroll
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
-                v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                v[rr][it] = zero4;
                 if (c < D) {
                     const f32x4 y = *(const f32x4*)(slab + r * XS_STRIDE + c) + *(const f32x4*)(slab + RBM * XS_STRIDE + r * XS_STRIDE + c);
-                    v[it] = a.alpha * (y + *(const f32x4*)(a.b2 + c)) + *(const f32x4*)(xs + r * XS_STRIDE + c);
+                    v[rr][it] = a.alpha * (y + pn_b2[it]) + *(const f32x4*)(xs + r * XS_STRIDE + c);
                 }
             }
-            auto norm = [&](const float* gam, const float* bet) {
-                float s = 0.f;
+        }
+        if (a.ln1_g) rows_layernorm<RPW, VPL, D>(v, pn_g1, pn_b1, a.eps, lane);
+        if (a.out_f32) {
 #pragma unroll
-                for (int it = 0; it < VPL; ++it)
-                    if ((lane + 64 * it) * 4 < D) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
-                const float mean = wave_sum(s) / (float)D;
-                float q = 0.f;
-#pragma unroll
-                for (int it = 0; it < VPL; ++it)
-                    if ((lane + 64 * it) * 4 < D) {
-                        const f32x4 d = v[it] - mean;
-                        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-                    }
-                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
+            for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
                 for (int it = 0; it < VPL; ++it) {
                     const int c = (lane + 64 * it) * 4;
-                    if (c < D) v[it] = (v[it] - mean) * rstd * *(const f32x4*)(gam + c) + *(const f32x4*)(bet + c);
+                    const int64_t grow = row0 + wave * RPW + rr;
+                    if (c < D && grow < a.M) *(f32x4*)(a.out_f32 + grow * D + c) = v[rr][it];
                 }
-            };
-            if (a.ln1_g) norm(a.ln1_g, a.ln1_b);
-            if (grow < a.M && a.out_f32) {
+        }
+        if (a.ln2_g) {
+            rows_layernorm<RPW, VPL, D>(v, pn_g2, pn_be2, a.eps, lane);
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
                 for (int it = 0; it < VPL; ++it) {
                     const int c = (lane + 64 * it) * 4;
-                    if (c < D) *(f32x4*)(a.out_f32 + grow * D + c) = v[it];
-                }
-            }
-            if (a.ln2_g) {
-                norm(a.ln2_g, a.ln2_b);
-#pragma unroll
-                for (int it = 0; it < VPL; ++it) {
-                    const int c = (lane + 64 * it) * 4;
+                    const int r = wave * RPW + rr;
+                    const int64_t grow = row0 + r;
                     if (c < KP) {
-                        const f32x4 o = c < D ? v[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        const f32x4 o = c < D ? v[rr][it] : zero4;
                         const u32x2 pk = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
                         if constexpr (TAIL) *(u32x2*)(xn + r * XN_STRIDE + c) = pk;   // the tail's input tile
                         if (c < D && grow < a.M && a.out16) *(u32x2*)((u16*)a.out16 + grow * D + c) = pk;
                     }
                 }
-            }
         }
         if constexpr (TAIL) __syncthreads();
     }
+    CFM_STAMP(6);
 
     // ================= TAIL: t = xn . Wt^T + bt (GLU optional), 16-bit store ===================================
     if constexpr (TAIL) {
-        const int nfrags = a.tail_N / 16;
         const int ldo = TGLU ? a.tail_N / 2 : a.tail_N;
-        const u32x4* wp = (const u32x4*)a.tail_w + lane;
-        auto frag0 = [&](int s) { return (s * NW + wave) * 2; };
-        auto clampf = [&](int f) { return f < nfrags ? f : nfrags - 1; };
-        u32x4 wr[2 * KS1];
-#pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) {
-            wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
-            wr[KS1 + kk] = wp[((int64_t)clampf(frag0(0) + 1) * KS1 + kk) * 64];
-        }
 #pragma unroll
         for (int s = 0; s < TSTEPS; ++s) {
-            const int f = frag0(s);
-            const int fn = frag0(s + 1 < TSTEPS ? s + 1 : s);
+            const int f = t_frag0(s);
+            const int fn = t_frag0(s + 1 < TSTEPS ? s + 1 : s);
+            const bool v0ok = f < t_nfrags, v1ok = f + 1 < t_nfrags;
+            const f32x4 bb0 = *(const f32x4*)(a.tail_b + t_clamp(f) * 16 + 4 * g);      // issued before this step's MFMAs
+            const f32x4 bb1 = *(const f32x4*)(a.tail_b + t_clamp(f + 1) * 16 + 4 * g);
             f32x4 acc[2][2];
-            linear_step<HT, KS1, XN_STRIDE>(xn, wp, clampf(fn), clampf(fn + 1), wr, acc, g, l15);
-            const bool v0ok = f < nfrags, v1ok = f + 1 < nfrags;
-            const f32x4 bb0 = *(const f32x4*)(a.tail_b + clampf(f) * 16 + 4 * g);
-            const f32x4 bb1 = *(const f32x4*)(a.tail_b + clampf(f + 1) * 16 + 4 * g);
+            linear_step<HT, KS1, XN_STRIDE>(xn, twp, s + 1 < TSTEPS, t_clamp(fn), t_clamp(fn + 1), twr, acc, g, l15);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int64_t grow = row0 + mf * 16 + l15;
@@ -481,6 +585,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
             }
         }
     }
+    CFM_STAMP(7);
 }
 
 template <typename HT, int D, int NW, int HS, int FS, int TS, bool TGLU>
