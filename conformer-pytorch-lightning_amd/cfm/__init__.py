@@ -61,7 +61,7 @@ class FfnPartialDesc(ctypes.Structure):
 
 class RowChainDesc(ctypes.Structure):
     _fields_ = [("x", c_p), ("py0", c_p), ("py1", c_p), ("pb2", c_p), ("pln_g", c_p), ("pln_b", c_p), ("head_a", c_p), ("head_w", c_p), ("head_b", c_p), ("head_res", c_p), ("head_mask", c_p),
-                ("ln_g", c_p), ("ln_b", c_p), ("ln_mask", c_p), ("w1f", c_p), ("w2f", c_p), ("b1", c_p), ("b2", c_p),
+                ("ln_g", c_p), ("ln_b", c_p), ("ln_mask", c_p), ("w1f", c_p), ("w2n", c_p), ("b1", c_p), ("b2", c_p),
                 ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p), ("ln2_b", c_p), ("out_f32", c_p), ("out16", c_p),
                 ("tail_w", c_p), ("tail_b", c_p), ("tail_out", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32),
                 ("tail_N", c_i32), ("tail_glu", c_i32), ("w_dtype", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float),
@@ -71,7 +71,7 @@ class RowChainDesc(ctypes.Structure):
 _LAYER_W_FIELDS = [
     "ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "ln_conv_b", "ln_ff_g", "ln_ff_b", "ln_final_g", "ln_final_b",
     "ffm_w1", "ffm_w1_lo", "ffm_w2", "ffm_w2_lo", "ffm_b1", "ffm_b2",
-    "ff_w1", "ff_w1_lo", "ff_w2", "ff_w2_lo", "ff_b1", "ff_b2", "ffm_w1f", "ffm_w2f", "ff_w1f", "ff_w2f", "qkv_wf", "out_wf", "pw1_wf", "pw2_wf",
+    "ff_w1", "ff_w1_lo", "ff_w2", "ff_w2_lo", "ff_b1", "ff_b2", "ffm_w1f", "ffm_w2f", "ff_w1f", "ff_w2f", "ffm_w2n", "ff_w2n", "qkv_wf", "out_wf", "pw1_wf", "pw2_wf",
     "qkv_w", "qkv_w_lo", "pos_w", "pos_w_lo", "out_w", "out_w_lo", "qkv_b", "out_b", "bias_u", "bias_v",
     "pw1_w", "pw1_w_lo", "pw2_w", "pw2_w_lo", "pw1_b", "pw2_b", "dw_w", "dw_b", "bn_scale", "bn_shift"]
 

@@ -133,7 +133,8 @@ def ffn_partial(x, ln, w1f, w2f, b1, FF, y0, y1, pending=None, head=None, x_out=
 def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, alpha=1.0, ln1=None, ln2=None, out_f32=None, out16=None,
              tail=None, eps=1e-5, pending=None):
     """One-launch row-local chain (include/cfm.h cfm_rowchain).
-    head = (a16 [M,D], w_frag, bias, residual f32 [M,D], out_mask u8 [M] | None);  ffn = (w1f, w2f, b1, b2, FF);
+    head = (a16 [M,D], w_frag, bias, residual f32 [M,D], out_mask u8 [M] | None);  ffn = (w1f, w2n, b1, b2, FF) with
+    w1f = pack_frag_major(W1), w2n = pack_frag_major(W2) (natural k order, NOT ffn_fused's permuted w2f);
     tail = (w_frag, bias, N, glu, out 16-bit [M, N or N/2]);  ln/ln1/ln2 = (gain, bias)."""
     d = _c.RowChainDesc()
     keep = [x, out_f32, out16, ln_mask]
@@ -148,7 +149,7 @@ def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, a
             setattr(d, name + "_g", _c.ptr(pair[0]))
             setattr(d, name + "_b", _c.ptr(pair[1]))
     if ffn is not None:
-        d.w1f, d.w2f, d.b1, d.b2, d.FF = _c.ptr(ffn[0]), _c.ptr(ffn[1]), _c.ptr(ffn[2]), _c.ptr(ffn[3]), ffn[4]
+        d.w1f, d.w2n, d.b1, d.b2, d.FF = _c.ptr(ffn[0]), _c.ptr(ffn[1]), _c.ptr(ffn[2]), _c.ptr(ffn[3]), ffn[4]
     if tail is not None:
         d.tail_w, d.tail_b, d.tail_N, d.tail_glu, d.tail_out = _c.ptr(tail[0]), _c.ptr(tail[1]), tail[2], 1 if tail[3] else 0, _c.ptr(tail[4])
     if pending is not None:                     # (py0, py1, pb2, palpha, pln | None): finish a partial FFN while loading the rows

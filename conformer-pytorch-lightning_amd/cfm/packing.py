@@ -89,10 +89,12 @@ def pack_ffn(mod, prec):
     def build():
         w1, w1l = matrix(mod.w_1.weight, prec)
         w2, w2l = matrix(mod.w_2.weight, prec)
-        pk = Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias), w1f=None, w2f=None)
+        pk = Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias), w1f=None, w2f=None, w2n=None)
         FF, D = mod.w_1.weight.shape
         if _c.ffn_fused_supported(D, FF, prec):
             pk.w1f, pk.w2f = pack_ffn_fragments(mod.w_1.weight, mod.w_2.weight, prec.w_dtype)
+        if _c.rowchain_supported(D, FF, prec):
+            pk.w2n = pack_frag_major(mod.w_2.weight, prec.w_dtype)      # the row chains read W2 in natural k order
         return pk
     return mod._pack.get([mod.w_1.weight, mod.w_1.bias, mod.w_2.weight, mod.w_2.bias], prec, build)
 
@@ -196,6 +198,7 @@ def layer_weight_struct(layer, prec):
         setattr(w, pre + "_b2", pk.b2.data_ptr())
         setattr(w, pre + "_w1f", _c.ptr(pk.w1f))
         setattr(w, pre + "_w2f", _c.ptr(pk.w2f))
+        setattr(w, pre + "_w2n", _c.ptr(pk.w2n))
     w.qkv_wf, w.out_wf, w.pw1_wf, w.pw2_wf = _c.ptr(att.qkv_wf), _c.ptr(att.out_wf), _c.ptr(cv.pw1_wf), _c.ptr(cv.pw2_wf)
     w.qkv_w, w.qkv_w_lo, w.qkv_b = att.qkv_w.data_ptr(), _c.ptr(att.qkv_w_lo), att.qkv_b.data_ptr()
     w.pos_w, w.pos_w_lo = _c.ptr(att.pos_w), _c.ptr(att.pos_w_lo)

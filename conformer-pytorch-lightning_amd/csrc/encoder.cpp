@@ -75,10 +75,10 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     CFM_CHECK_ARG(Tc == 0 || io->new_cache, "encoder layer: a KV cache input needs new_cache storage");
 
     // ---- 6-launch path: the three row-local chains of rowchain.hip -----------------------------------------------------
-    const bool chains = !c.split && w->ffm_w1f && w->ffm_w2f && w->ff_w1f && w->ff_w2f && w->qkv_wf && w->out_wf && w->pw1_wf &&
+    const bool chains = !c.split && w->ffm_w1f && w->ffm_w2n && w->ff_w1f && w->ff_w2n && w->qkv_wf && w->out_wf && w->pw1_wf &&
                         w->pw2_wf && cfm_rowchain_supported(D, FF);
     // ---- partial-FFN pipeline (ffnpart.hip): each CU streams HALF of an FFN's weights for 64 rows ---------------------
-    const bool parts = chains && s->xs2 && s->yp0 && s->yp1 && s->yq0 && s->yq1 && cfm_ffn_partial_supported(D, FF);
+    const bool parts = chains && w->ffm_w2f && w->ff_w2f && s->xs2 && s->yp0 && s->yp1 && s->yq0 && s->yq1 && cfm_ffn_partial_supported(D, FF);
     CFM_CHECK_ARG(!io->pending_in || parts, "encoder layer: pending_in needs the partial-FFN pipeline (scratch slabs)");
     CFM_CHECK_ARG(!io->defer_final || parts, "encoder layer: defer_final needs the partial-FFN pipeline (scratch slabs)");
     if (parts) {
@@ -102,7 +102,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         CFM_TRY(cfm_rowchain(&m, stream));
     } else if (chains) {
         cfm_rowchain_desc m = {};
-        m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2f = w->ffm_w2f; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
+        m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2n = w->ffm_w2n; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
         m.ln2_g = w->ln_mha_g; m.ln2_b = w->ln_mha_b; m.out_f32 = x_out; m.tail_w = w->qkv_wf; m.tail_b = w->qkv_b; m.tail_out = s->qkv;
         m.M = M; m.D = D; m.FF = FF; m.tail_N = 3 * D; m.tail_glu = 0; m.w_dtype = c.w_dt; m.alpha = 0.5f; m.eps = eps;
         CFM_TRY(cfm_rowchain(&m, stream));
@@ -180,7 +180,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         // final chain: pointwise-conv-2 + pad mask + residual -> LN_ff -> FFN -> +res -> LN_final, in place on x_out
         cfm_rowchain_desc fi = {};
         fi.head_a = s->dw; fi.head_w = w->pw2_wf; fi.head_b = w->pw2_b; fi.head_res = x_out; fi.head_mask = io->pad_valid;
-        fi.ln_g = w->ln_ff_g; fi.ln_b = w->ln_ff_b; fi.w1f = w->ff_w1f; fi.w2f = w->ff_w2f; fi.b1 = w->ff_b1; fi.b2 = w->ff_b2;
+        fi.ln_g = w->ln_ff_g; fi.ln_b = w->ln_ff_b; fi.w1f = w->ff_w1f; fi.w2n = w->ff_w2n; fi.b1 = w->ff_b1; fi.b2 = w->ff_b2;
         fi.ln1_g = w->ln_final_g; fi.ln1_b = w->ln_final_b; fi.out_f32 = x_out;
         fi.M = M; fi.D = D; fi.FF = FF; fi.w_dtype = c.w_dt; fi.alpha = 0.5f; fi.eps = eps;
         return cfm_rowchain(&fi, stream);

@@ -8,7 +8,7 @@
 //     [HEAD]  x  = residual + mask( A16 . Wh^T + bh )          A16 = 16-bit tile from the previous kernel
 //      else   x  = rows of the f32 residual stream
 //             xn = LN(x; ln)  (optionally zeroing padded rows)                      -> LDS, 16 bit
-//     [MID]   y  = x + alpha * ( W2 . act( W1 . xn + b1 ) + b2 )                    (the fused FFN of ffn.hip)
+//     [MID]   y  = x + alpha * ( W2 . act( W1 . xn + b1 ) + b2 )                    (feed-forward module)
 //      else   y  = x
 //             y1 = LN1(y) -> out_f32 ;   y2 = LN2(y1) -> LDS / out16
 //     [TAIL]  t  = y2 . Wt^T + bt   (optionally GLU: a * sigmoid(g))               -> tail_out, 16 bit
@@ -19,16 +19,26 @@
 //     final    : HEAD + MID           pointwise-conv-2 + mask + res -> LN_ff -> FFN -> +res -> LN_final
 // so a block is 6 launches: macaron, pos-projection, attention, conv-in, depthwise, final.
 //
-// All linears use the machinery proven in ffn.hip: fragment-major weights (one wavefront-load = 1 KB = one MFMA A
-// fragment), streamed L2 -> VGPR by a pinned rolling ring, straight-line unrolled steps (no branches: see ffn.hip for
-// why), swapped MFMA roles (a lane owns 4 consecutive output columns of one row), NW wavefronts that each own distinct
-// output columns (HEAD/TAIL: no cross-wavefront reduction) or distinct FF slices (MID: fixed-order LDS reduction).
-//
-// NW = 8 (two wavefronts per SIMD) for D = 256.  A wavefront pays ~60-100 clk to ISSUE one 1 KB weight load and issues in
-// order, so with one wavefront per SIMD the 32 loads of an FFN step (~3 k clk) serialise with its 64 MFMAs (1 k clk) -- measured
-// 34 us for one workgroup alone, nowhere near either the L2 stream rate (scripts/ubench.hip: 57 B/clk/CU at 4 wavefronts,
-// 109 at 8) or the MFMA rate.  With two wavefronts per SIMD one issues loads while the other runs MFMAs, and each wavefront
-// has half as many loads to issue.  256 VGPRs per wavefront then: 128 accumulators + a 12-fragment unified weight ring.
+// Design (measured with scripts/probe_chain.hip and scripts/ubench.hip on MI355X):
+//  * weights are 16-bit FRAGMENT-MAJOR: one wavefront-load (lane * 16 B, 1 KB) is one MFMA A fragment; they stream
+//    L2 -> VGPR through a register ring, every ring slot a compile-time constant (all loops unrolled, no branches on the
+//    load path), so the compiler's waits are exact vmcnt values;
+//  * swapped MFMA roles: weights are the A operand, activations (read from an LDS tile by ds_read_b128) the B operand, so
+//    a lane owns 4 consecutive output columns of one row -- vector bias / residual / stores;
+//  * 16 wavefronts per workgroup (4 per SIMD, <= 128 VGPRs each).  A wavefront pays ~64 clk to ISSUE a 1 KB load and issues
+//    in order, so its loads serialise with its own MFMAs; per-CU load throughput scales with the number of wavefronts issuing
+//    (57 B/clk/CU at 4, 109 at 8, 155 at 16).  Earlier versions of this kernel split the FFN's K over 4 or 8 wavefronts with
+//    the hidden activation fed from accumulators straight into the second product: that needs the whole 32 x D output
+//    (128 VGPRs) per wavefront, which caps the workgroup at 8 wavefronts and a 12-deep ring -- 46 k cycles per FFN against
+//    a 16 k MFMA floor.  Here the FFN runs in two phases around a 32 x FF 16-bit HIDDEN TILE IN LDS (128 KB of the 160):
+//        phase 1  hidden = act(xn . W1^T + b1)   each wavefront owns distinct hidden columns (pairs of 16-column fragments)
+//        phase 2  y      = hidden . W2^T         each wavefront owns two 16-column output fragments and half of K
+//    so accumulators are 16 VGPRs, every weight fragment is still loaded exactly once per workgroup, and there is no
+//    cross-wavefront reduction tree (the two K halves meet in the f32 output tile, fixed order);
+//  * LDS tiles are padded so that the row step is 8 words mod 64: the ds_read_b128 lane groups are then conflict-free
+//    (a 4-word step, the "+8 halfs" habit, makes every fragment read 2-way conflicted);
+//  * everything a phase needs from global memory is requested a phase early (row data, norm parameters, epilogue
+//    operands, the next phase's first weights).
 #include <string>
 #include <type_traits>
 
@@ -45,7 +55,7 @@ struct ChainArgs {
     const uint8_t* head_mask; // zero the head OUTPUT row where 0 (before the residual add)
     const float *ln_g, *ln_b;
     const uint8_t* ln_mask;   // zero the normalised row where 0
-    const u16 *w1f, *w2f;
+    const u16 *w1f, *w2n;     // fragment-major W1 [FF/16][KS1][64][8] and W2 [D/16][FF/32][64][8]
     const float *b1, *b2;
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     float* out_f32;
@@ -54,7 +64,7 @@ struct ChainArgs {
     const float* tail_b;
     void* tail_out;           // 16-bit [M, tail_N] (GLU: [M, tail_N/2])
     int64_t M;
-    int FF, tail_N;
+    int tail_N;
     int out16_dtype;
     float alpha, eps;
 };
@@ -70,45 +80,41 @@ __device__ long long cfm_chain_stamps[1024 * 16];
 
 namespace {
 
-constexpr int RBM = 32;
+constexpr int RBM = 32;                                    // rows per workgroup
+constexpr int NW = 16;                                     // wavefronts per workgroup
+constexpr int NT = 64 * NW;
+constexpr int RPW = RBM / NW;                              // rows per wavefront in the row-wise (LayerNorm) phases
+constexpr int MF = RBM / 16;                               // 16-row MFMA fragments per tile
 
-// One "linear step": this wavefront's two 16-column fragments (n-fragments f0, f0+1) over the whole K of the LDS tile.
-// With `refill`, weights for the NEXT step (n-fragments nxa, nxb -- clamped by the caller when out of range) replace the
-// current ones in the ring as they are consumed; the last step of a phase passes false (a compile-time constant after
-// unrolling) and issues no loads.
-template <typename HT, int KS1, int XN_STRIDE>
-__device__ __forceinline__ void linear_step(const u16* xn, const u32x4* wp, bool refill, int nxa, int nxb, u32x4 (&wr)[2 * KS1],
-                                            f32x4 (&acc)[2][2], int g, int l15) {
-    u32x4 xf[2][KS1];
+// One "linear step": NFR 16-column output fragments of this wavefront over the whole K (KS 32-wide slices) of an LDS tile.
+// With `refill` the weights of the NEXT step (fragments nx[], clamped by the caller) replace the current ones in the ring as
+// they are consumed; the last step of a phase passes false (a compile-time constant after unrolling) and issues no loads.
+template <typename HT, int KS, int NFR, int STRIDE>
+__device__ __forceinline__ void linear_step(const u16* tile, const u32x4* wp, bool refill, const int (&nx)[NFR], u32x4 (&wr)[NFR * KS],
+                                            f32x4 (&acc)[MF][NFR], int g, int l15) {
+    auto frag = [&](int mf, int kk) { return *(const u32x4*)(tile + (mf * 16 + l15) * STRIDE + kk * 32 + 8 * g); };
+    u32x4 xf[2][MF];                                       // activation fragments: this kk and the next (one-ahead LDS reads)
 #pragma unroll
-    for (int kk = 0; kk < KS1; ++kk)
+    for (int mf = 0; mf < MF; ++mf) {
+        xf[0][mf] = frag(mf, 0);
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) xf[mf][kk] = *(const u32x4*)(xn + (mf * 16 + l15) * XN_STRIDE + kk * 32 + 8 * g);
+        for (int nf = 0; nf < NFR; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int kk = 0; kk < KS; ++kk) {
+        if (kk + 1 < KS) {
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mf = 0; mf < MF; ++mf) xf[(kk + 1) & 1][mf] = frag(mf, kk + 1);
+        }
 #pragma unroll
-    for (int kk = 0; kk < KS1; ++kk) {
+        for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) acc[mf][nf] = HT::mfma(wr[nf * KS1 + kk], xf[mf][kk], acc[mf][nf]);
+            for (int mf = 0; mf < MF; ++mf) acc[mf][nf] = HT::mfma(wr[nf * KS + kk], xf[kk & 1][mf], acc[mf][nf]);
         if (refill) {
-            wr[kk] = wp[((int64_t)nxa * KS1 + kk) * 64];
-            wr[KS1 + kk] = wp[((int64_t)nxb * KS1 + kk) * 64];
+#pragma unroll
+            for (int nf = 0; nf < NFR; ++nf) wr[nf * KS + kk] = wp[((int64_t)nx[nf] * KS + kk) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// s_setprio takes an immediate; the argument is a constant after unrolling and the switch folds away.
-__device__ __forceinline__ void set_wave_priority(int p) {
-    switch (p) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
     }
 }
 
@@ -142,24 +148,26 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
             if ((lane + 64 * it) * 4 < D) v[rr][it] = (v[rr][it] - mean[rr]) * rstd[rr] * gam[it] + bet[it];
 }
 
-template <typename HT, int D, int NW, int HSTEPS, int FSTEPS, int TSTEPS, bool TGLU>
-__global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a) {
-    constexpr bool HEAD = HSTEPS > 0, MID = FSTEPS > 0, TAIL = TSTEPS > 0;
-    constexpr int NT = 64 * NW;
-    constexpr int RPW = RBM / NW;                          // rows per wavefront in the row-wise (LayerNorm) phases
-    static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts");
-    constexpr int KS1 = (D + 31) / 32;
+template <typename HT, int D, int FF, int HSTEPS, bool MID, int TSTEPS, bool TGLU>
+__global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
+    constexpr bool HEAD = HSTEPS > 0, TAIL = TSTEPS > 0;
+    constexpr int KS1 = (D + 31) / 32;                     // 32-wide K slices of a D-long row
     constexpr int KP = KS1 * 32;
-    constexpr int NF2 = D / 16;
-    constexpr int MF = RBM / 16;
-    constexpr int XS_STRIDE = D + 4;
-    constexpr int XN_STRIDE = KP + 8;
+    constexpr int NF2 = D / 16;                            // 16-column fragments of a D-wide output
+    constexpr int XS_STRIDE = D + 4;                       // f32 tile rows (floats)
+    constexpr int XN_STRIDE = KP + 16;                     // 16-bit tile rows (halfs): row step = 8 words mod 64
+    constexpr int HS = FF + 16;                            // hidden tile rows (halfs): same rule (FF/2 words = 0 or 32 mod 64)
     constexpr int VPL = (D + 255) / 256;
-    static_assert(D % 16 == 0 && D <= 256 && MF == 2, "row chain supports D % 16 == 0, D <= 256");
+    constexpr int TFR = TGLU ? 2 : 1;                      // fragments per wavefront per tail step ((value, gate) pairs for GLU)
+    static_assert(D % 16 == 0 && D <= 256 && MF == 2 && RPW == 2, "row chain supports D % 16 == 0, D <= 256");
+    static_assert(!MID || (FF % 64 == 0 && (XN_STRIDE / 2) % 64 % 16 == 8 && (HS / 2) % 64 % 16 == 8), "FF % 64 == 0 and conflict-free LDS strides");
 
-    __shared__ __attribute__((aligned(16))) float xs[RBM * XS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float slab[(MID ? 2 : 0) * RBM * XS_STRIDE + 4];
+    // region A: the f32 x tile between HEAD and LN_in, then the 16-bit hidden tile, then the f32 y tile of the FFN
+    constexpr int A_BYTES = MID && RBM * HS * 2 > RBM * XS_STRIDE * 4 ? RBM * HS * 2 : RBM * XS_STRIDE * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[A_BYTES];
     __shared__ __attribute__((aligned(16))) u16 xn[RBM * XN_STRIDE];
+    float* const xs = (float*)lds_a;
+    u16* const hid = (u16*)lds_a;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,32 +177,27 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
     CFM_STAMP(0);
 
     // The tail's weight ring is declared here so that its first fill can be issued a phase or two before the tail runs
-    // (with no FFN in between: at kernel start; otherwise right after the FFN steps, to land during the reduction).
+    // (with no FFN in between: at kernel start; otherwise at the end of the FFN's second phase).
     const int t_nfrags = TAIL ? a.tail_N / 16 : 1;
-    auto t_frag0 = [&](int s) { return (s * NW + wave) * 2; };
+    auto t_frag0 = [&](int s) { return (s * NW + wave) * TFR; };
     auto t_clamp = [&](int f) { return f < t_nfrags ? f : t_nfrags - 1; };
     const u32x4* twp = (const u32x4*)a.tail_w + lane;
-    u32x4 twr[2 * KS1];
+    u32x4 twr[TFR * KS1];
     auto tail_prefetch = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) {
-            twr[kk] = twp[((int64_t)t_clamp(t_frag0(0)) * KS1 + kk) * 64];
-            twr[KS1 + kk] = twp[((int64_t)t_clamp(t_frag0(0) + 1) * KS1 + kk) * 64];
-        }
+        for (int nf = 0; nf < TFR; ++nf)
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk) twr[nf * KS1 + kk] = twp[((int64_t)t_clamp(t_frag0(0) + nf) * KS1 + kk) * 64];
     };
 
     // ================= HEAD: x = res + mask(A . Wh^T + bh) =====================================================
     if constexpr (HEAD) {
         const u32x4* wp = (const u32x4*)a.head_w + lane;
-        auto frag0 = [&](int s) { return (s * NW + wave) * 2; };
+        auto frag0 = [&](int s) { return s * NW + wave; };
         auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
-        u32x4 wr[2 * KS1];
+        u32x4 wr[KS1];
 #pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) {                 // weights first: their latency overlaps the tile staging below
-            wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
-            wr[KS1 + kk] = wp[((int64_t)clampf(frag0(0) + 1) * KS1 + kk) * 64];
-        }
-        if constexpr (TAIL && !MID) tail_prefetch();
+        for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];   // weights first
         // stage the 16-bit input tile (rows clamped), zero-padded to KP columns
         constexpr int CPRW = KP / 8;                       // 16-byte chunks per row
         for (int id = tid; id < RBM * CPRW; id += NT) {
@@ -209,53 +212,78 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
 #pragma unroll
         for (int s = 0; s < HSTEPS; ++s) {
             const int f = frag0(s);
-            const int fn = frag0(s + 1 < HSTEPS ? s + 1 : s);
+            const int nx[1] = {clampf(frag0(s + 1 < HSTEPS ? s + 1 : s))};
             // epilogue operands of this step, issued before its MFMAs
-            f32x4 bb[2], rs[2][MF];
+            const int col = clampf(f) * 16 + 4 * g;
+            f32x4 rs[MF];
             bool keep[MF];
             int64_t grows[MF];
+            const f32x4 bb = *(const f32x4*)(a.head_b + col);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int64_t gr = row0 + mf * 16 + l15;
                 grows[mf] = gr < a.M ? gr : a.M - 1;
                 keep[mf] = true;
-            }
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                const int col = clampf(f + nf) * 16 + 4 * g;
-                bb[nf] = *(const f32x4*)(a.head_b + col);
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) rs[nf][mf] = *(const f32x4*)(a.head_res + grows[mf] * D + col);
+                rs[mf] = *(const f32x4*)(a.head_res + grows[mf] * D + col);
             }
             if (a.head_mask) {
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf) keep[mf] = a.head_mask[grows[mf]] != 0;
             }
-            f32x4 acc[2][2];
-            linear_step<HT, KS1, XN_STRIDE>(xn, wp, s + 1 < HSTEPS, clampf(fn), clampf(fn + 1), wr, acc, g, l15);
+            f32x4 acc[MF][1];
+            linear_step<HT, KS1, 1, XN_STRIDE>(xn, wp, s + 1 < HSTEPS, nx, wr, acc, g, l15);
+            if (f < NF2) {
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                const int col = (f + nf) * 16 + 4 * g;
-                if (f + nf < NF2) {
-#pragma unroll
-                    for (int mf = 0; mf < MF; ++mf) {
-                        f32x4 v = acc[mf][nf] + bb[nf];
-                        if (!keep[mf]) v = zero4;
-                        v += rs[nf][mf];
-                        *(f32x4*)(xs + (mf * 16 + l15) * XS_STRIDE + col) = v;
-                    }
+                for (int mf = 0; mf < MF; ++mf) {
+                    f32x4 v = acc[mf][0] + bb;
+                    if (!keep[mf]) v = zero4;
+                    v += rs[mf];
+                    *(f32x4*)(xs + (mf * 16 + l15) * XS_STRIDE + col) = v;
                 }
             }
         }
         __syncthreads();
-    } else {
-        if constexpr (TAIL && !MID) tail_prefetch();
     }
+    if constexpr (TAIL && !MID) tail_prefetch();           // lands during the LayerNorm phase
     CFM_STAMP(2);
 
-    // ================= rows -> (x in LDS,) LN_in -> xn ===========================================================
+    // ================= FFN weight stream (declared here: its first ring fill is issued before the LayerNorm phase) ======
+    // phase 1: this wavefront owns hidden-fragment PAIRS q = i * NW + wave (i < P1); phase 2: output fragments 2 np, 2 np + 1
+    // over the K half kh.  One stream of positions per wavefront,
+    //     phase 1: pos = (i * KS1 + kk) * 2 + nf          phase 2: pos = NPOS1 + k * 2 + nf
+    // a ring of RING registers holds the next RING fragments, slot = pos % RING, and the slot just consumed is refilled with
+    // the fragment RING positions ahead.
+    constexpr int NPAIR1 = FF / 32, P1 = (NPAIR1 + NW - 1) / NW;
+    constexpr int KS2 = FF / 32, KH = KS2 / 2;
+    constexpr int NPOS1 = P1 * KS1 * 2, NPOS2 = KH * 2, NPOS = NPOS1 + NPOS2;
+    constexpr int RING = 12;                             // 16 spills ~10 VGPRs at the 128-register budget
+    static_assert(!MID || ((NF2 + 1) / 2 <= NW / 2 && KS2 % 2 == 0), "phase 2 maps (fragment pair, K half) onto 16 wavefronts");
+    const int np = wave & 7, kh = wave >> 3;
+    const u32x4* w1p = (const u32x4*)a.w1f + lane;
+    const u32x4* w2p = (const u32x4*)a.w2n + lane;
+    u32x4 ring[RING];
+    auto pair_of = [&](int i) { const int q = i * NW + wave; return q < NPAIR1 ? q : NPAIR1 - 1; };
+    auto frag_ptr = [&](int pos) {
+        if (pos < NPOS1) {
+            const int i = pos / (2 * KS1), kk = (pos / 2) % KS1, nf = pos & 1;
+            return w1p + ((int64_t)(2 * pair_of(i) + nf) * KS1 + kk) * 64;
+        }
+        const int k = (pos - NPOS1) / 2, nf = pos & 1;
+        const int n = 2 * np + nf < NF2 ? 2 * np + nf : NF2 - 1;
+        return w2p + ((int64_t)n * KS2 + kh * KH + k) * 64;
+    };
+    auto refill = [&](int pos) {
+        if (pos + RING < NPOS) ring[pos % RING] = *frag_ptr(pos + RING);
+    };
+    if constexpr (MID) {
+#pragma unroll
+        for (int t = 0; t < RING; ++t)
+            if (t < NPOS) ring[t] = *frag_ptr(t);
+    }
+
+    // ================= rows -> LN_in -> xn ======================================================================
+    f32x4 xres[RPW][VPL];                                  // this wavefront's rows of x: the residual, kept in registers
     {
-        f32x4 v[RPW][VPL];
         int64_t grows[RPW];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {                 // all of this wavefront's rows are requested before any is used
@@ -265,8 +293,8 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
 #pragma unroll
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
-                if constexpr (HEAD) v[rr][it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : zero4;
-                else v[rr][it] = c < D ? *(const f32x4*)(a.x + grows[rr] * D + c) : zero4;
+                if constexpr (HEAD) xres[rr][it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : zero4;
+                else xres[rr][it] = c < D ? *(const f32x4*)(a.x + grows[rr] * D + c) : zero4;
             }
         }
         f32x4 gam[VPL], bet[VPL];
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
                         const int c = (lane + 64 * it) * 4;
                         if (c < D) {
                             const f32x4 y = *(const f32x4*)(a.py0 + grows[rr] * D + c) + *(const f32x4*)(a.py1 + grows[rr] * D + c);
-                            v[rr][it] += a.palpha * (y + *(const f32x4*)(a.pb2 + c));
+                            xres[rr][it] += a.palpha * (y + *(const f32x4*)(a.pb2 + c));
                         }
                     }
                 if (a.pln_g) {
@@ -305,16 +333,9 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
                         pg[it] = c < D ? *(const f32x4*)(a.pln_g + c) : zero4;
                         pb[it] = c < D ? *(const f32x4*)(a.pln_b + c) : zero4;
                     }
-                    rows_layernorm<RPW, VPL, D>(v, pg, pb, a.eps, lane);
+                    rows_layernorm<RPW, VPL, D>(xres, pg, pb, a.eps, lane);
                 }
             }
-#pragma unroll
-            for (int rr = 0; rr < RPW; ++rr)
-#pragma unroll
-                for (int it = 0; it < VPL; ++it) {
-                    const int c = (lane + 64 * it) * 4;
-                    if (c < D) *(f32x4*)(xs + (wave * RPW + rr) * XS_STRIDE + c) = v[rr][it];
-                }
         }
         if constexpr (!MID) {                              // no FFN here: the rows ARE the new residual stream
             if (a.out_f32) {
@@ -323,10 +344,15 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
 #pragma unroll
                     for (int it = 0; it < VPL; ++it) {
                         const int c = (lane + 64 * it) * 4;
-                        if (c < D && row0 + wave * RPW + rr < a.M) *(f32x4*)(a.out_f32 + (row0 + wave * RPW + rr) * D + c) = v[rr][it];
+                        if (c < D && row0 + wave * RPW + rr < a.M) *(f32x4*)(a.out_f32 + (row0 + wave * RPW + rr) * D + c) = xres[rr][it];
                     }
             }
         }
+        f32x4 v[RPW][VPL];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) v[rr][it] = xres[rr][it];
         if (a.ln_g) rows_layernorm<RPW, VPL, D>(v, gam, bet, a.eps, lane);
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr)
@@ -339,115 +365,92 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
                 }
             }
     }
-    __syncthreads();
+    __syncthreads();                                       // xn complete; every read of the x tile in region A is done
     CFM_STAMP(3);
 
-    // parameters of the post norms: requested after the FFN steps, used after the reduction
+    // parameters of the post norms: requested during the FFN, used after it
     f32x4 pn_b2[VPL], pn_g1[VPL], pn_b1[VPL], pn_g2[VPL], pn_be2[VPL];
 
-    // ================= MID: fused feed-forward (see ffn.hip for the design notes) ================================
+    // ================= MID: feed-forward in two phases around the hidden tile ====================================
     if constexpr (MID) {
-        auto xfrag = [&](int mf, int kk) { return *(const u32x4*)(xn + (mf * 16 + l15) * XN_STRIDE + kk * 32 + 8 * g); };
-        const int nsteps_total = a.FF / 32;
-        f32x4 acc2[MF][NF2];
+        // ---- phase 1: hidden = SiLU(xn . W1^T + b1) -> region A, 16 bit
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = zero4;
-        const u32x4* w1p = (const u32x4*)a.w1f + lane;
-        const u32x4* w2p = (const u32x4*)a.w2f + lane;
-        // One weight STREAM per wavefront: step s consumes NW1 fragments of W1 (in (kk, nf) order) and then NF2 fragments of
-        // W2; a ring of RING registers holds the next RING fragments of that stream, slot = position % RING, and the slot
-        // just consumed is refilled with the fragment RING positions ahead.  Everything about a position is a compile-time
-        // constant after unrolling, so the ring lives in registers and the waits are exact vmcnt values.
-        constexpr int NW1 = 2 * KS1, NFR = NW1 + NF2;
-        constexpr int RING = NW == 4 ? 32 : 12;            // 16 spills at 256 VGPRs (128 of them accumulators)
-        u32x4 ring[RING];
-        f32x4 b1r[2];
-        const int rot = (int)(blockIdx.x % FSTEPS);
-        auto step_of = [&](int s) { int q = s + rot; q = q >= FSTEPS ? q - FSTEPS : q; return q * NW + wave; };
-        auto step_clamped = [&](int s) { const int f = step_of(s); return f < nsteps_total ? f : nsteps_total - 1; };
-        auto frag_ptr = [&](int fs, int p) {
-            if (p < NW1) return w1p + ((int64_t)(2 * fs) * KS1 + (p & 1) * KS1 + (p >> 1)) * 64;   // (kk, nf) = (p >> 1, p & 1)
-            return w2p + ((int64_t)fs * NF2 + (p - NW1)) * 64;
-        };
-        auto refill = [&](int s, int p) {                  // after consuming position (s, p)
-            const int t = s * NFR + p + RING;
-            const int s2 = t / NFR, p2 = t % NFR;
-            if (s2 < FSTEPS) ring[(s * NFR + p) % RING] = *frag_ptr(step_clamped(s2), p2);
-        };
-        auto step = [&](int s) {
-            const bool valid = step_of(s) < nsteps_total;
-            const int nx = step_clamped(s + 1 < FSTEPS ? s + 1 : s);
+        for (int i = 0; i < P1; ++i) {
+            const int q = i * NW + wave;
+            const bool valid = NPAIR1 % NW == 0 ? true : q < NPAIR1;
+            const int qc = pair_of(i);
+            const f32x4 bb0 = *(const f32x4*)(a.b1 + (2 * qc) * 16 + 4 * g);      // used after this pair's MFMAs
+            const f32x4 bb1 = *(const f32x4*)(a.b1 + (2 * qc + 1) * 16 + 4 * g);
+            auto xfrag = [&](int mf, int kk) { return *(const u32x4*)(xn + (mf * 16 + l15) * XN_STRIDE + kk * 32 + 8 * g); };
             f32x4 acc1[MF][2];
+            u32x4 xf[2][MF];
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < 2; ++nf) acc1[mf][nf] = zero4;
-            u32x4 xf[2][MF];                               // activation fragments: this kk and the next (one-ahead LDS reads)
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) xf[0][mf] = xfrag(mf, 0);
+            for (int mf = 0; mf < MF; ++mf) {
+                xf[0][mf] = xfrag(mf, 0);
+                acc1[mf][0] = zero4;
+                acc1[mf][1] = zero4;
+            }
 #pragma unroll
             for (int kk = 0; kk < KS1; ++kk) {
+                const int pos = (i * KS1 + kk) * 2;
                 if (kk + 1 < KS1) {
 #pragma unroll
                     for (int mf = 0; mf < MF; ++mf) xf[(kk + 1) & 1][mf] = xfrag(mf, kk + 1);
                 }
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf) {
+                for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-                    for (int mf = 0; mf < MF; ++mf)
-                        acc1[mf][nf] = HT::mfma(ring[(s * NFR + kk * 2 + nf) % RING], xf[kk & 1][mf], acc1[mf][nf]);
-                }
-                refill(s, kk * 2);
-                refill(s, kk * 2 + 1);
+                    for (int mf = 0; mf < MF; ++mf) acc1[mf][nf] = HT::mfma(ring[(pos + nf) % RING], xf[kk & 1][mf], acc1[mf][nf]);
+                refill(pos);
+                refill(pos + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const f32x4 bb0 = b1r[0], bb1 = b1r[1];
-            if (s + 1 < FSTEPS) {
-                b1r[0] = *(const f32x4*)(a.b1 + nx * 32 + 4 * g);
-                b1r[1] = *(const f32x4*)(a.b1 + nx * 32 + 16 + 4 * g);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            u32x4 hf[MF];
+            if (valid) {
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                f32x4 h0 = acc1[mf][0] + bb0, h1 = acc1[mf][1] + bb1;
+                for (int mf = 0; mf < MF; ++mf) {
+                    f32x4 h0 = acc1[mf][0] + bb0, h1 = acc1[mf][1] + bb1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    h0[r] = siluf_(h0[r]);
-                    h1[r] = siluf_(h1[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        h0[r] = siluf_(h0[r]);
+                        h1[r] = siluf_(h1[r]);
+                    }
+                    u16* hp = hid + (mf * 16 + l15) * HS + (2 * q) * 16 + 4 * g;
+                    *(u32x2*)hp = (u32x2){pack2<HT>(h0.x, h0.y), pack2<HT>(h0.z, h0.w)};
+                    *(u32x2*)(hp + 16) = (u32x2){pack2<HT>(h1.x, h1.y), pack2<HT>(h1.z, h1.w)};
                 }
-                hf[mf] = pack8<HT>(h0, h1);
-                if (!valid) hf[mf] = (u32x4){0u, 0u, 0u, 0u};
             }
-#pragma unroll
-            for (int nf = 0; nf < NF2; ++nf) {
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) acc2[mf][nf] = HT::mfma(ring[(s * NFR + NW1 + nf) % RING], hf[mf], acc2[mf][nf]);
-                refill(s, NW1 + nf);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        {
-            const int f0 = step_clamped(0);
-            b1r[0] = *(const f32x4*)(a.b1 + f0 * 32 + 4 * g);
-            b1r[1] = *(const f32x4*)(a.b1 + f0 * 32 + 16 + 4 * g);
-#pragma unroll
-            for (int t = 0; t < RING; ++t)
-                if (t / NFR < FSTEPS) ring[t] = *frag_ptr(step_clamped(t / NFR), t % NFR);
         }
-#pragma unroll
-        for (int s = 0; s < FSTEPS; ++s) {
-            // the two wavefronts of a SIMD share its issue slots; the one that is behind gets priority, so that both finish
-            // together instead of the younger one running its last steps alone (loads and MFMAs serialised again)
-            if constexpr (NW == 8) set_wave_priority(3 - (s * 4) / FSTEPS);
-            step(s);
-        }
-        if constexpr (NW == 8) set_wave_priority(0);
+        __syncthreads();
         CFM_STAMP(4);
 
-        // requests that land during the reduction: post-norm parameters and the tail's first weights
+        // ---- phase 2: y = hidden . W2^T, fragments (2 np, 2 np + 1), K half kh
+        f32x4 acc2[MF][2];
+        {
+            auto hfrag = [&](int mf, int k) { return *(const u32x4*)(hid + (mf * 16 + l15) * HS + (kh * KH + k) * 32 + 8 * g); };
+            u32x4 hf[2][MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                hf[0][mf] = hfrag(mf, 0);
+                acc2[mf][0] = zero4;
+                acc2[mf][1] = zero4;
+            }
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                const int pos = NPOS1 + k * 2;
+                if (k + 1 < KH) {
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) hf[(k + 1) & 1][mf] = hfrag(mf, k + 1);
+                }
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) acc2[mf][nf] = HT::mfma(ring[(pos + nf) % RING], hf[k & 1][mf], acc2[mf][nf]);
+                refill(pos);
+                refill(pos + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // requests that land during the tile exchange below: post-norm parameters and the tail's first weights
 #pragma unroll
         for (int it = 0; it < VPL; ++it) {
             const int c = (lane + 64 * it) * 4;
@@ -470,37 +473,24 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
             }
         }
         if constexpr (TAIL) tail_prefetch();
-
-        // cross-wavefront reduction through two LDS slabs, fixed order:
-        //   NW = 4: (w0 + w2) + (w1 + w3)        NW = 8: ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
-        auto slab_ptr = [&](int which, int mf, int nf) { return slab + which * RBM * XS_STRIDE + (mf * 16 + l15) * XS_STRIDE + nf * 16 + 4 * g; };
-        auto dump = [&](int which) {
+        __syncthreads();                                   // every wavefront is done reading the hidden tile
+        // the two K halves meet in the f32 y tile (region A again), fixed order: half 0 stores, half 1 adds
+        auto ytile = [&](int mf, int nf) { return xs + (mf * 16 + l15) * XS_STRIDE + (2 * np + nf) * 16 + 4 * g; };
+        if (kh == 0) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                for (int nf = 0; nf < NF2; ++nf) *(f32x4*)slab_ptr(which, mf, nf) = acc2[mf][nf];
-        };
-        auto absorb = [&](int which) {
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] += *(const f32x4*)slab_ptr(which, mf, nf);
-        };
-        if constexpr (NW == 8) {
-            if (wave >= 6) dump(wave - 6);
-            __syncthreads();
-            if (wave == 2 || wave == 3) absorb(wave - 2);
-            __syncthreads();
-            if (wave == 4 || wave == 5) dump(wave - 4);
-            __syncthreads();
-            if (wave < 2) absorb(wave);
-            __syncthreads();
+                for (int nf = 0; nf < 2; ++nf)
+                    if (2 * np + nf < NF2) *(f32x4*)ytile(mf, nf) = acc2[mf][nf];
         }
-        if (wave == 2 || wave == 3) dump(wave - 2);
         __syncthreads();
-        if (wave < 2) absorb(wave);
-        __syncthreads();
-        if (wave < 2) dump(wave);
+        if (kh == 1) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    if (2 * np + nf < NF2) *(f32x4*)ytile(mf, nf) = *(const f32x4*)ytile(mf, nf) + acc2[mf][nf];
+        }
         __syncthreads();
     }
     CFM_STAMP(5);
@@ -515,10 +505,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
                 v[rr][it] = zero4;
-                if (c < D) {
-                    const f32x4 y = *(const f32x4*)(slab + r * XS_STRIDE + c) + *(const f32x4*)(slab + RBM * XS_STRIDE + r * XS_STRIDE + c);
-                    v[rr][it] = a.alpha * (y + pn_b2[it]) + *(const f32x4*)(xs + r * XS_STRIDE + c);
-                }
+                if (c < D) v[rr][it] = a.alpha * (*(const f32x4*)(xs + r * XS_STRIDE + c) + pn_b2[it]) + xres[rr][it];
             }
         }
         if (a.ln1_g) rows_layernorm<RPW, VPL, D>(v, pn_g1, pn_b1, a.eps, lane);
@@ -560,27 +547,34 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
         for (int s = 0; s < TSTEPS; ++s) {
             const int f = t_frag0(s);
             const int fn = t_frag0(s + 1 < TSTEPS ? s + 1 : s);
-            const bool v0ok = f < t_nfrags, v1ok = f + 1 < t_nfrags;
-            const f32x4 bb0 = *(const f32x4*)(a.tail_b + t_clamp(f) * 16 + 4 * g);      // issued before this step's MFMAs
-            const f32x4 bb1 = *(const f32x4*)(a.tail_b + t_clamp(f + 1) * 16 + 4 * g);
-            f32x4 acc[2][2];
-            linear_step<HT, KS1, XN_STRIDE>(xn, twp, s + 1 < TSTEPS, t_clamp(fn), t_clamp(fn + 1), twr, acc, g, l15);
+            int nx[TFR];
+            f32x4 bb[TFR];
+#pragma unroll
+            for (int nf = 0; nf < TFR; ++nf) {
+                nx[nf] = t_clamp(fn + nf);
+                bb[nf] = *(const f32x4*)(a.tail_b + t_clamp(f + nf) * 16 + 4 * g);      // issued before this step's MFMAs
+            }
+            f32x4 acc[MF][TFR];
+            linear_step<HT, KS1, TFR, XN_STRIDE>(xn, twp, s + 1 < TSTEPS, nx, twr, acc, g, l15);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int64_t grow = row0 + mf * 16 + l15;
                 if (grow >= a.M) continue;
-                f32x4 v0 = acc[mf][0] + bb0, v1 = acc[mf][1] + bb1;
                 if constexpr (TGLU) {
-                    if (v1ok) {                               // (value, gate) fragment pairs: tail_N % 32 == 0
+                    if (f + 1 < t_nfrags) {                   // (value, gate) fragment pairs: tail_N % 32 == 0
+                        f32x4 v0 = acc[mf][0] + bb[0];
+                        const f32x4 v1 = acc[mf][TFR - 1] + bb[TFR - 1];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v0[r] *= sigmoidf_(v1[r]);
                         const int64_t o = grow * ldo + (f >> 1) * 16 + 4 * g;
                         *(u32x2*)((u16*)a.tail_out + o) = (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)};
                     }
                 } else {
-                    const int64_t o = grow * ldo + f * 16 + 4 * g;
-                    if (v0ok) *(u32x2*)((u16*)a.tail_out + o) = (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)};
-                    if (v1ok) *(u32x2*)((u16*)a.tail_out + o + 16) = (u32x2){pack2<HT>(v1.x, v1.y), pack2<HT>(v1.z, v1.w)};
+                    if (f < t_nfrags) {
+                        const f32x4 v0 = acc[mf][0] + bb[0];
+                        const int64_t o = grow * ldo + f * 16 + 4 * g;
+                        *(u32x2*)((u16*)a.tail_out + o) = (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)};
+                    }
                 }
             }
         }
@@ -588,11 +582,11 @@ __global__ __launch_bounds__(64 * NW) void cfm_rowchain_kernel(const ChainArgs a
     CFM_STAMP(7);
 }
 
-template <typename HT, int D, int NW, int HS, int FS, int TS, bool TGLU>
+template <typename HT, int D, int FF, int HS, bool MID, int TS, bool TGLU>
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
     const unsigned grid = (unsigned)((a.M + RBM - 1) / RBM);
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, NW, HS, FS, TS, TGLU>), dim3(grid), dim3(64 * NW), 0, s, a);
+    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, FF, HS, MID, TS, TGLU>), dim3(grid), dim3(NT), 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -607,41 +601,40 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_rowchain: w_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(head || d->x, "cfm_rowchain: need x or a head input");
     CFM_CHECK_ARG(!head || (d->head_w && d->head_b && d->head_res), "cfm_rowchain: head needs weights, bias and residual");
-    CFM_CHECK_ARG(!mid || (d->w2f && d->b1 && d->b2 && d->FF > 0 && d->FF % 32 == 0 && d->FF <= 2048), "cfm_rowchain: bad FFN arguments");
+    CFM_CHECK_ARG(!mid || (d->w2n && d->b1 && d->b2 && d->FF > 0), "cfm_rowchain: the feed-forward needs w1f, w2n, b1, b2 and FF");
     CFM_CHECK_ARG(!tail || (d->tail_b && d->tail_out && d->tail_N % 16 == 0 && d->tail_N > 0 && (!d->tail_glu || d->tail_N % 32 == 0)),
                   "cfm_rowchain: tail needs bias, output and N %% 16 == 0 (GLU: N %% 32 == 0)");
     CFM_CHECK_ARG(!tail || (mid ? d->ln2_g != nullptr : true), "cfm_rowchain: a tail after the FFN takes its input from the second LayerNorm");
     ChainArgs a;
     a.x = d->x; a.head_a = (const u16*)d->head_a; a.head_w = (const u16*)d->head_w; a.head_b = d->head_b; a.head_res = d->head_res;
-    a.head_mask = d->head_mask; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_mask = d->ln_mask; a.w1f = (const u16*)d->w1f; a.w2f = (const u16*)d->w2f;
+    a.head_mask = d->head_mask; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_mask = d->ln_mask; a.w1f = (const u16*)d->w1f; a.w2n = (const u16*)d->w2n;
     a.b1 = d->b1; a.b2 = d->b2; a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32;
-    a.out16 = d->out16; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M; a.FF = d->FF;
+    a.out16 = d->out16; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M;
     a.tail_N = d->tail_N; a.out16_dtype = d->w_dtype; a.alpha = d->alpha; a.eps = d->eps;
     a.py0 = d->py0; a.py1 = d->py1; a.pb2 = d->pb2; a.pln_g = d->pln_g; a.pln_b = d->pln_b; a.palpha = d->palpha;
     CFM_CHECK_ARG(!d->py0 || (d->py1 && d->pb2 && !head), "cfm_rowchain: the reduce input needs both slabs and the bias, and no head");
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->w_dtype == CFM_BF16;
-    const int nw = d->D == 256 ? 8 : 4;                    // wavefronts per workgroup (see the header comment)
-    const int fsteps = mid ? (d->FF / 32 + nw - 1) / nw : 0;
-    const int tsteps = tail ? (d->tail_N / 16 + 2 * nw - 1) / (2 * nw) : 0;
+    const int tfrags = tail ? d->tail_N / 16 : 0;
+    const int tsteps = !tail ? 0 : d->tail_glu ? (tfrags / 2 + NW - 1) / NW : (tfrags + NW - 1) / NW;
     const double M = (double)d->M;
     const double fl_head = head ? 2.0 * M * d->D * d->D : 0.0, fl_mid = mid ? 4.0 * M * d->D * d->FF : 0.0,
                  fl_tail = tail ? 2.0 * M * d->D * d->tail_N : 0.0;
     const double fl = fl_head + fl_mid + fl_tail;
-#define CFM_RC(HT, DD, NWV, HS, FS, TS, GLU, NAME) return launch_chain<HT, DD, NWV, HS, FS, TS, GLU>(a, s, NAME, fl)
-    // the three roles of a conformer block, for D = 256 (ff 2048) and D = 144 (ff 576)
-    if (d->D == 256) {
-        if (!head && mid && tail && !d->tail_glu && fsteps == 8 && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 8, 0, 8, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 8, 0, 8, 3, false, "chain_macaron_f16_d256"); }
-        if (head && !mid && tail && d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 256, 8, 1, 0, 2, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 8, 1, 0, 2, true, "chain_convin_f16_d256"); }
-        if (head && mid && !tail && fsteps == 8) { if (bf) CFM_RC(BF16, 256, 8, 1, 8, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 8, 1, 8, 0, false, "chain_final_f16_d256"); }
-        if (!head && !mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 8, 0, 0, 3, false, "chain_qkv_bf16_d256"); else CFM_RC(F16, 256, 8, 0, 0, 3, false, "chain_qkv_f16_d256"); }
-        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 256, 8, 0, 0, 0, false, "chain_rows_bf16_d256"); else CFM_RC(F16, 256, 8, 0, 0, 0, false, "chain_rows_f16_d256"); }
-    } else {
-        if (!head && mid && tail && !d->tail_glu && fsteps == 5 && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 4, 0, 5, 4, false, "chain_macaron_bf16_d144"); else CFM_RC(F16, 144, 4, 0, 5, 4, false, "chain_macaron_f16_d144"); }
-        if (head && !mid && tail && d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 144, 4, 2, 0, 3, true, "chain_convin_bf16_d144"); else CFM_RC(F16, 144, 4, 2, 0, 3, true, "chain_convin_f16_d144"); }
-        if (head && mid && !tail && fsteps == 5) { if (bf) CFM_RC(BF16, 144, 4, 2, 5, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 4, 2, 5, 0, false, "chain_final_f16_d144"); }
-        if (!head && !mid && tail && !d->tail_glu && tsteps == 4) { if (bf) CFM_RC(BF16, 144, 4, 0, 0, 4, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 4, 0, 0, 4, false, "chain_qkv_f16_d144"); }
-        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 4, 0, 0, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 4, 0, 0, 0, false, "chain_rows_f16_d144"); }
+#define CFM_RC(HT, DD, FFV, HS, MIDV, TS, GLU, NAME) return launch_chain<HT, DD, FFV, HS, MIDV, TS, GLU>(a, s, NAME, fl)
+    // the three roles of a conformer block (+ a bare QKV projection and a bare LayerNorm), for D = 256 (ff 2048) and D = 144 (ff 576)
+    if (d->D == 256 && (!mid || d->FF == 2048)) {
+        if (!head && mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 2048, 0, true, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 2048, 0, true, 3, false, "chain_macaron_f16_d256"); }
+        if (head && !mid && tail && d->tail_glu && tsteps == 1) { if (bf) CFM_RC(BF16, 256, 64, 1, false, 1, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 64, 1, false, 1, true, "chain_convin_f16_d256"); }
+        if (head && mid && !tail) { if (bf) CFM_RC(BF16, 256, 2048, 1, true, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 2048, 1, true, 0, false, "chain_final_f16_d256"); }
+        if (!head && !mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 64, 0, false, 3, false, "chain_qkv_bf16_d256"); else CFM_RC(F16, 256, 64, 0, false, 3, false, "chain_qkv_f16_d256"); }
+        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 256, 64, 0, false, 0, false, "chain_rows_bf16_d256"); else CFM_RC(F16, 256, 64, 0, false, 0, false, "chain_rows_f16_d256"); }
+    } else if (d->D == 144 && (!mid || d->FF == 576)) {
+        if (!head && mid && tail && !d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 144, 576, 0, true, 2, false, "chain_macaron_bf16_d144"); else CFM_RC(F16, 144, 576, 0, true, 2, false, "chain_macaron_f16_d144"); }
+        if (head && !mid && tail && d->tail_glu && tsteps == 1) { if (bf) CFM_RC(BF16, 144, 64, 1, false, 1, true, "chain_convin_bf16_d144"); else CFM_RC(F16, 144, 64, 1, false, 1, true, "chain_convin_f16_d144"); }
+        if (head && mid && !tail) { if (bf) CFM_RC(BF16, 144, 576, 1, true, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 576, 1, true, 0, false, "chain_final_f16_d144"); }
+        if (!head && !mid && tail && !d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 2, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 2, false, "chain_qkv_f16_d144"); }
+        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 0, false, "chain_rows_f16_d144"); }
     }
 #undef CFM_RC
     return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: no instance for D=%d FF=%d tail_N=%d head=%d mid=%d tail=%d glu=%d", d->D, d->FF,

@@ -135,7 +135,8 @@ int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
  *     conv-in : head = out-proj on the attention context + residual, LN_conv + pad mask, tail = pointwise-conv-1 + GLU
  *     final   : head = pointwise-conv-2 (+ pad mask) + residual, LN_ff, FFN, ln1 = LN_final
  * All matrices are 16-bit FRAGMENT-MAJOR: w[((nfrag*KS + kk)*64 + lane)*8 + j] = W[nfrag*16 + (lane&15)][kk*32 + 8*(lane>>4) + j]
- * (w2f additionally k-permuted, see cfm_ffn_desc).  Instances: D in {144, 256} with the FF / tail sizes of those configs.
+ * for every matrix here, W2 included (the feed-forward keeps its hidden activation as a 32 x FF tile in LDS between the two
+ * products, so W2 is read in natural k order).  Instances: D in {144, 256} with the FF / tail sizes of those configs.
  */
 typedef struct {
     const float* x;
@@ -147,7 +148,7 @@ typedef struct {
     const uint8_t* head_mask;
     const float *ln_g, *ln_b;
     const uint8_t* ln_mask;
-    const void *w1f, *w2f;
+    const void *w1f, *w2n; /* fragment-major W1 [FF,D] and W2 [D,FF] (w2n: NATURAL k order, not cfm_ffn_fused's permuted w2f) */
     const float *b1, *b2;
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     float* out_f32;
@@ -297,6 +298,7 @@ typedef struct {
     const float *ff_b1, *ff_b2;
     /* optional fragment-major packs for cfm_ffn_fused / cfm_rowchain (NULL: the separate-GEMM path is used) */
     const void *ffm_w1f, *ffm_w2f, *ff_w1f, *ff_w2f;
+    const void *ffm_w2n, *ff_w2n; /* W2 fragment-major in natural k order: what cfm_rowchain reads (w2f: cfm_ffn_fused) */
     const void *qkv_wf, *out_wf, *pw1_wf, *pw2_wf;
     /* attention: fused qkv [3D,D], pos [D,D] (NULL for plain MHSA), out [D,D] */
     const void *qkv_w, *qkv_w_lo, *pos_w, *pos_w_lo, *out_w, *out_w_lo;

@@ -16,7 +16,7 @@ static void* dalloc(size_t bytes, int fill) {
     return p;
 }
 
-static const char* PHASE[8] = {"", "head: stage A tile", "head: GEMM + epilogue", "rows + LN_in", "FFN steps", "FFN reduce", "post norms", "tail GEMM + stores"};
+static const char* PHASE[8] = {"", "head: stage A tile", "head: GEMM + epilogue", "rows + LN_in", "FFN phase 1 (hidden)", "FFN phase 2 + y tile", "post norms", "tail GEMM + stores"};
 
 static void run(const char* name, cfm_rowchain_desc d, int M) {
     d.M = M;
@@ -77,7 +77,7 @@ int main() {
     uint8_t* mask = (uint8_t*)dalloc(MMAX, 1);
 
     cfm_rowchain_desc mac = z;                             // macaron: LN, FFN, +res, LN_mha, QKV
-    mac.x = x; mac.ln_g = vec; mac.ln_b = vec; mac.w1f = w1f; mac.w2f = w2f; mac.b1 = vec; mac.b2 = vec; mac.ln2_g = vec; mac.ln2_b = vec;
+    mac.x = x; mac.ln_g = vec; mac.ln_b = vec; mac.w1f = w1f; mac.w2n = w2f; mac.b1 = vec; mac.b2 = vec; mac.ln2_g = vec; mac.ln2_b = vec;
     mac.out_f32 = out; mac.tail_w = wt; mac.tail_b = vec; mac.tail_out = t16; mac.D = D; mac.FF = FF; mac.tail_N = 768; mac.w_dtype = CFM_BF16;
     mac.alpha = 0.5f; mac.eps = 1e-5f;
 
@@ -88,7 +88,7 @@ int main() {
 
     cfm_rowchain_desc fin = z;                             // final: pw2 + mask + res, LN_ff, FFN, +res, LN_final
     fin.head_a = a16; fin.head_w = wh; fin.head_b = vec; fin.head_res = res; fin.head_mask = mask; fin.ln_g = vec; fin.ln_b = vec;
-    fin.w1f = w1f; fin.w2f = w2f; fin.b1 = vec; fin.b2 = vec; fin.ln1_g = vec; fin.ln1_b = vec; fin.out_f32 = out; fin.D = D; fin.FF = FF;
+    fin.w1f = w1f; fin.w2n = w2f; fin.b1 = vec; fin.b2 = vec; fin.ln1_g = vec; fin.ln1_b = vec; fin.out_f32 = out; fin.D = D; fin.FF = FF;
     fin.w_dtype = CFM_BF16; fin.alpha = 0.5f; fin.eps = 1e-5f;
 
     for (int M : {32, 7968}) {

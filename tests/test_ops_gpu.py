@@ -372,7 +372,7 @@ def test_rowchain_three_roles(cfm, M, D, FF, wdt):
     wg, bg = rnd((2 * D, D), 110, D ** -0.5), rnd((2 * D,), 111, 0.2)
     lns = [(1 + 0.1 * rnd((D,), 112 + i), 0.1 * rnd((D,), 116 + i)) for i in range(3)]
     mask = (torch.rand(M, device="cuda") > 0.3).to(torch.uint8)
-    w1f, w2f = packing.pack_ffn_fragments(w1, w2, dt)
+    w1f, w2n = packing.pack_frag_major(w1, dt), packing.pack_frag_major(w2, dt)
     r16 = lambda t: t.to(dt).float()
     lin = lambda a, w, b: r16(a) @ r16(w).t() + b
     ffn = lambda xn: lin(F.silu(lin(xn, w1, b1)), w2, b2)
@@ -382,7 +382,7 @@ def test_rowchain_three_roles(cfm, M, D, FF, wdt):
     # macaron: x1 = x + 1/2 FFN(LN(x)); qkv = LN_mha(x1) . Wqkv^T + b
     out = torch.empty_like(x)
     qkv = torch.empty((M, 3 * D), dtype=dt, device="cuda")
-    cfm.rowchain(M, D, code, x=x, ln=lns[0], ffn=(w1f, w2f, b1, b2, FF), alpha=0.5, ln2=lns[1], out_f32=out,
+    cfm.rowchain(M, D, code, x=x, ln=lns[0], ffn=(w1f, w2n, b1, b2, FF), alpha=0.5, ln2=lns[1], out_f32=out,
                  tail=(packing.pack_frag_major(wq, dt), bq, 3 * D, False, qkv))
     x1 = x + 0.5 * ffn(ln(x, lns[0]))
     assert relerr(out, x1) < tol
@@ -401,13 +401,13 @@ def test_rowchain_three_roles(cfm, M, D, FF, wdt):
 
     # final: x3 = x + mask(a16 . Wpw2^T + b); out = LN_final(x3 + 1/2 FFN(LN_ff(x3))), in place
     xi = x.clone()
-    cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xi, mask), ln=lns[0], ffn=(w1f, w2f, b1, b2, FF), alpha=0.5,
+    cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xi, mask), ln=lns[0], ffn=(w1f, w2n, b1, b2, FF), alpha=0.5,
                  ln1=lns[1], out_f32=xi)
     x3 = x + lin(a16.float(), wh, bh) * mask[:, None].float()
     ref = ln(x3 + 0.5 * ffn(ln(x3, lns[0])), lns[1])
     assert relerr(xi, ref) < tol
     xj = x.clone()
-    cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xj, mask), ln=lns[0], ffn=(w1f, w2f, b1, b2, FF), alpha=0.5,
+    cfm.rowchain(M, D, code, head=(a16, packing.pack_frag_major(wh, dt), bh, xj, mask), ln=lns[0], ffn=(w1f, w2n, b1, b2, FF), alpha=0.5,
                  ln1=lns[1], out_f32=xj)
     assert torch.equal(xi, xj)          # bitwise reproducible
 
