@@ -65,7 +65,7 @@ class RowChainDesc(ctypes.Structure):
                 ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p), ("ln2_b", c_p), ("out_f32", c_p), ("out16", c_p),
                 ("tail_w", c_p), ("tail_b", c_p), ("tail_out", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32),
                 ("tail_N", c_i32), ("tail_glu", c_i32), ("w_dtype", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float),
-                ("palpha", ctypes.c_float)]
+                ("palpha", ctypes.c_float), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32)]
 
 
 _LAYER_W_FIELDS = [

@@ -131,8 +131,9 @@ def ffn_partial(x, ln, w1f, w2f, b1, FF, y0, y1, pending=None, head=None, x_out=
 
 
 def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, alpha=1.0, ln1=None, ln2=None, out_f32=None, out16=None,
-             tail=None, eps=1e-5, pending=None):
+             tail=None, eps=1e-5, pending=None, dw=None):
     """One-launch row-local chain (include/cfm.h cfm_rowchain).
+    dw = (taps f32 [D,15], bias, bn_scale, bn_shift, T): depthwise conv + BatchNorm + SiLU applied to the head input first;
     head = (a16 [M,D], w_frag, bias, residual f32 [M,D], out_mask u8 [M] | None);  ffn = (w1f, w2n, b1, b2, FF) with
     w1f = pack_frag_major(W1), w2n = pack_frag_major(W2) (natural k order, NOT ffn_fused's permuted w2f);
     tail = (w_frag, bias, N, glu, out 16-bit [M, N or N/2]);  ln/ln1/ln2 = (gain, bias)."""
@@ -156,6 +157,9 @@ def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, a
         d.py0, d.py1, d.pb2, d.palpha = _c.ptr(pending[0]), _c.ptr(pending[1]), _c.ptr(pending[2]), pending[3]
         if pending[4] is not None:
             d.pln_g, d.pln_b = _c.ptr(pending[4][0]), _c.ptr(pending[4][1])
+    if dw is not None:
+        _c.require_hip(*dw[:4])
+        d.dw_w, d.dw_b, d.dw_scale, d.dw_shift, d.dw_T, d.dw_K = _c.ptr(dw[0]), _c.ptr(dw[1]), _c.ptr(dw[2]), _c.ptr(dw[3]), dw[4], dw[0].shape[1]
     _c.require_hip(x, out_f32, out16)
     d.M, d.D, d.w_dtype, d.alpha, d.eps = M, D, w_code, alpha, eps
     _c.check(_c.lib().cfm_rowchain(ctypes.byref(d), _c.stream()), "cfm_rowchain")

@@ -162,7 +162,10 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         ci.ln_mask = io->pad_valid; ci.out_f32 = x_out; ci.tail_w = w->pw1_wf; ci.tail_b = w->pw1_b; ci.tail_out = s->glu;
         ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
         CFM_TRY(cfm_rowchain(&ci, stream));
-        CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+        // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise, and for the partial pipeline, on its own
+        const bool dw_fused = !parts && io->ktaps == 15;
+        if (!dw_fused)
+            CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
         if (parts) {
             // D: pointwise-conv-2 + pad mask + residual -> (rows to xs2) -> LN_ff -> FFN partial sums
             cfm_ffn_partial_desc pd = {};
@@ -179,7 +182,8 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         }
         // final chain: pointwise-conv-2 + pad mask + residual -> LN_ff -> FFN -> +res -> LN_final, in place on x_out
         cfm_rowchain_desc fi = {};
-        fi.head_a = s->dw; fi.head_w = w->pw2_wf; fi.head_b = w->pw2_b; fi.head_res = x_out; fi.head_mask = io->pad_valid;
+        fi.head_a = dw_fused ? s->glu : s->dw; fi.head_w = w->pw2_wf;
+        if (dw_fused) { fi.dw_w = w->dw_w; fi.dw_b = w->dw_b; fi.dw_scale = w->bn_scale; fi.dw_shift = w->bn_shift; fi.dw_T = io->T; fi.dw_K = 15; } fi.head_b = w->pw2_b; fi.head_res = x_out; fi.head_mask = io->pad_valid;
         fi.ln_g = w->ln_ff_g; fi.ln_b = w->ln_ff_b; fi.w1f = w->ff_w1f; fi.w2n = w->ff_w2n; fi.b1 = w->ff_b1; fi.b2 = w->ff_b2;
         fi.ln1_g = w->ln_final_g; fi.ln1_b = w->ln_final_b; fi.out_f32 = x_out;
         fi.M = M; fi.D = D; fi.FF = FF; fi.w_dtype = c.w_dt; fi.alpha = 0.5f; fi.eps = eps;

@@ -53,6 +53,8 @@ struct ChainArgs {
     const float* head_b;
     const float* head_res;    // f32 [M,D]
     const uint8_t* head_mask; // zero the head OUTPUT row where 0 (before the residual add)
+    const float *dw_w, *dw_b, *dw_scale, *dw_shift;   // HDW: depthwise conv [D,15] + bias + folded BatchNorm applied to head_a first
+    int dw_T;                 //      frames per utterance (rows are [B, T] flattened; the conv zero-pads at utterance edges)
     const float *ln_g, *ln_b;
     const uint8_t* ln_mask;   // zero the normalised row where 0
     const u16 *w1f, *w2n;     // fragment-major W1 [FF/16][KS1][64][8] and W2 [D/16][FF/32][64][8]
@@ -73,7 +75,8 @@ struct ChainArgs {
 // workgroup records the shader clock at every phase boundary.
 #ifdef CFM_CHAIN_STAMPS
 __device__ long long cfm_chain_stamps[1024 * 16];
-#define CFM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) cfm_chain_stamps[blockIdx.x * 16 + (i)] = clock64(); } while (0)
+#define CFM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { cfm_chain_stamps[blockIdx.x * 16 + (i)] = clock64(); \
+        if ((i) == 0 || (i) == 7) cfm_chain_stamps[blockIdx.x * 16 + 8 + ((i) == 7)] = wall_clock64(); } } while (0)   /* [8], [9]: 100 MHz wall clock */
 #else
 #define CFM_STAMP(i) do { } while (0)
 #endif
@@ -148,9 +151,10 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
             if ((lane + 64 * it) * 4 < D) v[rr][it] = (v[rr][it] - mean[rr]) * rstd[rr] * gam[it] + bet[it];
 }
 
-template <typename HT, int D, int FF, int HSTEPS, bool MID, int TSTEPS, bool TGLU>
+template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU>
 __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr bool HEAD = HSTEPS > 0, TAIL = TSTEPS > 0;
+    constexpr int DWK = 15, DWH = (DWK - 1) / 2, DWROWS = RBM + DWK - 1;     // depthwise taps, halo, rows of the halo tile
     constexpr int KS1 = (D + 31) / 32;                     // 32-wide K slices of a D-long row
     constexpr int KP = KS1 * 32;
     constexpr int NF2 = D / 16;                            // 16-column fragments of a D-wide output
@@ -163,7 +167,9 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     static_assert(!MID || (FF % 64 == 0 && (XN_STRIDE / 2) % 64 % 16 == 8 && (HS / 2) % 64 % 16 == 8), "FF % 64 == 0 and conflict-free LDS strides");
 
     // region A: the f32 x tile between HEAD and LN_in, then the 16-bit hidden tile, then the f32 y tile of the FFN
-    constexpr int A_BYTES = MID && RBM * HS * 2 > RBM * XS_STRIDE * 4 ? RBM * HS * 2 : RBM * XS_STRIDE * 4;
+    constexpr int A_MAIN = MID && RBM * HS * 2 > RBM * XS_STRIDE * 4 ? RBM * HS * 2 : RBM * XS_STRIDE * 4;
+    constexpr int A_DW = HDW ? DWROWS * D * 2 + DWK * D * 4 : 0;          // 16-bit halo tile + the f32 taps of the depthwise input stage
+    constexpr int A_BYTES = A_MAIN > A_DW ? A_MAIN : A_DW;
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[A_BYTES];
     __shared__ __attribute__((aligned(16))) u16 xn[RBM * XN_STRIDE];
     float* const xs = (float*)lds_a;
@@ -196,16 +202,106 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         auto frag0 = [&](int s) { return s * NW + wave; };
         auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
         u32x4 wr[KS1];
+        if constexpr (!HDW) {
 #pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];   // weights first
-        // stage the 16-bit input tile (rows clamped), zero-padded to KP columns
+            for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];   // weights first
+        }
         constexpr int CPRW = KP / 8;                       // 16-byte chunks per row
-        for (int id = tid; id < RBM * CPRW; id += NT) {
-            const int r = id / CPRW, c = id % CPRW;
-            int64_t grow = row0 + r;
-            grow = grow < a.M ? grow : a.M - 1;
-            const u32x4 v = c * 8 < D ? *(const u32x4*)(a.head_a + grow * D + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-            *(u32x4*)(xn + r * XN_STRIDE + c * 8) = v;
+        if constexpr (HDW) {
+            // The head input is DepthwiseConv15 + bias + BatchNorm(eval, folded) + SiLU of the GLU rows (convolution.py:43-45),
+            // computed here instead of in a launch of its own.  A (32 + 14)-row halo tile goes to region A; a thread owns TWO
+            // channels of FOUR consecutive frames: 30 taps in registers, an 18-frame register window read once from LDS, packed
+            // fp32 FMAs in the tap order of cfm_dwconv_bn_silu (bit-identical results), 16-bit results into the xn tile.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            u16* const halo = (u16*)lds_a;
+            constexpr int C8 = D / 8, CP = D / 2, RG = RBM / 4;
+            static_assert(CP * RG <= NT, "one (channel pair, frame group) per thread");
+            constexpr int NHALO = (DWROWS * C8 + NT - 1) / NT;
+            u32x4 hv[NHALO];
+#pragma unroll
+            for (int i = 0; i < NHALO; ++i) {               // all requests first, then the LDS stores
+                const int id = tid + i * NT;
+                const int64_t grow = row0 - DWH + id / C8;
+                hv[i] = (u32x4){0u, 0u, 0u, 0u};
+                if (id < DWROWS * C8 && grow >= 0 && grow < a.M) hv[i] = *(const u32x4*)(a.head_a + grow * D + (id % C8) * 8);
+            }
+            const bool worker = tid < CP * RG;
+            const int cp = worker ? tid % CP : 0, rg = worker ? tid / CP : 0;   // channel pair, frame group (wave-uniform: CP % 64 == 0 or idle tail)
+            float* const taps = (float*)(lds_a + DWROWS * D * 2);                // [D][15] as in memory, staged with 16-byte loads
+            static_assert((DWK * D) % 4 == 0 && DWK * D / 4 <= NT, "one 16-byte piece of the taps per thread");
+            f32x4 tv = zero4;
+            if (tid < DWK * D / 4) tv = *(const f32x4*)(a.dw_w + 4 * tid);
+            const f32x2 pb = *(const f32x2*)(a.dw_b + 2 * cp), ps = *(const f32x2*)(a.dw_scale + 2 * cp), ph = *(const f32x2*)(a.dw_shift + 2 * cp);
+#pragma unroll
+            for (int i = 0; i < NHALO; ++i) {
+                const int id = tid + i * NT;
+                if (id < DWROWS * C8) *(u32x4*)(halo + (id / C8) * D + (id % C8) * 8) = hv[i];
+            }
+            if (tid < DWK * D / 4) *(f32x4*)(taps + 4 * tid) = tv;
+            // pad columns of the xn tile (K padded to a multiple of 32)
+            if constexpr (KP > D) {
+                for (int id = tid; id < RBM * (KP - D) / 2; id += NT) {
+                    const int r = id / ((KP - D) / 2), c = D + 2 * (id % ((KP - D) / 2));
+                    *(unsigned*)(xn + r * XN_STRIDE + c) = 0u;
+                }
+            }
+            __syncthreads();
+            if (worker) {
+                f32x2 tw[DWK];                                 // taps of channels 2cp, 2cp+1: 30 consecutive floats
+                {
+                    f32x2 raw[DWK];
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) raw[k] = *(const f32x2*)(taps + 2 * cp * DWK + 2 * k);
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) {
+                        const int i0 = k, i1 = DWK + k;            // positions in the 30-float run
+                        tw[k] = (f32x2){(i0 & 1) ? raw[i0 >> 1].y : raw[i0 >> 1].x, (i1 & 1) ? raw[i1 >> 1].y : raw[i1 >> 1].x};
+                    }
+                }
+                f32x2 win[4 + DWK - 1];
+#pragma unroll
+                for (int j = 0; j < 4 + DWK - 1; ++j) {
+                    const unsigned v = *(const unsigned*)(halo + (rg * 4 + j) * D + 2 * cp);
+                    win[j] = (f32x2){HT::to_f32((u16)(v & 0xffffu)), HT::to_f32((u16)(v >> 16))};
+                }
+                // frames outside [0, T) of their own utterance are zero padding; only groups near an edge need the selects
+                const int64_t g0 = row0 + rg * 4;
+                const int t0 = (int)((unsigned)g0 % (unsigned)a.dw_T);
+                // wave-uniform, so that it stays a scalar branch: if-converted, both variants would run with selects everywhere
+                const bool edge = __any(t0 < DWH || t0 + 3 + DWH >= a.dw_T) != 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ti = (int)((unsigned)(t0 + i) % (unsigned)a.dw_T);   // the group may cross into the next utterance
+                    f32x2 acc = (f32x2){0.f, 0.f};
+                    if (edge) {
+#pragma unroll
+                        for (int k = 0; k < DWK; ++k) {
+                            const int tt = ti - DWH + k;
+                            const f32x2 xv = (tt >= 0 && tt < a.dw_T) ? win[i + k] : (f32x2){0.f, 0.f};
+                            acc = (f32x2){fmaf(tw[k].x, xv.x, acc.x), fmaf(tw[k].y, xv.y, acc.y)};
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < DWK; ++k) acc = (f32x2){fmaf(tw[k].x, win[i + k].x, acc.x), fmaf(tw[k].y, win[i + k].y, acc.y)};
+                    }
+                    const f32x2 y = (f32x2){fmaf(acc.x + pb.x, ps.x, ph.x), fmaf(acc.y + pb.y, ps.y, ph.y)};   // as the scalar kernel contracts it
+                    const unsigned o = g0 + i < a.M ? pack2<HT>(siluf_(y.x), siluf_(y.y)) : 0u;
+                    *(unsigned*)(xn + (rg * 4 + i) * XN_STRIDE + 2 * cp) = o;
+                }
+            }
+        } else {
+            // stage the 16-bit input tile (rows clamped), zero-padded to KP columns
+            for (int id = tid; id < RBM * CPRW; id += NT) {
+                const int r = id / CPRW, c = id % CPRW;
+                int64_t grow = row0 + r;
+                grow = grow < a.M ? grow : a.M - 1;
+                const u32x4 v = c * 8 < D ? *(const u32x4*)(a.head_a + grow * D + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+                *(u32x4*)(xn + r * XN_STRIDE + c * 8) = v;
+            }
+        }
+        if constexpr (HDW) {                               // (after the depthwise stage: its register window leaves no room before)
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
         }
         __syncthreads();
         CFM_STAMP(1);
@@ -582,11 +678,11 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     CFM_STAMP(7);
 }
 
-template <typename HT, int D, int FF, int HS, bool MID, int TS, bool TGLU>
+template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU>
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
     const unsigned grid = (unsigned)((a.M + RBM - 1) / RBM);
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, FF, HS, MID, TS, TGLU>), dim3(grid), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU>), dim3(grid), dim3(NT), 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -596,7 +692,9 @@ extern "C" int cfm_rowchain_supported(int32_t D, int32_t FF) { return (D == 256 
 
 extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d, "cfm_rowchain: null descriptor");
-    const bool head = d->head_a != nullptr, mid = d->w1f != nullptr, tail = d->tail_w != nullptr;
+    const bool head = d->head_a != nullptr, mid = d->w1f != nullptr, tail = d->tail_w != nullptr, dw = d->dw_w != nullptr;
+    CFM_CHECK_ARG(!dw || (head && mid && !tail && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
+                  "cfm_rowchain: the depthwise input stage needs a head + feed-forward chain, bias/scale/shift, 15 taps and M %% dw_T == 0");
     CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256), "cfm_rowchain: D=%d has no instance (144, 256)", d->D);
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_rowchain: w_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(head || d->x, "cfm_rowchain: need x or a head input");
@@ -607,6 +705,7 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(!tail || (mid ? d->ln2_g != nullptr : true), "cfm_rowchain: a tail after the FFN takes its input from the second LayerNorm");
     ChainArgs a;
     a.x = d->x; a.head_a = (const u16*)d->head_a; a.head_w = (const u16*)d->head_w; a.head_b = d->head_b; a.head_res = d->head_res;
+    a.dw_w = d->dw_w; a.dw_b = d->dw_b; a.dw_scale = d->dw_scale; a.dw_shift = d->dw_shift; a.dw_T = d->dw_T;
     a.head_mask = d->head_mask; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_mask = d->ln_mask; a.w1f = (const u16*)d->w1f; a.w2n = (const u16*)d->w2n;
     a.b1 = d->b1; a.b2 = d->b2; a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32;
     a.out16 = d->out16; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M;
@@ -620,23 +719,27 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     const double M = (double)d->M;
     const double fl_head = head ? 2.0 * M * d->D * d->D : 0.0, fl_mid = mid ? 4.0 * M * d->D * d->FF : 0.0,
                  fl_tail = tail ? 2.0 * M * d->D * d->tail_N : 0.0;
-    const double fl = fl_head + fl_mid + fl_tail;
-#define CFM_RC(HT, DD, FFV, HS, MIDV, TS, GLU, NAME) return launch_chain<HT, DD, FFV, HS, MIDV, TS, GLU>(a, s, NAME, fl)
+    const double fl = fl_head + fl_mid + fl_tail + (dw ? 2.0 * M * d->D * 15 : 0.0);
+#define CFM_RC(HT, DD, FFV, HS, MIDV, TS, GLU, NAME) return launch_chain<HT, DD, FFV, HS, false, MIDV, TS, GLU>(a, s, NAME, fl)
+#define CFM_RCDW(HT, DD, FFV, NAME) return launch_chain<HT, DD, FFV, 1, true, true, 0, false>(a, s, NAME, fl)
     // the three roles of a conformer block (+ a bare QKV projection and a bare LayerNorm), for D = 256 (ff 2048) and D = 144 (ff 576)
     if (d->D == 256 && (!mid || d->FF == 2048)) {
         if (!head && mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 2048, 0, true, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 2048, 0, true, 3, false, "chain_macaron_f16_d256"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 1) { if (bf) CFM_RC(BF16, 256, 64, 1, false, 1, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 64, 1, false, 1, true, "chain_convin_f16_d256"); }
+        if (head && mid && !tail && dw) { if (bf) CFM_RCDW(BF16, 256, 2048, "chain_dwfinal_bf16_d256"); else CFM_RCDW(F16, 256, 2048, "chain_dwfinal_f16_d256"); }
         if (head && mid && !tail) { if (bf) CFM_RC(BF16, 256, 2048, 1, true, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 2048, 1, true, 0, false, "chain_final_f16_d256"); }
         if (!head && !mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 64, 0, false, 3, false, "chain_qkv_bf16_d256"); else CFM_RC(F16, 256, 64, 0, false, 3, false, "chain_qkv_f16_d256"); }
         if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 256, 64, 0, false, 0, false, "chain_rows_bf16_d256"); else CFM_RC(F16, 256, 64, 0, false, 0, false, "chain_rows_f16_d256"); }
     } else if (d->D == 144 && (!mid || d->FF == 576)) {
         if (!head && mid && tail && !d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 144, 576, 0, true, 2, false, "chain_macaron_bf16_d144"); else CFM_RC(F16, 144, 576, 0, true, 2, false, "chain_macaron_f16_d144"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 1) { if (bf) CFM_RC(BF16, 144, 64, 1, false, 1, true, "chain_convin_bf16_d144"); else CFM_RC(F16, 144, 64, 1, false, 1, true, "chain_convin_f16_d144"); }
+        if (head && mid && !tail && dw) { if (bf) CFM_RCDW(BF16, 144, 576, "chain_dwfinal_bf16_d144"); else CFM_RCDW(F16, 144, 576, "chain_dwfinal_f16_d144"); }
         if (head && mid && !tail) { if (bf) CFM_RC(BF16, 144, 576, 1, true, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 576, 1, true, 0, false, "chain_final_f16_d144"); }
         if (!head && !mid && tail && !d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 2, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 2, false, "chain_qkv_f16_d144"); }
         if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 0, false, "chain_rows_f16_d144"); }
     }
 #undef CFM_RC
+#undef CFM_RCDW
     return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: no instance for D=%d FF=%d tail_N=%d head=%d mid=%d tail=%d glu=%d", d->D, d->FF,
                     d->tail_N, (int)head, (int)mid, (int)tail, d->tail_glu);
 }

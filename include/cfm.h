@@ -160,6 +160,11 @@ typedef struct {
     int32_t D, FF, tail_N, tail_glu;
     int32_t w_dtype;
     float alpha, eps, palpha;
+    /* optional depthwise input stage of the "final" chain (head + feed-forward, no tail): head_a is the GLU output and
+     *   a = SiLU( (DepthwiseConv15(head_a) + dw_b) * dw_scale + dw_shift )      rows [B, dw_T] flattened, zero padding at
+     * utterance edges -- exactly cfm_dwconv_bn_silu (convolution.py:43-45) without its launch and its round trip. */
+    const float *dw_w, *dw_b, *dw_scale, *dw_shift;
+    int32_t dw_T, dw_K;
 } cfm_rowchain_desc;
 
 int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);

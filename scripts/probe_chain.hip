@@ -56,9 +56,16 @@ static void run(const char* name, cfm_rowchain_desc d, int M) {
         tot += sum / nb;
         (void)last;
     }
-    long long t_first = h[0], t_last = h[7];
-    for (int b = 0; b < nb; ++b) { t_first = h[b * 16] < t_first ? h[b * 16] : t_first; t_last = h[b * 16 + 7] > t_last ? h[b * 16 + 7] : t_last; }
-    printf("    in-kernel total %9.0f cycles mean;  first start -> last end %lld cycles\n", tot, t_last - t_first);
+    long long w_first = h[8], w_last = h[9], w_lastst = h[8];
+    double wsum = 0;
+    for (int b = 0; b < nb; ++b) {
+        w_first = h[b * 16 + 8] < w_first ? h[b * 16 + 8] : w_first;
+        w_lastst = h[b * 16 + 8] > w_lastst ? h[b * 16 + 8] : w_lastst;
+        w_last = h[b * 16 + 9] > w_last ? h[b * 16 + 9] : w_last;
+        wsum += (double)(h[b * 16 + 9] - h[b * 16 + 8]);
+    }
+    printf("    in-kernel total %9.0f cycles mean = %.2f us mean by the 100 MHz wall clock (=> %.2f GHz);  first start -> last start %.2f us, -> last end %.2f us\n",
+           tot, wsum / nb / 100.0, tot / (wsum / nb * 10.0), (w_lastst - w_first) / 100.0, (w_last - w_first) / 100.0);
 }
 
 int main() {
@@ -90,6 +97,10 @@ int main() {
     fin.head_a = a16; fin.head_w = wh; fin.head_b = vec; fin.head_res = res; fin.head_mask = mask; fin.ln_g = vec; fin.ln_b = vec;
     fin.w1f = w1f; fin.w2n = w2f; fin.b1 = vec; fin.b2 = vec; fin.ln1_g = vec; fin.ln1_b = vec; fin.out_f32 = out; fin.D = D; fin.FF = FF;
     fin.w_dtype = CFM_BF16; fin.alpha = 0.5f; fin.eps = 1e-5f;
+
+    cfm_rowchain_desc fdw = fin;                           // final with the depthwise conv + BatchNorm + SiLU in its input stage
+    fdw.dw_w = vec; fdw.dw_b = vec; fdw.dw_scale = vec; fdw.dw_shift = vec; fdw.dw_T = 249; fdw.dw_K = 15;
+    run("dw-final", fdw, 7968);
 
     for (int M : {32, 7968}) {
         run("macaron", mac, M);

@@ -412,6 +412,42 @@ def test_rowchain_three_roles(cfm, M, D, FF, wdt):
     assert torch.equal(xi, xj)          # bitwise reproducible
 
 
+@pytest.mark.parametrize("B,T,D,FF", [(32, 249, 256, 2048), (3, 41, 144, 576), (2, 5, 256, 2048), (5, 32, 256, 2048)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+def test_rowchain_depthwise_input_stage(cfm, B, T, D, FF, wdt):
+    """final chain with the depthwise conv + BatchNorm + SiLU (convolution.py:43-45) in its input stage == cfm_dwconv_bn_silu, then the
+    plain final chain: same fp32 operation order (bit-identical in bf16), including frames next to utterance edges and a ragged last tile."""
+    from cfm import packing
+    dt = torch.bfloat16 if wdt == "bf16" else torch.float16
+    code = cfm.BF16 if wdt == "bf16" else cfm.F16
+    M = B * T
+    x = rnd((M, D), 200, 1.2)
+    glu = rnd((B, T, D), 201).to(dt)
+    w1, w2 = rnd((FF, D), 202, D ** -0.5), rnd((D, FF), 203, FF ** -0.5)
+    b1, b2 = rnd((FF,), 204, 0.1), rnd((D,), 205, 0.1)
+    wh, bh = rnd((D, D), 206, D ** -0.5), rnd((D,), 207, 0.1)
+    taps, tb = rnd((D, 15), 208, 0.3), rnd((D,), 209, 0.1)
+    sc, sh = 1 + 0.2 * rnd((D,), 210), 0.1 * rnd((D,), 211)
+    lns = [(1 + 0.1 * rnd((D,), 212 + i), 0.1 * rnd((D,), 216 + i)) for i in range(2)]
+    mask = (torch.rand(M, device="cuda") > 0.2).to(torch.uint8)
+    w1f, w2n, whf = packing.pack_frag_major(w1, dt), packing.pack_frag_major(w2, dt), packing.pack_frag_major(wh, dt)
+    dwo = cfm.dwconv_bn_silu(glu, taps, tb, sc, sh, out_dtype=dt)
+    ref = x.clone()
+    cfm.rowchain(M, D, code, head=(dwo.view(M, D), whf, bh, ref, mask), ln=lns[0], ffn=(w1f, w2n, b1, b2, FF), alpha=0.5, ln1=lns[1], out_f32=ref)
+    out = x.clone()
+    cfm.rowchain(M, D, code, head=(glu.view(M, D), whf, bh, out, mask), ln=lns[0], ffn=(w1f, w2n, b1, b2, FF), alpha=0.5, ln1=lns[1], out_f32=out,
+                 dw=(taps, tb, sc, sh, T))
+    assert torch.isfinite(out).all()
+    if wdt == "bf16":
+        assert torch.equal(out, ref)
+    else:
+        # fp16: the fused kernel's compiler folds SiLU's last multiply into the f32->f16 conversion (v_fma_mixlo_f16, ONE rounding)
+        # where the stand-alone kernel rounds the product to f32 first: a handful of conv outputs differ by one f16 ulp.
+        assert relerr(out, ref) < 1e-3 and (out - ref).abs().max().item() < 2e-3 and (out != ref).float().mean().item() < 0.05
+    with pytest.raises(RuntimeError):     # the stage belongs to the head + feed-forward chain only
+        cfm.rowchain(M, D, code, x=x, ln=lns[0], out_f32=out, dw=(taps, tb, sc, sh, T))
+
+
 @pytest.mark.parametrize("M,D,FF", [(7968, 256, 2048), (98, 144, 576), (65, 256, 2048)])
 @pytest.mark.parametrize("wdt", ["bf16", "fp16"])
 def test_ffn_partial_and_reduce(cfm, M, D, FF, wdt):
