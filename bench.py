@@ -12,7 +12,8 @@ timed region and the MAX-over-ranks of the elapsed time.  Rank 0 prints ONE JSON
 
 Besides the headline value the line carries
   roofline      the dominant kernel (largest share of device time) from a second, instrumented pass over the same
-                K steps: every launch bracketed by HIP events on its own stream (cfm_prof_*), algorithmic FLOPs per launch
+                K steps: every launch carries HIP start/stop events on its own stream (cfm_prof_*: the events are attached to the
+                dispatch, so they read the kernel's own begin/end like rocprofv3 does), algorithmic FLOPs per launch
                 / average launch duration, against the dense bf16 MFMA peak (2.5 PFLOP/s);
   cpu_baseline  the CPU oracle (a port of the reference's PyTorch CPU path, oracle/conformer_oracle.py) timed on the host
                 cores of the same box on a bounded sample of the same workload (rank 0, N=1 only).
@@ -117,7 +118,7 @@ def selftest_cpu(args):
         dist.destroy_process_group()
 
 
-KERNEL_SYMBOL = {"chain_macaron": "cfm_rowchain_kernel", "chain_final": "cfm_rowchain_kernel", "chain_convin": "cfm_rowchain_kernel",
+KERNEL_SYMBOL = {"chain_macaron": "cfm_rowchain_kernel", "chain_dwfinal": "cfm_rowchain_kernel", "chain_final": "cfm_rowchain_kernel", "chain_convin": "cfm_rowchain_kernel",
                  "chain_qkv": "cfm_rowchain_kernel", "ffn_fused": "cfm_ffn_kernel", "ffn_partial": "cfm_ffnpart_kernel",
                  "gemm_conv": "cfm_gemm_kernel", "gemm": "cfm_gemm_kernel", "attn2": "cfm_attn2_kernel", "attn": "cfm_attn_kernel"}
 
@@ -130,7 +131,9 @@ def measured_traffic(kernel_name, d_model):
     if not files:
         return None
     kernels = json.load(open(files[-1]))["kernels"]
-    role = {"chain_macaron": "0, 16, 6, false", "chain_final": "2, 16, 0, false", "chain_convin": "2, 0, 4, true"}
+    # template arguments after <type, D, FF,: head steps, depthwise input stage, feed-forward, tail steps, GLU
+    role = {"chain_macaron": "0, false, true, 3, false", "chain_dwfinal": "1, true, true, 0, false", "chain_final": "1, false, true, 0, false",
+            "chain_convin": "1, false, false, 1, true"}
     for prefix, sym in KERNEL_SYMBOL.items():
         if kernel_name.startswith(prefix):
             want = role.get(prefix)
@@ -231,7 +234,7 @@ def main():
         mfma = {k: e for k, e in table.items() if e["flops"] > 0 and k.split("_")[0] in ("gemm", "attn", "attn2", "ffn", "chain")}
         if mfma:
             name, e = max(mfma.items(), key=lambda kv: kv[1]["ms"])
-            avg_ms = e["ms"] / e["calls"]
+            avg_ms = e["ms"] / e["calls"]               # dispatch begin -> end (events attached to the launch: CFM_LAUNCH)
             achieved = e["flops"] / e["calls"] / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.precision]
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -62,23 +63,22 @@ std::map<std::string, Agg> g_agg;
 std::vector<std::pair<std::string, Agg>> g_sorted;
 }  // namespace
 
-CfmProfScope::CfmProfScope(const char* name, hipStream_t s, double flops, double bytes) : rec(nullptr), stream(s) {
+CfmProfScope::CfmProfScope(const char* name, hipStream_t s, double flops, double bytes) : rec(nullptr), stream(s), ev_start(nullptr), ev_stop(nullptr) {
     if (!g_on) return;
     Rec* r = new Rec{name, nullptr, nullptr, flops, bytes};
     if (hipEventCreate(&r->start) != hipSuccess || hipEventCreate(&r->stop) != hipSuccess) {
         delete r;
         return;
     }
-    (void)hipEventRecord(r->start, s);
+    ev_start = r->start;                                   // stamped by the dispatch (CFM_LAUNCH), not recorded here
+    ev_stop = r->stop;
     rec = r;
 }
 
 CfmProfScope::~CfmProfScope() {
     if (!rec) return;
-    Rec* r = (Rec*)rec;
-    (void)hipEventRecord(r->stop, stream);
     std::lock_guard<std::mutex> lk(g_mu);
-    g_recs.push_back(r);
+    g_recs.push_back((Rec*)rec);
 }
 
 extern "C" void cfm_prof_enable(int on) {

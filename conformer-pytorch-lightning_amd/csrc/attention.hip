@@ -484,8 +484,8 @@ int launch_attn2(const AttnArgs& a, hipStream_t s, const char* name) {
     const bool mfull = a.mask && a.m_sq != 0;
 #define CFM_A2(PM)                                                                                       \
     do {                                                                                                 \
-        if (mfull) hipLaunchKernelGGL((cfm_attn2_kernel<HT, PM, true>), grid, block, 0, s, a);            \
-        else hipLaunchKernelGGL((cfm_attn2_kernel<HT, PM, false>), grid, block, 0, s, a);                 \
+        if (mfull) CFM_LAUNCH((cfm_attn2_kernel<HT, PM, true>), grid, block, 0, s, a);            \
+        else CFM_LAUNCH((cfm_attn2_kernel<HT, PM, false>), grid, block, 0, s, a);                 \
     } while (0)
     if (pmode == 0) CFM_A2(0);
     else if (pmode == 1) CFM_A2(1);
@@ -525,9 +525,9 @@ int launch_attn(const AttnArgs& a, bool has_pos, hipStream_t s, const char* name
     const double bytes = 2.0 * a.B * a.H * ((double)a.Tq * 2 + (double)a.Tk * 2) * a.dk;
     CfmProfScope prof(name, s, flops, bytes);
     if (has_pos)
-        hipLaunchKernelGGL((cfm_attn_kernel<HT, true, SPLIT>), grid, block, 0, s, a);
+        CFM_LAUNCH((cfm_attn_kernel<HT, true, SPLIT>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((cfm_attn_kernel<HT, false, SPLIT>), grid, block, 0, s, a);
+        CFM_LAUNCH((cfm_attn_kernel<HT, false, SPLIT>), grid, block, 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -574,7 +574,7 @@ extern "C" int cfm_kv_cache_pack(const float* old_cache, int32_t Tc, const void*
     const int64_t n = (int64_t)B * H * (Tc + Tn) * 2 * dk;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     CfmProfScope prof("kv_cache_pack", s, 0.0, (double)n * 8);
-    hipLaunchKernelGGL(cfm_kv_pack_kernel, dim3(blocks), dim3(256), 0, s, old_cache, Tc, k, v, kv_dtype, k_sb, k_st, v_sb, v_st,
+    CFM_LAUNCH(cfm_kv_pack_kernel, dim3(blocks), dim3(256), 0, s, old_cache, Tc, k, v, kv_dtype, k_sb, k_st, v_sb, v_st,
                        new_cache, B, H, Tn, dk);
     return cfm_launch_status("cfm_kv_cache_pack");
 }

@@ -284,7 +284,7 @@ extern "C" int cfm_add_rows(float* x, const float* add, int64_t rows, int32_t D,
     int64_t nb = (n4 + 255) / 256;
     if (nb > 2048) nb = 2048;
     CfmProfScope prof("add_rows", s, 0.0, (double)rows * D * 8);
-    hipLaunchKernelGGL(cfm_add_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, add, n4, D / 4, group);
+    CFM_LAUNCH(cfm_add_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, add, n4, D / 4, group);
     return cfm_launch_status("cfm_add_rows");
 }
 
@@ -300,20 +300,20 @@ extern "C" int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, co
     if (ktaps == 15 && D % 8 == 0 && D >= 64 && D <= 512) {
         const dim3 grid((unsigned)((T + DW_TS - 1) / DW_TS), B), block(256);
         const size_t lds = (size_t)(DW_TS + 14 + DW_TS) * D * sizeof(float);
-        hipLaunchKernelGGL((cfm_dwconv_tiled_kernel<15>), grid, block, lds, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype, y_dtype, T, D);
+        CFM_LAUNCH((cfm_dwconv_tiled_kernel<15>), grid, block, lds, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype, y_dtype, T, D);
     } else if (ktaps == 15) {
         const int segs = (T + TSEG - 1) / TSEG;
         const dim3 grid((unsigned)(((int64_t)segs * (D / 2) + 255) / 256), B), block(256);
         if (x_dtype == CFM_F32)
-            hipLaunchKernelGGL((cfm_dwconv_kernel<15, true>), grid, block, 0, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype,
+            CFM_LAUNCH((cfm_dwconv_kernel<15, true>), grid, block, 0, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype,
                                y_dtype, T, D);
         else
-            hipLaunchKernelGGL((cfm_dwconv_kernel<15, false>), grid, block, 0, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype,
+            CFM_LAUNCH((cfm_dwconv_kernel<15, false>), grid, block, 0, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype,
                                y_dtype, T, D);
     } else {
         int64_t nb = ((int64_t)T * D + 255) / 256;
         if (nb > 1024) nb = 1024;
-        hipLaunchKernelGGL(cfm_dwconv_generic_kernel, dim3((unsigned)nb, B), dim3(256), 0, s, x, w, dw_bias, bn_scale, bn_shift, y,
+        CFM_LAUNCH(cfm_dwconv_generic_kernel, dim3((unsigned)nb, B), dim3(256), 0, s, x, w, dw_bias, bn_scale, bn_shift, y,
                            x_dtype, y_dtype, T, D, ktaps);
     }
     return cfm_launch_status("cfm_dwconv_bn_silu");
@@ -334,9 +334,9 @@ extern "C" int cfm_conv1_relu(const float* x, const float* w, const float* bias,
     CfmProfScope prof("conv1_relu", s, 2.0 * 9 * (double)total * 8, bytes);
     const dim3 grid((unsigned)nblocks), block((unsigned)(slots * (C / 8)));
     if (y_dtype == CFM_F32)
-        hipLaunchKernelGGL((cfm_conv1_kernel<true>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
+        CFM_LAUNCH((cfm_conv1_kernel<true>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
     else
-        hipLaunchKernelGGL((cfm_conv1_kernel<false>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
+        CFM_LAUNCH((cfm_conv1_kernel<false>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
     return cfm_launch_status("cfm_conv1_relu");
 }
 
@@ -346,6 +346,6 @@ extern "C" int cfm_cast(const void* src, int src_dtype, void* dst, int dst_dtype
     int64_t nb = (n + 255) / 256;
     if (nb > 2048) nb = 2048;
     CfmProfScope prof("cast", s, 0.0, (double)n * (cfm_elt_size(src_dtype) + cfm_elt_size(dst_dtype)));
-    hipLaunchKernelGGL(cfm_cast_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, src_dtype, dst, dst_dtype, n);
+    CFM_LAUNCH(cfm_cast_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, src_dtype, dst, dst_dtype, n);
     return cfm_launch_status("cfm_cast");
 }

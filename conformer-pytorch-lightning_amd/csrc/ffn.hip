@@ -308,8 +308,8 @@ int launch_ffn(const FfnArgs& a, hipStream_t s, const char* name) {
     const bool silu = a.act == CFM_ACT_SILU;
 #define CFM_FFN_LAUNCH(NS)                                                                                      \
     do {                                                                                                        \
-        if (silu) hipLaunchKernelGGL((cfm_ffn_kernel<HT, D, NS, CFM_ACT_SILU>), dim3(grid), dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((cfm_ffn_kernel<HT, D, NS, CFM_ACT_RELU>), dim3(grid), dim3(256), 0, s, a);      \
+        if (silu) CFM_LAUNCH((cfm_ffn_kernel<HT, D, NS, CFM_ACT_SILU>), dim3(grid), dim3(256), 0, s, a); \
+        else CFM_LAUNCH((cfm_ffn_kernel<HT, D, NS, CFM_ACT_RELU>), dim3(grid), dim3(256), 0, s, a);      \
     } while (0)
     // instances exist for 4, 5, 8 and 16 steps per wavefront; other counts run the next larger one (extra steps masked)
     if (steps <= 4) CFM_FFN_LAUNCH(4);

@@ -322,9 +322,9 @@ int launch_part(const PartArgs& a, int inmode, hipStream_t s, const char* name) 
     const unsigned grid = 2u * (unsigned)((a.M + PBM - 1) / PBM);
     const double flops = 4.0 * (double)a.M * D * a.FF + (inmode == 2 ? 2.0 * (double)a.M * D * D : 0.0);
     CfmProfScope prof(name, s, flops, (double)a.M * D * 16);
-    if (inmode == 0) hipLaunchKernelGGL((cfm_ffnpart_kernel<HT, D, NS, 0>), dim3(grid), dim3(PNW * 64), 0, s, a);
-    else if (inmode == 1) hipLaunchKernelGGL((cfm_ffnpart_kernel<HT, D, NS, 1>), dim3(grid), dim3(PNW * 64), 0, s, a);
-    else hipLaunchKernelGGL((cfm_ffnpart_kernel<HT, D, NS, 2>), dim3(grid), dim3(PNW * 64), 0, s, a);
+    if (inmode == 0) CFM_LAUNCH((cfm_ffnpart_kernel<HT, D, NS, 0>), dim3(grid), dim3(PNW * 64), 0, s, a);
+    else if (inmode == 1) CFM_LAUNCH((cfm_ffnpart_kernel<HT, D, NS, 1>), dim3(grid), dim3(PNW * 64), 0, s, a);
+    else CFM_LAUNCH((cfm_ffnpart_kernel<HT, D, NS, 2>), dim3(grid), dim3(PNW * 64), 0, s, a);
     return cfm_launch_status(name);
 }
 

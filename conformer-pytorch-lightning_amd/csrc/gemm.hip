@@ -307,7 +307,7 @@ int launch(const GemmArgs& a, hipStream_t s, const char* name) {
     const double bytes = (double)a.M * a.K * (A_F32 ? 4 : 2) + (double)a.N * a.K * 2 * (SPLIT ? 2 : 1) +
                          (double)a.M * a.N * (a.c_dtype == CFM_F32 ? 4 : 2);
     CfmProfScope prof(nm.c_str(), s, flops, bytes);
-    hipLaunchKernelGGL((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV>), dim3(tiles), dim3(256), 0, s, a);
+    CFM_LAUNCH((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV>), dim3(tiles), dim3(256), 0, s, a);
     return cfm_launch_status(nm.c_str());
 }
 

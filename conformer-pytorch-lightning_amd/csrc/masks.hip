@@ -57,7 +57,7 @@ extern "C" int cfm_valid_mask(const void* lengths, int len_is_i64, uint8_t* out,
     CFM_CHECK_ARG(lengths && out && B > 0 && T > 0 && stride > 0 && first >= 0, "cfm_valid_mask: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     CfmProfScope prof("valid_mask", s, 0.0, (double)B * T);
-    hipLaunchKernelGGL(cfm_valid_mask_kernel, dim3(blocks_for((int64_t)B * T)), dim3(256), 0, s, lengths, len_is_i64, out, B, T,
+    CFM_LAUNCH(cfm_valid_mask_kernel, dim3(blocks_for((int64_t)B * T)), dim3(256), 0, s, lengths, len_is_i64, out, B, T,
                        first, stride);
     return cfm_launch_status("cfm_valid_mask");
 }
@@ -66,7 +66,7 @@ extern "C" int cfm_chunk_mask(uint8_t* out, int32_t size, int32_t chunk, int32_t
     CFM_CHECK_ARG(out && size > 0 && chunk > 0, "cfm_chunk_mask: bad arguments (size=%d chunk=%d)", size, chunk);
     hipStream_t s = (hipStream_t)stream;
     CfmProfScope prof("chunk_mask", s, 0.0, (double)size * size);
-    hipLaunchKernelGGL(cfm_chunk_mask_kernel, dim3(blocks_for((int64_t)size * size)), dim3(256), 0, s, out, size, chunk, left);
+    CFM_LAUNCH(cfm_chunk_mask_kernel, dim3(blocks_for((int64_t)size * size)), dim3(256), 0, s, out, size, chunk, left);
     return cfm_launch_status("cfm_chunk_mask");
 }
 
@@ -75,6 +75,6 @@ extern "C" int cfm_attn_mask(const uint8_t* valid, const uint8_t* chunk, uint8_t
     CFM_CHECK_ARG(valid && chunk && out && B > 0 && T > 0, "cfm_attn_mask: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     CfmProfScope prof("attn_mask", s, 0.0, (double)B * T * T + (double)T * T + (double)B * T);
-    hipLaunchKernelGGL(cfm_attn_mask_kernel, dim3(blocks_for((int64_t)B * T * T)), dim3(256), 0, s, valid, chunk, out, B, T);
+    CFM_LAUNCH(cfm_attn_mask_kernel, dim3(blocks_for((int64_t)B * T * T)), dim3(256), 0, s, valid, chunk, out, B, T);
     return cfm_launch_status("cfm_attn_mask");
 }

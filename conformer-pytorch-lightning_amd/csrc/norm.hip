@@ -96,7 +96,7 @@ extern "C" int cfm_layernorm(const float* x, const float* g1, const float* b1, v
     const double bytes = (double)M * D * (4.0 + (out1 ? cfm_elt_size(out1_dtype) : 0) + (out2 ? cfm_elt_size(out2_dtype) : 0));
     CfmProfScope prof("layernorm", s, 0.0, bytes);
 #define CFM_LN_LAUNCH(IT)                                                                                                \
-    hipLaunchKernelGGL((cfm_layernorm_kernel<IT>), grid, block, 0, s, x, g1, b1, out1, out1_dtype, g2, b2, out2, out2_dtype, \
+    CFM_LAUNCH((cfm_layernorm_kernel<IT>), grid, block, 0, s, x, g1, b1, out1, out1_dtype, g2, b2, out2, out2_dtype, \
                        row_mask, eps, M, D)
     if (D <= 256)
         CFM_LN_LAUNCH(1);

@@ -682,7 +682,7 @@ template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool T
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
     const unsigned grid = (unsigned)((a.M + RBM - 1) / RBM);
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    hipLaunchKernelGGL((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU>), dim3(grid), dim3(NT), 0, s, a);
+    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU>), dim3(grid), dim3(NT), 0, s, a);
     return cfm_launch_status(name);
 }
 
