@@ -271,22 +271,34 @@ __global__ __launch_bounds__(256) void cfm_attn_kernel(const AttnArgs a) {
 // =============================================================================================
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Phase stamps for scripts/probe_attn.hip (built with -DCFM_ATTN_STAMPS; never defined in the product build).
+#ifdef CFM_ATTN_STAMPS
+__device__ long long cfm_attn_stamps[2048 * 8];
+#define CFM_ASTAMP(i) do { if (threadIdx.x == 0) { const int bid_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+        if (bid_ < 2048) cfm_attn_stamps[bid_ * 8 + (i)] = (i) >= 6 ? wall_clock64() : clock64(); } } while (0)
+#else
+#define CFM_ASTAMP(i) do { } while (0)
+#endif
+
 constexpr int SK = 256;        // keys resident per super-tile
 constexpr int V2STR = 72;      // V row stride in 16-bit elements (144 B)
 constexpr int MLSTR = SK + 4;  // mask row stride in bytes
 
-template <typename HT>
-__device__ __forceinline__ u32x4 load_row8(const void* base, int dt, int64_t off) {  // 8 consecutive elements -> 16-bit x8
-    if (dt == CFM_F32) {
+// 8 consecutive elements -> 16-bit x8.  The element type is a template argument: a run-time branch around each load makes the
+// compiler wait at every join, which serialised the 16 K/V loads of a thread (6 k cycles to ISSUE them, measured).
+template <typename HT, bool F32>
+__device__ __forceinline__ u32x4 load_row8(const void* base, int64_t off) {
+    if constexpr (F32) {
         const f32x4 a = *(const f32x4*)((const float*)base + off);
         const f32x4 b = *(const f32x4*)((const float*)base + off + 4);
         return pack8<HT>(a, b);
+    } else {
+        return *(const u32x4*)((const u16*)base + off);
     }
-    return *(const u32x4*)((const u16*)base + off);
 }
 
-template <typename HT, int PMODE, bool MFULL>
-__global__ __launch_bounds__(256) void cfm_attn2_kernel(const AttnArgs a) {
+template <typename HT, int PMODE, bool MFULL, bool KVF32>
+__global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {   // 2 wavefronts per SIMD: two workgroups share a CU
     __shared__ u32x4 Kl[SK * 8];
     __shared__ u32x4 Pl[PMODE == 2 ? SK * 8 : 1];
     __shared__ __attribute__((aligned(16))) u16 Vl[SK * V2STR];
@@ -300,14 +312,51 @@ __global__ __launch_bounds__(256) void cfm_attn2_kernel(const AttnArgs a) {
     const int qi = q0 + wave * 16 + l15;
     const int qc = qi < a.Tq ? qi : a.Tq - 1;
     constexpr int dk = 64;
+    CFM_ASTAMP(0);
+    CFM_ASTAMP(6);
+
+    // ---- every global request of the first super-tile goes out before anything is computed: Q, biases, the positional
+    //      row, up to 256 keys of K and V (and P), the mask bytes ------------------------------------------------------
+    u32x4 qraw[2], praw[2];
+    f32x4 bu[2][2], bv[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int d0 = kk * 32 + g * 8;
+        qraw[kk] = *(const u32x4*)((const u16*)a.q + (int64_t)b * a.q_sb + (int64_t)qc * a.q_st + h * dk + d0);
+        if constexpr (PMODE != 0) {
+            bu[kk][0] = *(const f32x4*)(a.bias_u + h * dk + d0); bu[kk][1] = *(const f32x4*)(a.bias_u + h * dk + d0 + 4);
+            bv[kk][0] = *(const f32x4*)(a.bias_v + h * dk + d0); bv[kk][1] = *(const f32x4*)(a.bias_v + h * dk + d0 + 4);
+        }
+        if constexpr (PMODE == 1) praw[kk] = *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + h * dk + d0);
+    }
+    u32x4 kr[8], vr[8], pr[PMODE == 2 ? 8 : 1];
+    auto stage_load = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = i * 256 + tid;
+            const int key = id >> 3, c = id & 7;
+            const int kj = ks + key;
+            const bool ok = kj < a.Tk;
+            const int64_t kc = ok ? kj : 0;
+            kr[i] = load_row8<HT, KVF32>(a.k, (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + kc * a.k_st + c * 8);
+            vr[i] = load_row8<HT, KVF32>(a.v, (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + kc * a.v_st + c * 8);
+            if constexpr (PMODE == 2) pr[i] = *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + kc * a.p_st + h * dk + c * 8);
+            if (!ok) {                                     // keys past Tk: clamped address, zeroed value (no branch around the load)
+                kr[i] = (u32x4){0u, 0u, 0u, 0u};
+                vr[i] = (u32x4){0u, 0u, 0u, 0u};
+                if constexpr (PMODE == 2) pr[i] = (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    stage_load(0);
+    CFM_ASTAMP(1);
 
     // ---- Q~ fragments: q + u (and q + v) rounded to the MFMA operand type ----------------------------------------
     u32x4 qu[2], qv[2];
     float bd = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        const int d0 = kk * 32 + g * 8;
-        const u32x4 raw = *(const u32x4*)((const u16*)a.q + (int64_t)b * a.q_sb + (int64_t)qc * a.q_st + h * dk + d0);
+        const u32x4 raw = qraw[kk];
         const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
         float f[8];
 #pragma unroll
@@ -318,14 +367,11 @@ __global__ __launch_bounds__(256) void cfm_attn2_kernel(const AttnArgs a) {
         if constexpr (PMODE == 0) {
             qu[kk] = raw;
         } else {
-            const f32x4 u0 = *(const f32x4*)(a.bias_u + h * dk + d0), u1 = *(const f32x4*)(a.bias_u + h * dk + d0 + 4);
-            const f32x4 v0 = *(const f32x4*)(a.bias_v + h * dk + d0), v1 = *(const f32x4*)(a.bias_v + h * dk + d0 + 4);
             const f32x4 fa = {f[0], f[1], f[2], f[3]}, fb = {f[4], f[5], f[6], f[7]};
-            qu[kk] = pack8<HT>(fa + u0, fb + u1);
-            qv[kk] = pack8<HT>(fa + v0, fb + v1);
+            qu[kk] = pack8<HT>(fa + bu[kk][0], fb + bu[kk][1]);
+            qv[kk] = pack8<HT>(fa + bv[kk][0], fb + bv[kk][1]);
             if constexpr (PMODE == 1) {   // bd_i = (q_i + v) . p_b : the lane's 8 d-values of this kk
-                const u32x4 pr = *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + h * dk + d0);
-                const unsigned pw[4] = {pr.x, pr.y, pr.z, pr.w}, qw[4] = {qv[kk].x, qv[kk].y, qv[kk].z, qv[kk].w};
+                const unsigned pw[4] = {praw[kk].x, praw[kk].y, praw[kk].z, praw[kk].w}, qw[4] = {qv[kk].x, qv[kk].y, qv[kk].z, qv[kk].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     bd = fmaf(HT::to_f32((u16)(qw[i] & 0xffffu)), HT::to_f32((u16)(pw[i] & 0xffffu)), bd);
@@ -345,22 +391,12 @@ __global__ __launch_bounds__(256) void cfm_attn2_kernel(const AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     for (int ks = 0; ks < a.Tk; ks += SK) {
-        if (ks) __syncthreads();  // everyone is done with the previous super-tile
-        // ---- stage up to 256 keys: 16-byte copies, all loads issued before the first LDS write -------------------
+        if (ks) {
+            __syncthreads();  // everyone is done with the previous super-tile
+            stage_load(ks);
+        }
+        // ---- stage up to 256 keys: the requests above, now the LDS writes ------------------------------------------
         {
-            u32x4 kr[8], vr[8], pr[PMODE == 2 ? 8 : 1];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int id = i * 256 + tid;
-                const int key = id >> 3, c = id & 7;
-                const int kj = ks + key;
-                const bool ok = kj < a.Tk;
-                const int64_t kc = ok ? kj : 0;
-                kr[i] = ok ? load_row8<HT>(a.k, a.kv_dtype, (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + kc * a.k_st + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-                vr[i] = ok ? load_row8<HT>(a.v, a.kv_dtype, (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + kc * a.v_st + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-                if constexpr (PMODE == 2)
-                    pr[i] = ok ? *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + kc * a.p_st + h * dk + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-            }
             // mask bytes: a validity row (no mask / broadcast mask) or 64 query rows
             if constexpr (!MFULL) {
                 const int kj = ks + tid;
@@ -385,76 +421,73 @@ __global__ __launch_bounds__(256) void cfm_attn2_kernel(const AttnArgs a) {
             }
         }
         __syncthreads();
+        CFM_ASTAMP(2);
 
-        const int ntile = (min(a.Tk - ks, SK) + KT - 1) / KT;
-        for (int t = 0; t < ntile; ++t) {
-            // ---- S^T tile ----------------------------------------------------------------------------------
-            f32x4 s[4];
+        // ---- S^T for all four 64-key tiles of the super-tile, ONE softmax pass over its 256 keys, then O^T += V^T . P^T.
+        //      (Per 64-key tile the chain K read -> MFMA -> max -> shuffles -> exp -> pack -> MFMA is serial: 2.3 k cycles a
+        //      tile; in bulk the 32 + 32 MFMAs and the 64 exponentials each run back to back.)  Keys past Tk are zero rows
+        //      with mask byte 0, so short super-tiles go through the same code.
+        f32x4 s[16];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < 16; ++f) {
+            s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int idx = k_swz(t * 64 + f * 16 + l15, kk * 4 + g);
-                    s[f] = HT::mfma(Kl[idx], qu[kk], s[f]);
-                    if constexpr (PMODE == 2) s[f] = HT::mfma(Pl[idx], qv[kk], s[f]);
-                }
+            for (int kk = 0; kk < 2; ++kk) {
+                const int idx = k_swz(f * 16 + l15, kk * 4 + g);
+                s[f] = HT::mfma(Kl[idx], qu[kk], s[f]);
+                if constexpr (PMODE == 2) s[f] = HT::mfma(Pl[idx], qv[kk], s[f]);
             }
-            // ---- scale, mask, online softmax ---------------------------------------------------------------------
-            float tmax = -INFINITY;
-            float sv[4][4];
-            const uint8_t* mrow = Ml + (MFULL ? (wave * 16 + l15) * MLSTR : 0) + t * 64 + 4 * g;
+        }
+        float tmax = -INFINITY;
+        const uint8_t* mrow = Ml + (MFULL ? (wave * 16 + l15) * MLSTR : 0) + 4 * g;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const unsigned mb = *(const unsigned*)(mrow + f * 16);
+        for (int f = 0; f < 16; ++f) {
+            const unsigned mb = *(const unsigned*)(mrow + f * 16);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = ((mb >> (8 * r)) & 0xffu) != 0;
-                    const float x = ok ? (s[f][r] + bd) * a.scale : -INFINITY;
-                    sv[f][r] = x;
-                    tmax = fmaxf(tmax, x);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = ((mb >> (8 * r)) & 0xffu) != 0;
+                const float x = ok ? (s[f][r] + bd) * a.scale : -INFINITY;
+                s[f][r] = x;
+                tmax = fmaxf(tmax, x);
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            float alpha = 1.f;
-            if (m_new != -INFINITY) alpha = __expf(m_run - m_new);
-            float psum = 0.f;
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        float alpha = 1.f;
+        if (m_new != -INFINITY) alpha = __expf(m_run - m_new);
+        float psum = 0.f;
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 16; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = (m_new == -INFINITY) ? 0.f : __expf(sv[f][r] - m_new);
-                    sv[f][r] = pv;
-                    psum += pv;
-                }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (m_new == -INFINITY) ? 0.f : __expf(s[f][r] - m_new);
+                s[f][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc_o[i] *= alpha;
-            // ---- O^T += V^T . P^T ; V fragments by transposed LDS reads ------------------------------------------------
+        for (int i = 0; i < 4; ++i) acc_o[i] *= alpha;
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const f32x4 p0 = {sv[2 * k2][0], sv[2 * k2][1], sv[2 * k2][2], sv[2 * k2][3]};
-                const f32x4 p1 = {sv[2 * k2 + 1][0], sv[2 * k2 + 1][1], sv[2 * k2 + 1][2], sv[2 * k2 + 1][3]};
-                const u32x4 ph = pack8<HT>(p0, p1);
-                const int key0 = t * 64 + (2 * k2) * 16 + 4 * g;
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const u32x4 ph = pack8<HT>(s[2 * k2], s[2 * k2 + 1]);
+            const int key0 = k2 * 32 + 4 * g;
 #pragma unroll
-                for (int fd = 0; fd < 4; ++fd) {
-                    // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the 4x16 block; it receives column
-                    // (lane & 15) of the 4 rows, i.e. V[key0 + 0..3][fd*16 + l15]
-                    const u16* pa = Vl + (key0 + (l15 >> 2)) * V2STR + fd * 16 + (l15 & 3) * 4;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 16 * V2STR));
-                    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-                    const u32x4 vf = {lo2.x, lo2.y, hi2.x, hi2.y};
-                    acc_o[fd] = HT::mfma(vf, ph, acc_o[fd]);
-                }
+            for (int fd = 0; fd < 4; ++fd) {
+                // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the 4x16 block; it receives column
+                // (lane & 15) of the 4 rows, i.e. V[key0 + 0..3][fd*16 + l15]
+                const u16* pa = Vl + (key0 + (l15 >> 2)) * V2STR + fd * 16 + (l15 & 3) * 4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 16 * V2STR));
+                const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+                const u32x4 vf = {lo2.x, lo2.y, hi2.x, hi2.y};
+                acc_o[fd] = HT::mfma(vf, ph, acc_o[fd]);
             }
         }
     }
 
+    CFM_ASTAMP(3);
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
@@ -472,6 +505,8 @@ __global__ __launch_bounds__(256) void cfm_attn2_kernel(const AttnArgs a) {
                 *(u32x2*)((u16*)a.out + ob + d) = (u32x2){pack2<F16>(o.x, o.y), pack2<F16>(o.z, o.w)};
         }
     }
+    CFM_ASTAMP(4);
+    CFM_ASTAMP(7);
 }
 
 template <typename HT>
@@ -482,10 +517,13 @@ int launch_attn2(const AttnArgs& a, hipStream_t s, const char* name) {
     CfmProfScope prof(name, s, flops, bytes);
     const int pmode = a.p ? (a.p_st == 0 ? 1 : 2) : 0;
     const bool mfull = a.mask && a.m_sq != 0;
+    const bool kvf32 = a.kv_dtype == CFM_F32;
 #define CFM_A2(PM)                                                                                       \
     do {                                                                                                 \
-        if (mfull) CFM_LAUNCH((cfm_attn2_kernel<HT, PM, true>), grid, block, 0, s, a);            \
-        else CFM_LAUNCH((cfm_attn2_kernel<HT, PM, false>), grid, block, 0, s, a);                 \
+        if (mfull && kvf32) CFM_LAUNCH((cfm_attn2_kernel<HT, PM, true, true>), grid, block, 0, s, a);      \
+        else if (mfull) CFM_LAUNCH((cfm_attn2_kernel<HT, PM, true, false>), grid, block, 0, s, a);         \
+        else if (kvf32) CFM_LAUNCH((cfm_attn2_kernel<HT, PM, false, true>), grid, block, 0, s, a);         \
+        else CFM_LAUNCH((cfm_attn2_kernel<HT, PM, false, false>), grid, block, 0, s, a);                   \
     } while (0)
     if (pmode == 0) CFM_A2(0);
     else if (pmode == 1) CFM_A2(1);

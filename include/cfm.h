@@ -351,8 +351,9 @@ int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_layer_scratc
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling table (aux subsystem: tracing).  When enabled, every kernel launch made through this
- * library is bracketed by HIP events on its stream; cfm_prof_collect() synchronises those events and
- * accumulates per-kernel-name totals.  Used by bench.py for the live roofline figure.
+ * library carries a start and a stop HIP event attached to the dispatch itself (its own begin/end timestamps, the
+ * duration a profiler reports); cfm_prof_collect() synchronises those events and accumulates per-kernel-name
+ * totals.  Used by bench.py for the live roofline figure.
  */
 void cfm_prof_enable(int on);
 void cfm_prof_reset(void);
