@@ -227,31 +227,46 @@ __global__ __launch_bounds__(256) void cfm_conv1_kernel(const float* __restrict_
         w1[k] = *(const f32x4*)(w + k * C + c0 + 4);
     }
     const f32x4 b0 = *(const f32x4*)(bias + c0), b1 = *(const f32x4*)(bias + c0 + 4);
-    const int64_t first = ((int64_t)blockIdx.x * CONV1_PPT) * slots + slot;
+    // (b, t1, f1) of the thread's first position by ONE 32-bit decomposition, then carried forward: `slots` positions per step.
+    // (The first version divided 64-bit indices four times per position: ~400 VALU instructions next to 36 packed FMAs.)
+    const unsigned first = (blockIdx.x * (unsigned)CONV1_PPT) * (unsigned)slots + (unsigned)slot;
+    unsigned f1 = first % (unsigned)F1, bt0 = first / (unsigned)F1;
+    unsigned t1 = bt0 % (unsigned)T1, b = bt0 / (unsigned)T1;
+    // all taps of all CONV1_PPT positions are requested before the first is used (no early exit inside the loop: positions
+    // past the end are clamped for the loads and predicated for the store)
+    float xv[CONV1_PPT][9];
+    int64_t opos[CONV1_PPT];
 #pragma unroll
     for (int it = 0; it < CONV1_PPT; ++it) {
-        const int64_t pos = first + (int64_t)it * slots;
-        if (pos >= npos) break;
-        const int f1 = (int)(pos % F1);
-        const int64_t bt = pos / F1;
-        const int t1 = (int)(bt % T1);
-        const int b = (int)(bt / T1);
-        const float* xp = x + ((int64_t)b * T + 2 * t1) * F + 2 * f1;
-        float xv[9];
+        const int64_t pos = (int64_t)first + (int64_t)it * slots;
+        opos[it] = pos < npos ? pos : -1;
+        if (it) {
+            f1 += (unsigned)slots;
+            while (f1 >= (unsigned)F1) {                  // slots <= 32 < F1 in every configuration of interest: one pass
+                f1 -= (unsigned)F1;
+                if (++t1 == (unsigned)T1) { t1 = 0; ++b; }
+            }
+        }
+        const unsigned bc = b < (unsigned)B ? b : (unsigned)B - 1u;
+        const float* xp = x + ((int64_t)bc * T + 2 * t1) * F + 2 * f1;
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-            for (int kf = 0; kf < 3; ++kf) xv[kt * 3 + kf] = xp[kt * F + kf];
+            for (int kf = 0; kf < 3; ++kf) xv[it][kt * 3 + kf] = xp[kt * F + kf];
+    }
+#pragma unroll
+    for (int it = 0; it < CONV1_PPT; ++it) {
         f32x4 a0 = b0, a1 = b1;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            a0 += xv[k] * w0[k];
-            a1 += xv[k] * w1[k];
+            a0 += xv[it][k] * w0[k];
+            a1 += xv[it][k] * w1[k];
         }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         a0 = __builtin_elementwise_max(a0, z);
         a1 = __builtin_elementwise_max(a1, z);
-        const int64_t o = pos * C + c0;
+        if (opos[it] < 0) continue;
+        const int64_t o = opos[it] * C + c0;
         if constexpr (OUT_F32) {
             *(f32x4*)((float*)y + o) = a0;
             *(f32x4*)((float*)y + o + 4) = a1;
@@ -297,7 +312,8 @@ extern "C" int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, co
     hipStream_t s = (hipStream_t)stream;
     const double bytes = (double)B * T * D * (cfm_elt_size(x_dtype) + cfm_elt_size(y_dtype));
     CfmProfScope prof("dwconv_bn_silu", s, 2.0 * B * T * (double)D * ktaps, bytes);
-    if (ktaps == 15 && D % 8 == 0 && D >= 64 && D <= 512) {
+    // tiled kernel: 256 threads cover D/2 channel pairs x (256 / (D/2)) frame groups, at most 8 frames per thread => D <= 256
+    if (ktaps == 15 && D % 8 == 0 && D >= 64 && D <= 256 && (DW_TS + 256 / (D / 2) - 1) / (256 / (D / 2)) <= 8) {
         const dim3 grid((unsigned)((T + DW_TS - 1) / DW_TS), B), block(256);
         const size_t lds = (size_t)(DW_TS + 14 + DW_TS) * D * sizeof(float);
         CFM_LAUNCH((cfm_dwconv_tiled_kernel<15>), grid, block, lds, s, x, w, dw_bias, bn_scale, bn_shift, y, x_dtype, y_dtype, T, D);
@@ -328,6 +344,7 @@ extern "C" int cfm_conv1_relu(const float* x, const float* w, const float* bias,
     const int64_t total = (int64_t)B * T1 * F1 * (C / 8);
     const int slots = 256 / (C / 8);                         // position slots per block (threads beyond slots*C/8 idle)
     const int64_t npos = (int64_t)B * T1 * F1;
+    CFM_CHECK_ARG(npos < (int64_t)1 << 31, "cfm_conv1_relu: %lld output positions do not fit the kernel's 32-bit position index", (long long)npos);
     const int64_t nblocks = (npos + (int64_t)slots * CONV1_PPT - 1) / ((int64_t)slots * CONV1_PPT);
     hipStream_t s = (hipStream_t)stream;
     const double bytes = (double)B * T * F * 4 + (double)total * 8 * cfm_elt_size(y_dtype);

@@ -102,6 +102,32 @@ int main() {
     fdw.dw_w = vec; fdw.dw_b = vec; fdw.dw_scale = vec; fdw.dw_shift = vec; fdw.dw_T = 249; fdw.dw_K = 15;
     run("dw-final", fdw, 7968);
 
+    {   // cold weights: rotate 12 weight sets (as 12 layers do), so every launch first-touches its weights on all 8 XCDs
+        const int L = 12;
+        std::vector<cfm_rowchain_desc> macs(L, mac), fdws(L, fdw);
+        for (int l = 0; l < L; ++l) {
+            void* a1 = dalloc((size_t)FF * D * 2, 0x11); void* a2 = dalloc((size_t)FF * D * 2, 0x11);
+            void* a3 = dalloc((size_t)768 * D * 2, 0x11); void* a4 = dalloc((size_t)D * D * 2, 0x11);
+            void* junk = dalloc((size_t)24 << 20, 0x11); (void)junk;   // spacing between the sets
+            macs[l].w1f = a1; macs[l].w2n = a2; macs[l].tail_w = a3; macs[l].M = 7968;
+            fdws[l].w1f = a1; fdws[l].w2n = a2; fdws[l].head_w = a4; fdws[l].M = 7968;
+        }
+        for (int which = 0; which < 2; ++which) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            for (int l = 0; l < L; ++l) cfm_rowchain(which ? &fdws[l] : &macs[l], nullptr);
+            (void)hipEventRecord(e0, nullptr);
+            const int reps = 10;
+            for (int r = 0; r < reps; ++r)
+                for (int l = 0; l < L; ++l) cfm_rowchain(which ? &fdws[l] : &macs[l], nullptr);
+            (void)hipEventRecord(e1, nullptr);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("%s, 12 rotating weight sets (L2-cold weights): %.2f us/launch back-to-back\n", which ? "dw-final" : "macaron", ms * 1000.f / (reps * L));
+        }
+    }
+
     for (int M : {32, 7968}) {
         run("macaron", mac, M);
         run("conv-in", cin, M);

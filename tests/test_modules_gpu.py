@@ -301,6 +301,27 @@ def test_config2_full_size_against_oracle_and_properties(pkg, mode):
     check("config 2 ragged tail: in-batch vs own batch", yr[-2:], y2, mode)
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_config4_encoder_shape_against_oracle(pkg, mode):
+    """BASELINE config 4's encoder architecture (d=512, h=8, ff=2048, SURVEY 8: 17 layers) at a size the oracle finishes in
+    seconds: 3 layers, ragged batch of 3.  d=512 has no row-chain instance, so this exercises the general path of
+    cfm_encoder_layer_forward (separate GEMMs + LayerNorm + stand-alone depthwise kernel) against the same oracle."""
+    from oracle import conformer_oracle as O
+    pkg.cfm.set_precision(mode)
+    cfg = dict(input_dim=80, kernel_size=15, encoder_dim=512, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+               hidden_dim=2048, num_heads=8, encoder_num_layers=3, max_len=5000, use_relative=True)
+    enc = build_encoder(pkg, cfg, 41)
+    B, T = 3, 240
+    x = dev(synth.fbank(4321, B, T))
+    lens = [240, 201, 133]
+    with torch.no_grad():
+        y, m = enc(x, torch.tensor(lens, dtype=torch.int32, device=DEV))
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    y_ref, m_ref = O.encoder_forward(P, O.Config(**cfg), x.cpu(), lens)
+    assert np.array_equal(m.cpu().numpy(), np.asarray(m_ref))                                   # bit-exact
+    check("config-4 encoder shape (d=512, h=8, 3 layers)", y, y_ref, mode)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):

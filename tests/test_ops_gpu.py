@@ -241,7 +241,7 @@ def test_attention_kv_cache_layout(cfm):
     assert relerr(out.float(), ref_o) < 2e-2
 
 
-@pytest.mark.parametrize("B,T,D,K", [(32, 249, 256, 15), (3, 37, 144, 15), (2, 5, 16, 15), (2, 40, 32, 7)])
+@pytest.mark.parametrize("B,T,D,K", [(32, 249, 256, 15), (3, 37, 144, 15), (2, 5, 16, 15), (2, 40, 32, 7), (3, 61, 512, 15), (2, 33, 384, 15), (2, 20, 64, 15)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 def test_dwconv_bn_silu(cfm, B, T, D, K, dt):
     x = rnd((B, T, D), 50).to(dt)
