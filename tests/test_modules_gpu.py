@@ -322,6 +322,33 @@ def test_config4_encoder_shape_against_oracle(pkg, mode):
     check("config-4 encoder shape (d=512, h=8, 3 layers)", y, y_ref, mode)
 
 
+@pytest.mark.parametrize("D,H,FF,K,L,B,T,lens", [
+    (64, 4, 128, 15, 2, 2, 97, [97, 60]),          # tiny width, dk=16
+    (96, 2, 200, 7, 2, 3, 131, [131, 131, 40]),    # FF not a multiple of 32, 7-tap depthwise
+    (192, 3, 768, 31, 1, 2, 160, [160, 111]),      # dk=64 with 3 heads, 31-tap depthwise
+    (320, 5, 1280, 15, 2, 1, 75, [75]),            # batch 1, width between the chain instances
+    (384, 6, 1024, 15, 1, 4, 64, [64, 64, 33, 9]), # very short utterance in the batch (T'=1 .. 15)
+    (256, 8, 1024, 15, 2, 2, 120, [120, 77]),      # d=256 but dk=32 and FF=1024: no chain instance for this FF
+])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_encoder_shape_sweep_against_oracle(pkg, mode, D, H, FF, K, L, B, T, lens):
+    """Widths, head counts, FF sizes and depthwise kernel sizes away from the two benchmark configurations: every combination goes
+    through whatever path cfm_encoder_layer_forward picks for it and must match the oracle (masks bit-exact)."""
+    from oracle import conformer_oracle as O
+    pkg.cfm.set_precision(mode)
+    cfg = dict(input_dim=80, kernel_size=K, encoder_dim=D, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+               hidden_dim=FF, num_heads=H, encoder_num_layers=L, max_len=5000, use_relative=True)
+    enc = build_encoder(pkg, cfg, 100 + D)
+    x = dev(synth.fbank(900 + D, B, T))
+    with torch.no_grad():
+        y, m = enc(x, torch.tensor(lens, dtype=torch.int32, device=DEV))
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    y_ref, m_ref = O.encoder_forward(P, O.Config(**cfg), x.cpu(), lens)
+    assert np.array_equal(m.cpu().numpy(), np.asarray(m_ref))
+    assert torch.isfinite(y).all()
+    check("sweep d=%d h=%d ff=%d k=%d" % (D, H, FF, K), y, y_ref, mode)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
