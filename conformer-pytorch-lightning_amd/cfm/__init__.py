@@ -32,7 +32,7 @@ class GemmDesc(ctypes.Structure):
                 ("a_dtype", c_i32), ("w_dtype", c_i32), ("c_dtype", c_i32),
                 ("act", c_i32), ("alpha", ctypes.c_float),
                 ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
-                ("tile", c_i32), ("mask_mode", c_i32)]
+                ("tile", c_i32), ("mask_mode", c_i32), ("W_frag", c_p)]
 
 
 class AttnDesc(ctypes.Structure):

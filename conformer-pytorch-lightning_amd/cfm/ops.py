@@ -30,7 +30,7 @@ def scratch(tag, numel, dtype, device):
 
 
 def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, residual=None, alpha=1.0, row_mask=None,
-         mask_mode=0, conv=None, tile=0, n_out=None):
+         mask_mode=0, conv=None, tile=0, n_out=None, w_frag=None):
     """out = epilogue(a[M,K] . w[N,K]^T); see include/cfm.h cfm_gemm.  conv=(C,T1,F1,T2,F2,M) selects the implicit
     3x3/stride-2 convolution over a channels-last image `a` of shape [B,T1,F1,C]."""
     _c.require_hip(a, w, bias, w_lo, out, residual, row_mask)
@@ -68,6 +68,11 @@ def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, 
         raise ValueError("cfm.gemm: row_mask must be contiguous uint8 [M]")
     if w_lo is not None and (w_lo.shape != w.shape or w_lo.dtype != w.dtype or not w_lo.is_contiguous()):
         raise ValueError("cfm.gemm: w_lo must match w")
+    if w_frag is not None:
+        _c.require_hip(w_frag)
+        if w_frag.dtype != w.dtype or w_frag.numel() < N * K:
+            raise ValueError("cfm.gemm: w_frag must be the fragment-major pack of w")
+        d.W_frag = _c.ptr(w_frag)
     d.A, d.W, d.W_lo, d.bias, d.residual, d.row_mask, d.C = _c.ptr(a), _c.ptr(w), _c.ptr(w_lo), _c.ptr(bias), _c.ptr(residual), _c.ptr(row_mask), _c.ptr(out)
     d.ldc = out.stride(0)
     d.M, d.N, d.K = M, N, K

@@ -86,6 +86,8 @@ typedef struct {
     int32_t tile;                                       /* 0 = auto; 1: 128x128, 2: 64x128, 3: 64x64 (tuning) */
     int32_t mask_mode;                                  /* 0: row_mask zeroes the OUTPUT row (after act, before residual);
                                                            1: row_mask zeroes the INPUT row (acc = 0, bias/act still apply) */
+    const void* W_frag; /* optional: the same weights fragment-major (see cfm_rowchain), K %% 32 == 0, N %% 16 == 0.  16-bit, non-split
+                           launches with a 128- or 64-row tile then read W global -> VGPR in MFMA layout and stage only A in LDS */
 } cfm_gemm_desc;
 
 int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream);

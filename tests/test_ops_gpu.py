@@ -241,6 +241,35 @@ def test_attention_kv_cache_layout(cfm):
     assert relerr(out.float(), ref_o) < 2e-2
 
 
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_gemm_direct_weights_match_lds_staged(cfm, wdt, tile):
+    """cfm_gemm with W_frag (weights global -> VGPR in MFMA layout, only A staged in LDS) runs the same MFMA sequence as the
+    LDS-staged kernel: bit-identical outputs, for the plain GEMM (ragged M, N not a multiple of the tile) and the implicit conv."""
+    from cfm import packing
+    dt = torch.bfloat16 if wdt == "bf16" else torch.float16
+    # plain: M ragged, K = 19 * 64, N = 256 / 144-like widths
+    for M, N, K in ((1000, 256, 1216), (333, 144, 160), (4096, 512, 512)):
+        a = rnd((M, K), 300).to(dt)
+        w = rnd((N, K), 301, K ** -0.5)
+        b = rnd((N,), 302, 0.1)
+        w16 = w.to(dt)
+        ref = cfm.gemm(a, w16, bias=b, act=cfm.ACT_RELU, out_dtype=torch.float32, tile=tile)
+        out = cfm.gemm(a, w16, bias=b, act=cfm.ACT_RELU, out_dtype=torch.float32, tile=tile, w_frag=packing.pack_frag_major(w, dt))
+        assert torch.equal(out, ref), (M, N, K)
+        assert relerr(out, torch.relu(a.float() @ w16.float().t() + b)) < (2e-2 if wdt == "bf16" else 3e-3)
+    # implicit 3x3 / stride-2 convolution over a channels-last image
+    B, T1, F1, C = 3, 41, 19, 64
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    img = rnd((B, T1, F1, C), 303).to(dt)
+    w = rnd((C, 9 * C), 304, (9 * C) ** -0.5)
+    b = rnd((C,), 305, 0.1)
+    kw = dict(bias=b, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2), out_dtype=dt, tile=tile)
+    ref = cfm.gemm(img, w.to(dt), **kw)
+    out = cfm.gemm(img, w.to(dt), w_frag=packing.pack_frag_major(w, dt), **kw)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("B,T,D,K", [(32, 249, 256, 15), (3, 37, 144, 15), (2, 5, 16, 15), (2, 40, 32, 7), (3, 61, 512, 15), (2, 33, 384, 15), (2, 20, 64, 15)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 def test_dwconv_bn_silu(cfm, B, T, D, K, dt):
