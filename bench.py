@@ -97,7 +97,8 @@ def selftest_cpu(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dist = None
-    if world > 1:
+    # CFM_BENCH_FORCE_DIST=1: take the RCCL path (init, barrier, MAX all-reduce) even with one rank -- lets a 1-GPU box rehearse it
+    if world > 1 or os.environ.get("CFM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
@@ -164,7 +165,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # CFM_BENCH_FORCE_DIST=1: take the RCCL path (init, barrier, MAX all-reduce) even with one rank -- lets a 1-GPU box rehearse it
+    if world > 1 or os.environ.get("CFM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
