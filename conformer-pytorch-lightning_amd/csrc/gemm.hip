@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     // ---- per-thread staging addresses -------------------------------------------------------
     const int kc = tid % CPR;
     const int rl = tid / CPR;
-    int64_t a_off[ACH], w_off[WCH];
+    // element offsets as 32-bit values on top of the (uniform) base pointers: the loads then use SGPR-base + VGPR-offset addressing
+    // instead of a 64-bit VALU add per access (the host checks that both operands are < 2^31 elements)
+    unsigned a_off[ACH], w_off[WCH];
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
         int m = m0 + i * RPP + rl;
@@ -94,16 +96,23 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             const int rem = m - b * per_b;
             const int t2 = rem / g.F2;
             const int f2 = rem - t2 * g.F2;
-            a_off[i] = (((int64_t)b * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.convC;
+            a_off[i] = (unsigned)(((b * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.convC);
         } else {
-            a_off[i] = (int64_t)m * g.lda;
+            a_off[i] = (unsigned)((int64_t)m * g.lda);
         }
     }
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
         int n = n0 + j * RPP + rl;
         n = n < g.N ? n : g.N - 1;
-        w_off[j] = (int64_t)n * g.K;
+        w_off[j] = (unsigned)n * (unsigned)g.K;
+    }
+    // implicit conv: (tap, channel) of this thread's chunk of the NEXT K tile to be requested, advanced by BK per request
+    // (gload is called for K tiles 0, 1, 2, ... in order) -- no integer division in the loop
+    int cv_ci = kc * 8, cv_tap = 0;
+    if constexpr (CONV) {
+        cv_tap = cv_ci / g.convC;
+        cv_ci -= cv_tap * g.convC;
     }
 
     // register prefetch ring: PF K-tiles in flight per workgroup.  The K loops here are SHORT (4 tiles at K=256) and the
@@ -121,29 +130,32 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
         constexpr int S = decltype(slot_c)::value;
         const int k0 = kt * BK + kc * 8;
         const bool kv = k0 < g.K;
-        int64_t koff = k0;
+        unsigned koff = (unsigned)k0;
         if constexpr (CONV) {
-            const int tap = k0 / g.convC;
-            const int ci = k0 - tap * g.convC;
-            const int k3 = tap / 3;
-            const int f3 = tap - 3 * k3;
-            koff = ((int64_t)k3 * g.F1 + f3) * g.convC + ci;
+            const int k3 = cv_tap / 3;                       // cv_tap <= 8: a multiply-shift, not a division
+            const int f3 = cv_tap - 3 * k3;
+            koff = (unsigned)((k3 * g.F1 + f3) * g.convC + cv_ci);
+            cv_ci += BK;
+            while (cv_ci >= g.convC) {
+                cv_ci -= g.convC;
+                ++cv_tap;
+            }
         }
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             if constexpr (A_F32) {
-                const f32x4* p = (const f32x4*)((const float*)g.A + a_off[i] + koff);
+                const f32x4* p = (const f32x4*)((const float*)g.A + (a_off[i] + koff));
                 fa[S][i][0] = kv ? p[0] : zf;
                 fa[S][i][1] = kv ? p[1] : zf;
             } else {
-                ra[S][i] = kv ? *(const u32x4*)((const u16*)g.A + a_off[i] + koff) : z4;
+                ra[S][i] = kv ? *(const u32x4*)((const u16*)g.A + (a_off[i] + koff)) : z4;
             }
         }
         if constexpr (!WDIR) {
 #pragma unroll
             for (int j = 0; j < WCH; ++j) {
-                rw[S][j] = kv ? *(const u32x4*)(g.W + w_off[j] + k0) : z4;
-                if constexpr (SPLIT) rwl[S][j] = kv ? *(const u32x4*)(g.Wlo + w_off[j] + k0) : z4;
+                rw[S][j] = kv ? *(const u32x4*)(g.W + (w_off[j] + (unsigned)k0)) : z4;
+                if constexpr (SPLIT) rwl[S][j] = kv ? *(const u32x4*)(g.Wlo + (w_off[j] + (unsigned)k0)) : z4;
             }
         }
     };
@@ -405,6 +417,10 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     } else {
         CFM_CHECK_ARG(d->lda % 8 == 0, "cfm_gemm: lda=%lld must be a multiple of 8", (long long)d->lda);
     }
+    CFM_CHECK_ARG((int64_t)d->N * d->K < ((int64_t)1 << 31), "cfm_gemm: weight matrix too large for 32-bit element offsets");
+    CFM_CHECK_ARG(conv ? (int64_t)(d->M / (d->conv_T2 * d->conv_F2)) * d->conv_T1 * d->conv_F1 * d->conv_C < ((int64_t)1 << 31)
+                       : ((int64_t)(d->M - 1) * d->lda + d->K) < ((int64_t)1 << 31),
+                  "cfm_gemm: activation operand too large for 32-bit element offsets");
     GemmArgs a;
     CFM_CHECK_ARG(!d->W_frag || (d->K % 32 == 0 && d->N % 16 == 0), "cfm_gemm: W_frag needs K %% 32 == 0 and N %% 16 == 0");
     a.Wf = (split || d->a_dtype == CFM_F32) ? nullptr : (const u16*)d->W_frag;
