@@ -90,7 +90,7 @@ class LayerIO(ctypes.Structure):
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64),
                 ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32), ("pending_in", c_i32), ("defer_final", c_i32), ("pend_b2", c_p), ("pend_ln_g", c_p), ("pend_ln_b", c_p),
                 ("pos_proj", c_p), ("pos_proj_ld", c_i64),
-                ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p)]
+                ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p), ("pos_shared", c_i32)]
 
 
 _lib = None

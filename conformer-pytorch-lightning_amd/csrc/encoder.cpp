@@ -67,9 +67,10 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     const int Tk = Tc + io->T;
     int P = 0;
     if (has_pos) {
-        CFM_CHECK_ARG((io->pos_embed || io->pos_proj) && io->pos_rows % io->B == 0, "encoder layer: pos_embed rows (%d) must be a multiple of B (%d)",
-                      io->pos_rows, io->B);
-        P = io->pos_rows / io->B;
+        CFM_CHECK_ARG((io->pos_embed || io->pos_proj) && (io->pos_shared || io->pos_rows % io->B == 0),
+                      "encoder layer: pos_embed rows (%d) must be a multiple of B (%d)", io->pos_rows, io->B);
+        P = io->pos_shared ? io->pos_rows : io->pos_rows / io->B;
+        CFM_CHECK_ARG(!io->pos_shared || P == Tk, "encoder layer: shared positions need one row per key (%d rows, Tk=%d)", io->pos_rows, Tk);
         CFM_CHECK_ARG(P == 1 || P == Tk, "encoder layer: pos_embed gives %d rows per item, need 1 or Tk=%d (attention.py:78-88)", P, Tk);
     }
     CFM_CHECK_ARG(Tc == 0 || io->new_cache, "encoder layer: a KV cache input needs new_cache storage");
@@ -146,7 +147,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     }
     if (has_pos) {
         const int64_t pld = io->pos_proj ? io->pos_proj_ld : D;
-        a.p = io->pos_proj ? io->pos_proj : s->pos; a.p_dtype = adt; a.p_sb = (int64_t)P * pld; a.p_st = P == 1 ? 0 : pld;
+        a.p = io->pos_proj ? io->pos_proj : s->pos; a.p_dtype = adt; a.p_sb = io->pos_shared ? 0 : (int64_t)P * pld; a.p_st = P == 1 ? 0 : pld;
         a.bias_u = w->bias_u; a.bias_v = w->bias_v;
     }
     a.mask = io->attn_mask; a.m_sb = io->am_sb; a.m_sq = io->am_sq;

@@ -43,7 +43,7 @@ class ConformerEncoder(nn.Module):
         self.static_chunk_size = static_chunk_size
 
     # ------------------------------------------------------------------------------------------------------------
-    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from):
+    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from, pos_shared=False):
         """x (B,T',D) f32 -> after_norm(blocks(x)); returns (y, [trimmed per-layer caches] | None)."""
         n = len(self.encoders)
         proj = self._project_positions(pos_embed, x)
@@ -57,12 +57,14 @@ class ConformerEncoder(nn.Module):
         for i, block in enumerate(self.encoders):
             nxt = self.encoders[i + 1].norm_ff_macaron if i + 1 < n else None
             cache_i = None
-            if caches is not None and caches.dim() == 4 and caches.size(0) > 0:
+            if caches is not None and caches.dim() == 5 and caches.size(0) > 0:
+                cache_i = caches[i]                                   # batched streaming: (L,B,H,Tc,2dk)
+            elif caches is not None and caches.dim() == 4 and caches.size(0) > 0:
                 cache_i = caches[i:i + 1]
             pp = None if proj is None else (proj[:, i * self.encoder_dim:], proj.stride(0))
             out, nc = block.fused_forward(cur, attn_mask, pos_embed, pad_mask, cache_i, xn_ready=ready, next_norm=nxt,
                                           out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pending=pending,
-                                          defer_final=handover and i + 1 < n)
+                                          defer_final=handover and i + 1 < n, pos_shared=pos_shared)
             pending = block.pending_handover(prec) if handover and i + 1 < n else None
             if new_caches is not None:
                 new_caches.append(nc[:, :, keep_from:, :])
@@ -101,8 +103,11 @@ class ConformerEncoder(nn.Module):
         return y.to(inputs.dtype), pad_mask
 
     def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK):
-        """One streaming step (batch 1 in the reference).  attn_cache (L,H,Tc,2dk) or empty; returns
-        (chunk output, new attn cache (L,H,Tc',2dk), cnn cache (L,0,0,0) -- the reference keeps no conv context)."""
+        """One streaming step.  Batch 1 as in the reference: attn_cache (L,H,Tc,2dk) or empty; returns (chunk output, new attn
+        cache (L,H,Tc',2dk), cnn cache (L,0,0,0) -- the reference keeps no conv context).
+        Batch B > 1 (beyond the reference, whose forward_chunk only works at batch 1: SURVEY 8 row S): B streams in lockstep at
+        the same `offset`, attn_cache (L,B,H,Tc,2dk) or empty, returned cache (L,B,H,Tc',2dk); item b of the result equals the
+        batch-1 call on inputs[b:b+1] with attn_cache[:, b]."""
         if self.global_cmvn is not None:
             inputs = self.global_cmvn(inputs)
         cfm.require_hip(inputs)
@@ -110,8 +115,11 @@ class ConformerEncoder(nn.Module):
         attn_cache = attn_cache.to(dev)
         x = self.embed.embed_frames(inputs)
         x, _ = self.position_encoding(x, offset)
-        have = attn_cache.dim() == 4 and attn_cache.size(0) > 0
-        cached = attn_cache.size(2) if have else 0
+        batched = inputs.size(0) > 1
+        have = attn_cache.dim() == (5 if batched else 4) and attn_cache.size(0) > 0
+        if batched and attn_cache.dim() == 4 and attn_cache.size(0) > 0:
+            raise RuntimeError("forward_chunk with %d streams needs attn_cache of shape (L,B,H,Tc,2dk)" % inputs.size(0))
+        cached = attn_cache.size(-2) if have else 0
         span = cached + x.size(1)
         pos_embed = self.embed.position_encoding(offset=offset - cached, size=span)
         if required_cache_size < 0:
@@ -121,8 +129,8 @@ class ConformerEncoder(nn.Module):
         else:
             keep_from = max(span - required_cache_size, 0)
         caches = attn_cache if have else torch.zeros((0, 0, 0, 0), device=dev)
-        y, new = self._run_blocks(x, inputs_attn_mask, pos_embed, None, caches, keep_from)
-        r_attn = torch.cat(new, dim=0)
+        y, new = self._run_blocks(x, inputs_attn_mask, pos_embed, None, caches, keep_from, pos_shared=batched)
+        r_attn = torch.stack(new, dim=0) if batched else torch.cat(new, dim=0)
         r_cnn = torch.zeros((len(self.encoders), 0, 0, 0), dtype=x.dtype, device=dev)
         return y.to(inputs.dtype), r_attn, r_cnn
 
@@ -141,4 +149,4 @@ class ConformerEncoder(nn.Module):
             pieces.append(y)
             offset += y.size(1)
         out = torch.cat(pieces, 1)
-        return out, torch.ones((1, 1, out.size(1)))
+        return out, torch.ones((out.size(0), 1, out.size(1)))

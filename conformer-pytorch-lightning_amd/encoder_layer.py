@@ -68,7 +68,7 @@ class ConformerEncoderLayer(nn.Module):
         return self._fused[1]
 
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
-                      want_cache=True, pos_proj=None, pending=None, defer_final=False):
+                      want_cache=True, pos_proj=None, pending=None, defer_final=False, pos_shared=False):
         """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified."""
         _inference_only(self, "ConformerEncoderLayer")
         if self.training:
@@ -132,6 +132,7 @@ class ConformerEncoderLayer(nn.Module):
         if pos_proj is not None:                       # (tensor view [R, D] of the driver's all-blocks projection, row stride)
             io.pos_proj, io.pos_proj_ld = pos_proj[0].data_ptr(), pos_proj[1]
         io.attn_cache, io.cache_T = cfm.ptr(cache), Tc
+        io.pos_shared = 1 if pos_shared else 0
         io.new_cache = cfm.ptr(new_cache)
         if pending is not None:                        # (w_2.bias f32, norm_final) of the PREVIOUS block: its last FFN is unfinished
             io.pending_in = 1

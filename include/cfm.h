@@ -343,6 +343,9 @@ typedef struct {
     const float* attn_cache;  /* f32 [B,H,Tc,2dk] or NULL */
     int32_t cache_T;
     float* new_cache;         /* f32 [B,H,Tc+T,2dk] or NULL (not materialised) */
+    int32_t pos_shared;       /* 1: the pos_rows == Tk positional rows are the SAME for every batch item (batched streaming step: all
+                                 streams at one offset).  Beyond the reference, whose forward_chunk only works at batch 1
+                                 (attention.py:78-88); per item it equals that batch-1 call. */
 } cfm_layer_io;
 
 /* x_in f32 [B*T,D] (not modified) -> x_out f32 [B*T,D] = norm_final(block(x_in)).

@@ -1,0 +1,27 @@
+"""Config 5 (informational): 64 streams in lockstep, chunk = 16 output frames (67-frame windows), left context capped at 4 chunks
+(Tc = 64), the config-2 model, bf16.  Prints ms per streaming step in steady state and stream-frames per second."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "conformer-pytorch-lightning_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import cfm, bench
+
+B, chunk, left = int(os.environ.get("STREAMS", "64")), 16, 4
+cfm.set_precision("bf16")
+dev = torch.device("cuda", 0)
+enc = bench.build_encoder(dev)
+window, hop, need = (chunk - 1) * 4 + 7, 4 * chunk, chunk * left
+x = torch.from_numpy(np.random.RandomState(5).standard_normal((B, window + 40 * hop, 80)).astype(np.float32)).to(dev)
+empty = torch.zeros((0, 0, 0, 0), device=dev)
+cache, offset, times = empty, 0, []
+with torch.no_grad():
+    for step in range(40):
+        win = x[:, step * hop: step * hop + window].contiguous()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y, cache, _ = enc.forward_chunk(win, offset, need, cache, empty)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+        offset += y.size(1)
+steady = sorted(times[10:])
+ms = 1e3 * steady[len(steady) // 2]
+print("streams %d  chunk %d  cache %s: %.3f ms per step (median of steady state, eager launches) = %.0f input frames/s over all streams (%.1f x real time per stream at 10 ms frames)"
+      % (B, chunk, tuple(cache.shape), ms, B * hop / (ms * 1e-3), hop * 10.0 / ms))

@@ -349,6 +349,40 @@ def test_encoder_shape_sweep_against_oracle(pkg, mode, D, H, FF, K, L, B, T, len
     check("sweep d=%d h=%d ff=%d k=%d" % (D, H, FF, K), y, y_ref, mode)
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_batched_streaming_equals_batch1(pkg, mode):
+    """B streams advanced in lockstep by one forward_chunk call must equal, per item, the reference-shaped batch-1
+    forward_chunk on that item with its own cache (the batch-1 path is pinned to the reference by test_streaming_matches_reference).
+    Rows never mix across batch items in any kernel, so the match is exact."""
+    g, meta = load_golden("enc_cfg1_stream")
+    pkg.cfm.set_precision(mode)
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    B, frames, chunk, left = 3, 131, 4, 2
+    x = dev(synth.fbank(77, B, frames))
+    need, hop, window = chunk * left, 4 * chunk, (chunk - 1) * 4 + 7
+    empty = torch.zeros((0, 0, 0, 0), device=DEV)
+    with torch.no_grad():
+        cache_b, caches_1 = empty, [empty] * B
+        offset = 0
+        for start in range(0, frames - 7 + 1, hop):
+            win = x[:, start:min(start + window, frames), :].contiguous()
+            yb, cache_b, cnn_b = enc.forward_chunk(win, offset, need, cache_b, empty)
+            assert cache_b.dim() == 5 and cache_b.size(1) == B and cnn_b.shape[0] == len(enc.encoders)
+            for b in range(B):
+                y1, caches_1[b], _ = enc.forward_chunk(win[b:b + 1], offset, need, caches_1[b], empty)
+                assert torch.equal(yb[b:b + 1], y1), (start, b, relerr(yb[b:b + 1], y1))
+                assert torch.equal(cache_b[:, b], caches_1[b])
+            offset += yb.size(1)
+        # the whole-utterance helper agrees too
+        yall, mall = enc.forward_chunk_by_chunk(x, chunk, left)
+        for b in range(B):
+            y1, _ = enc.forward_chunk_by_chunk(x[b:b + 1], chunk, left)
+            assert torch.equal(yall[b:b + 1], y1)
+        assert mall.shape == (B, 1, yall.size(1))
+        with pytest.raises(RuntimeError):                     # a batch-1-shaped cache with several streams is refused, not misread
+            enc.forward_chunk(x[:, :window].contiguous(), 4, need, caches_1[0], empty)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
