@@ -1,10 +1,9 @@
 // ffnpart.hip -- feed-forward block as PARTIAL sums over FF halves on 64-row tiles (gfx950).
 //
-// Measured (scripts/probe_ffn_scaling.py): ONE workgroup alone on an idle MI355X streams its 2 MB of FFN weights at
-// 58 GB/s -- the same rate it gets with 249 workgroups running.  The L2 -> CU path is limited PER CU (outstanding L1
-// misses x L2 latency), not in aggregate, so with 32-row tiles (ffn.hip / rowchain.hip) every CU must pull all of W1 and
-// W2 for its ~31 rows and the block costs ~34-41 us no matter what.  The only way down is that each CU pulls a
-// DIFFERENT part of the stream for MORE rows:
+// EXPERIMENTAL, opt-in (CFM_PARTIAL_FFN=1), slower than the row chains of rowchain.hip -- kept with its tests as the plumbing for
+// a partial-sum pipeline.  Motivation, as understood now: with one 32-row tile per
+// CU every CU pulls all of W1 and W2 (2 MB) through its own vector-memory path (64 B/clk/CU), and that path bounds the
+// feed-forward.  The way down is that each CU pulls a DIFFERENT part of the stream for MORE rows:
 //
 //     workgroup (tile t, half s):   Y_s[64 rows, D] = act( LN(x_t) . W1[half s]^T + b1 ) . W2[:, half s]^T        (1 MB stream)
 //
@@ -18,7 +17,8 @@
 //     exchange    bias + SiLU, converted to the second product's B-operand fragments and parked in LDS fragment-major
 //                 (one barrier per step, two buffers),
 //     product 2   wavefront w accumulates Y[64, its 32 output columns] over all 256 hidden columns of the step.
-// 8 wavefronts (2 per SIMD, <= 256 VGPRs each) because a wavefront can only pull ~4 B/clk from L2: see PNW below.
+// 8 wavefronts (2 per SIMD, <= 256 VGPRs each): a wavefront pays ~64 clk to issue a 1 KB load, so load throughput scales with
+// the number of wavefronts issuing (see PNW below).
 // Input stages (template INMODE):  0 = f32 rows;  1 = rows reduced from the previous block's partial slabs
 // (x = LN?(res + alpha (Y0 + Y1 + b2)), written back by the half-0 workgroup);  2 = rows produced by a head GEMM on a
 // 16-bit tile (pointwise-conv-2 + pad mask + residual), also written back.
@@ -49,8 +49,8 @@ struct PartArgs {
 namespace {
 
 constexpr int PBM = 64;
-constexpr int PNW = 8;    // wavefronts per workgroup: per-CU L2 streaming bandwidth scales with the number of wavefronts issuing
-                          // loads (scripts/ubench.hip: 4 -> 16 B/clk/CU, 8 -> 37, 16 -> 74), a wavefront sustains only ~4 B/clk
+constexpr int PNW = 8;    // wavefronts per workgroup: a wavefront issues at most one 1 KB load per ~64 clk (16 B/clk), so per-CU
+                          // streaming scales with the wavefronts issuing loads, up to the CU's 64 B/clk vector-memory path
 
 template <typename HT, int D, int NSTEPS, int INMODE>
 __global__ __launch_bounds__(PNW * 64) void cfm_ffnpart_kernel(const PartArgs a) {

@@ -2,6 +2,9 @@
 //  A) cycles per v_mfma_f32_16x16x32_bf16 for 8 independent accumulators, operands in registers
 //  B) L2-resident streaming: 1 KB wavefront loads, NFL loads in flight per wavefront, 4 wavefronts per workgroup
 // each with 1 and 256 workgroups; reports shader clock (s_memtime / s_memrealtime) as well.
+// CAVEAT: only wavefront 0 of a workgroup is timed while the bytes of ALL its wavefronts are counted; wavefront 0 is the oldest and
+// gets issue priority, so the B/clk/CU figures at 8 and 16 wavefronts are upper bounds (a whole workgroup's FFN phase in the real
+// kernel sustains 49-61 B/clk/CU: scripts/probe_chain.hip).  The per-wavefront issue limit (~16 B/clk) is what this file is good for.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
