@@ -123,7 +123,7 @@ def lib():
         L.cfm_layernorm.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, ctypes.c_float, c_i64, c_i32, c_p]
         L.cfm_kv_cache_pack.argtypes = [c_p, c_i32, c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_dwconv_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
-        L.cfm_conv1_relu.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_conv1_relu.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_valid_mask.argtypes = [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_chunk_mask.argtypes = [c_p, c_i32, c_i32, c_i32, c_p]
         L.cfm_attn_mask.argtypes = [c_p, c_p, c_p, c_i32, c_i32, c_p]

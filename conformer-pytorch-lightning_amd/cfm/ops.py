@@ -248,16 +248,25 @@ def dwconv_bn_silu(x, w, dw_bias, bn_scale, bn_shift, out=None, out_dtype=None):
     return out
 
 
-def conv1_relu(x, w9c, bias, out_dtype):
-    """x [B,T,F] f32 -> relu(conv3x3 s2) channels-last [B,T1,F1,C]."""
+def conv1_relu(x, w9c, bias, out_dtype, cmvn=None):
+    """x [B,T,F] f32 -> relu(conv3x3 s2) channels-last [B,T1,F1,C].  cmvn = (mean [F], istd [F] | None): global CMVN folded into the
+    tap loads, (x - mean) * istd, bit-identical to normalising first."""
     _c.require_hip(x, w9c, bias)
+    mean = istd = None
+    if cmvn is not None:
+        mean, istd = cmvn
+        _c.require_hip(mean, istd)
+        for t in (mean, istd):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != x.shape[2] or not t.is_contiguous()):
+                raise ValueError("cfm.conv1_relu: cmvn statistics must be contiguous float32 [F]")
     if x.dim() != 3 or x.dtype != torch.float32 or not x.is_contiguous():
         raise ValueError("cfm.conv1_relu: x must be contiguous float32 [B,T,F]")
     B, T, F = x.shape
     C = w9c.shape[1]
     T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
     out = torch.empty((B, T1, F1, C), dtype=out_dtype, device=x.device)
-    _c.check(_c.lib().cfm_conv1_relu(_c.ptr(x), _c.ptr(w9c), _c.ptr(bias), _c.ptr(out), _c.dt_code(out), B, T, F, C, _c.stream()),
+    _c.check(_c.lib().cfm_conv1_relu(_c.ptr(x), _c.ptr(w9c), _c.ptr(bias), _c.ptr(out), _c.dt_code(out), B, T, F, C, _c.ptr(mean), _c.ptr(istd),
+                                     _c.stream()),
              "cfm_conv1_relu")
     return out
 

@@ -1,6 +1,7 @@
 """Global cepstral mean/variance normalisation (reference src/cmvn.py:5-33): (x - mean) * istd with the statistics held
-as buffers.  Out of the hot-path scope (BASELINE configs run with cmvn=None); provided so that an
-encoder built with a stats file still runs.  Elementwise, on whatever device the buffers live on."""
+as buffers.  BASELINE configs run with cmvn=None; an encoder built with a stats file folds these two operations into the first
+convolution's tap loads (cfm_conv1_relu, bit-identical; encoder.ConformerEncoder._cmvn_args), so this forward is only used when the
+module is called on its own or the statistics do not live on the input's device."""
 import torch
 
 from utils import load_cmvn

@@ -85,8 +85,9 @@ class ConvolutionSubSampling(nn.Module):
         self.pos_enc = pos_enc
         self._pack = packing.PackCache()
 
-    def embed_frames(self, inputs):
-        """(B,T,F) fbank -> (B,T',D) f32: the two stride-2 convolutions and the output projection."""
+    def embed_frames(self, inputs, cmvn=None):
+        """(B,T,F) fbank -> (B,T',D) f32: the two stride-2 convolutions and the output projection.  cmvn = (mean, istd | None):
+        global CMVN (cmvn.py:22-33) folded into the first convolution's tap loads instead of a pass of its own."""
         _inference_only(self, "ConvolutionSubSampling")
         cfm.require_hip(inputs)
         prec = cfm.get_precision()
@@ -98,7 +99,7 @@ class ConvolutionSubSampling(nn.Module):
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
         if T2 < 1 or F2 != pk.Fp:
             raise RuntimeError("input of shape %s is too short / has the wrong feature size for this front-end" % (tuple(inputs.shape),))
-        h1 = cfm.conv1_relu(x, pk.w1, pk.b1, prec.act_dtype)                                     # [B,T1,F1,C]
+        h1 = cfm.conv1_relu(x, pk.w1, pk.b1, prec.act_dtype, cmvn=cmvn)                                     # [B,T1,F1,C]
         h2 = cfm.gemm(h1, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2),
                       out_dtype=prec.act_dtype)                                                  # [B*T2*F2, C]
         y = cfm.gemm(h2.view(B * T2, F2 * C), pk.wl, bias=pk.bl, w_lo=pk.wl_lo, out_dtype=torch.float32)

@@ -213,7 +213,8 @@ constexpr int CONV1_PPT = 8;
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void cfm_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, void* __restrict__ y, int y_dt, int B,
-                                                        int T, int F, int T1, int F1, int C) {
+                                                        int T, int F, int T1, int F1, int C, const float* __restrict__ cm_mean,
+                                                        const float* __restrict__ cm_istd) {
     const int c8n = C >> 3;                      // channel octets; blockDim.x = 256 covers 256/c8n position slots ... see host
     const int oct = threadIdx.x % c8n;
     const int slot = threadIdx.x / c8n;
@@ -253,6 +254,17 @@ __global__ __launch_bounds__(256) void cfm_conv1_kernel(const float* __restrict_
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
             for (int kf = 0; kf < 3; ++kf) xv[it][kt * 3 + kf] = xp[kt * F + kf];
+        if (cm_mean) {                                     // global CMVN folded into the taps: (x - mean[f]) * istd[f]
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) {
+                const float mu = cm_mean[2 * f1 + kf], is = cm_istd ? cm_istd[2 * f1 + kf] : 1.0f;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const float d = xv[it][kt * 3 + kf] - mu;
+                    xv[it][kt * 3 + kf] = cm_istd ? d * is : d;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int it = 0; it < CONV1_PPT; ++it) {
@@ -336,7 +348,8 @@ extern "C" int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, co
 }
 
 extern "C" int cfm_conv1_relu(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B, int32_t T,
-                              int32_t F, int32_t C, cfm_stream_t stream) {
+                              int32_t F, int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream) {
+    CFM_CHECK_ARG(cmvn_mean || !cmvn_istd, "cfm_conv1_relu: cmvn_istd without cmvn_mean");
     CFM_CHECK_ARG(x && w && bias && y, "cfm_conv1_relu: null pointer");
     CFM_CHECK_ARG(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 8 == 0, "cfm_conv1_relu: bad shape B=%d T=%d F=%d C=%d", B, T, F, C);
     CFM_CHECK_ARG(C / 8 <= 256, "cfm_conv1_relu: C=%d too wide (max 2048)", C);
@@ -351,9 +364,9 @@ extern "C" int cfm_conv1_relu(const float* x, const float* w, const float* bias,
     CfmProfScope prof("conv1_relu", s, 2.0 * 9 * (double)total * 8, bytes);
     const dim3 grid((unsigned)nblocks), block((unsigned)(slots * (C / 8)));
     if (y_dtype == CFM_F32)
-        CFM_LAUNCH((cfm_conv1_kernel<true>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
+        CFM_LAUNCH((cfm_conv1_kernel<true>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd);
     else
-        CFM_LAUNCH((cfm_conv1_kernel<false>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C);
+        CFM_LAUNCH((cfm_conv1_kernel<false>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd);
     return cfm_launch_status("cfm_conv1_relu");
 }
 

@@ -73,6 +73,20 @@ class ConformerEncoder(nn.Module):
                              eps=self.after_norm.eps)
         return y.view_as(cur), new_caches
 
+    def _cmvn_args(self, inputs):
+        """(inputs, cmvn tuple for the front-end): a GlobalCMVN-like module with float32 `mean` / `istd` buffers on the input's device is
+        folded into the first convolution (bit-identical); anything else is applied as the module it is."""
+        m = self.global_cmvn
+        if m is None:
+            return inputs, None
+        mean, istd = getattr(m, "mean", None), getattr(m, "istd", None)
+        ok = (isinstance(mean, torch.Tensor) and isinstance(istd, torch.Tensor) and mean.dtype == torch.float32 and istd.dtype == torch.float32 and
+              mean.dim() == 1 and mean.shape == istd.shape and mean.numel() == inputs.size(-1) and mean.device == inputs.device and
+              inputs.dtype == torch.float32)
+        if not ok:
+            return m(inputs), None
+        return inputs, (mean.contiguous(), istd.contiguous() if getattr(m, "norm_var", True) else None)
+
     def _project_positions(self, pos_embed, x):
         """linear_pos of EVERY block applied to pos_embed in one GEMM: [R, D] . [L*D, D]^T -> [R, L*D] (block i reads columns
         i*D .. (i+1)*D).  The per-block projections are 8 us launches of a 32-row GEMM in the batch path otherwise."""
@@ -89,11 +103,10 @@ class ConformerEncoder(nn.Module):
         return cfm.gemm(pe, pk.w[0], w_lo=pk.w[1], out_dtype=prec.act_dtype)
 
     def forward(self, inputs, input_lengths, decoding_chunk_size=0, num_decoding_chunk_size=-1):
-        if self.global_cmvn is not None:
-            inputs = self.global_cmvn(inputs)
+        inputs, cmvn = self._cmvn_args(inputs)
         cfm.require_hip(inputs, input_lengths)
         frames = inputs.size(1)
-        x = self.embed.embed_frames(inputs)
+        x = self.embed.embed_frames(inputs, cmvn)
         x, pos_embed = self.position_encoding(x, 0)
         # (~make_pad_mask(len, T))[:, None, :][:, :, 2::2][:, :, 2::2]  ==  (6 + 4 j < len), built in one launch
         pad_mask = cfm.valid_mask(input_lengths, x.size(1), first=6, stride=4).unsqueeze(1)
@@ -108,12 +121,11 @@ class ConformerEncoder(nn.Module):
         Batch B > 1 (beyond the reference, whose forward_chunk only works at batch 1: SURVEY 8 row S): B streams in lockstep at
         the same `offset`, attn_cache (L,B,H,Tc,2dk) or empty, returned cache (L,B,H,Tc',2dk); item b of the result equals the
         batch-1 call on inputs[b:b+1] with attn_cache[:, b]."""
-        if self.global_cmvn is not None:
-            inputs = self.global_cmvn(inputs)
+        inputs, cmvn = self._cmvn_args(inputs)
         cfm.require_hip(inputs)
         dev = inputs.device
         attn_cache = attn_cache.to(dev)
-        x = self.embed.embed_frames(inputs)
+        x = self.embed.embed_frames(inputs, cmvn)
         x, _ = self.position_encoding(x, offset)
         batched = inputs.size(0) > 1
         have = attn_cache.dim() == (5 if batched else 4) and attn_cache.size(0) > 0

@@ -265,9 +265,12 @@ int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, const float* 
 /* ------------------------------------------------------------------------------------------------
  * Front-end first conv: x [B,T,F] f32 -> relu(conv3x3 stride 2) as channels-last [B,T1,F1,C].
  * replaces convolution.py:60-61.  w [9,C] f32 (tap-major), bias [C].  C % 8 == 0.
+ * Optional global CMVN folded into the tap loads (cmvn.py:22-33, encoder.py:59-60): every input sample is read as
+ * (x[b,t,f] - cmvn_mean[f]) * cmvn_istd[f]  (cmvn_istd NULL: mean only; both NULL: plain) -- the same two f32 operations the
+ * reference applies before the convolution, so results are bit-identical to normalising first.
  */
 int cfm_conv1_relu(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B,
-                   int32_t T, int32_t F, int32_t C, cfm_stream_t stream);
+                   int32_t T, int32_t F, int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Masks -- integer/bool, bit-exact with the reference.

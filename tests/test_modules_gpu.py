@@ -383,6 +383,35 @@ def test_batched_streaming_equals_batch1(pkg, mode):
             enc.forward_chunk(x[:, :window].contiguous(), 4, need, caches_1[0], empty)
 
 
+@pytest.mark.parametrize("norm_var", [True, False])
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_global_cmvn_folded_into_conv1(pkg, mode, norm_var):
+    """Global CMVN (reference src/cmvn.py:22-33, applied at encoder.py:59-60 / :83-84) is folded into the first convolution's tap loads:
+    the same two f32 operations per sample, so the encoder output is bit-identical to normalising the features first -- batch
+    path and streaming step alike."""
+    import cmvn as cmvn_mod
+    g, meta = load_golden("enc_cfg1")
+    pkg.cfm.set_precision(mode)
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    x = dev(synth.fbank(meta["xseed"], meta["batch"], meta["frames"])) * 3.0 + 1.5
+    lens = torch.tensor(meta["lens"], dtype=torch.int32, device=DEV)
+    m = cmvn_mod.GlobalCMVN.__new__(cmvn_mod.GlobalCMVN)
+    torch.nn.Module.__init__(m)
+    m.norm_var = norm_var
+    m.register_buffer("mean", dev(synth.normal(5, (80,), 1.0)) + 1.5)
+    m.register_buffer("istd", 1.0 / (0.5 + dev(synth.normal(6, (80,), 1.0)).abs()))
+    xn = m(x)
+    empty = torch.zeros((0, 0, 0, 0), device=DEV)
+    with torch.no_grad():
+        y_ref, mask_ref = enc(xn, lens)
+        c_ref, cache_ref, _ = enc.forward_chunk(xn[:1, :67].contiguous(), 0, 8, empty, empty)
+        enc.global_cmvn = m
+        y, mask = enc(x, lens)
+        c, cache, _ = enc.forward_chunk(x[:1, :67].contiguous(), 0, 8, empty, empty)
+    assert torch.equal(y, y_ref) and torch.equal(mask, mask_ref)
+    assert torch.equal(c, c_ref) and torch.equal(cache, cache_ref)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
