@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "valid_mask", "chunk_mask",
+__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "ctc_nll", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -268,6 +268,25 @@ def conv1_relu(x, w9c, bias, out_dtype, cmvn=None):
     _c.check(_c.lib().cfm_conv1_relu(_c.ptr(x), _c.ptr(w9c), _c.ptr(bias), _c.ptr(out), _c.dt_code(out), B, T, F, C, _c.ptr(mean), _c.ptr(istd),
                                      _c.stream()),
              "cfm_conv1_relu")
+    return out
+
+
+def ctc_nll(logits, V, enc_lens, labels, label_lens):
+    """Per-utterance CTC negative log-likelihood from UN-normalised f32 logits [B,T,ld>=V] (log-softmax applied on the fly); blank 0.
+    enc_lens / label_lens int32 [B], labels int32 [B,Umax].  Returns f32 [B] (include/cfm.h cfm_ctc_nll)."""
+    _c.require_hip(logits, enc_lens, labels, label_lens)
+    if logits.dim() != 3 or logits.dtype != torch.float32 or logits.stride(2) != 1 or logits.stride(0) != logits.size(1) * logits.stride(1):
+        raise ValueError("cfm.ctc_nll: logits must be float32 [B,T,>=V] with contiguous rows")
+    B, T = logits.shape[:2]
+    for t in (enc_lens, labels, label_lens):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise ValueError("cfm.ctc_nll: lengths and labels must be contiguous int32")
+    if labels.dim() != 2 or labels.size(0) != B or enc_lens.numel() != B or label_lens.numel() != B:
+        raise ValueError("cfm.ctc_nll: batch sizes differ")
+    out = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    work = scratch("ctc_lp", B * T * (2 * labels.size(1) + 1), torch.float32, logits.device)
+    _c.check(_c.lib().cfm_ctc_nll(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
+                                  _c.ptr(work), _c.ptr(out), _c.stream()), "cfm_ctc_nll")
     return out
 
 

@@ -1,0 +1,168 @@
+// ctc.hip -- CTC negative log-likelihood on top of the vocabulary projection (gfx950).
+//
+// replaces the part of CTCDecoder.forward after the Linear (reference src/decoder.py:20-21):
+//     probs = logits.transpose(0, 1).log_softmax(2);  loss = nn.CTCLoss(reduction='sum')(probs, labels, enc_lens, label_lens)
+// blank = 0, no zero_infinity (nn.CTCLoss defaults).  The logits [B, T, V] (f32, row stride ld) come from cfm_gemm; nothing of
+// size B x T x V is written again: the log-softmax is applied on the fly as  lp[t, c] = logits[t, c] - lse[t].
+//
+// Two launches:
+//   rows   one wavefront per frame (b, t < len), the whole chip busy: lse = log sum_c exp(logits[t, c]) (16-byte loads, max-shifted,
+//          fp32), then the <= 2U+1 log-probabilities the recursion will need, lp[b, t, s] = logits[t, z_s] - lse, written to a
+//          compact work buffer [B, T, 2 Umax + 1] (z = (blank, y1, blank, y2, ..., blank) is the blank-extended label sequence);
+//   alpha  one workgroup per utterance, thread s owns state s (two states per thread when S > 256), alpha double-buffered in
+//          LDS, one barrier per frame, the lp rows of the next frames already in registers (they do not depend on alpha):
+//              alpha_t[s] = lp[t, s] + logaddexp(alpha_{t-1}[s], alpha_{t-1}[s-1], alpha_{t-1}[s-2] if z_s != blank and z_s != z_{s-2})
+//          nll = -logaddexp(alpha_{T-1}[S-1], alpha_{T-1}[S-2])     (an impossible alignment gives +inf, as nn.CTCLoss does)
+// The first version did both in one workgroup per utterance with a dependent global gather in every step: 1.16 ms at B = 32,
+// T' = 249, V = 5002 (32 of 256 CUs busy, ~1 us of memory latency per frame).  fp32 throughout, as the reference computes the loss
+// on probs.to(float32).
+#include "cfm_common.h"
+
+namespace {
+
+constexpr int CTC_NT = 256;
+constexpr int CTC_MAXS = 2 * CTC_NT;                       // extended states (U <= 255)
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// log(exp(a) + exp(b)) on the hardware exp2/log2 units (v_exp_f32 / v_log_f32, ~1 ulp): the recursion is a serial chain of these, the
+// library expf / log1pf sequences made it 181 us at T' = 249.  1 + e is in (1, 2], where log needs no special care.
+__device__ __forceinline__ float logaddexp_(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(1.0f + __expf(-fabsf(a - b)));
+}
+
+__device__ __forceinline__ int ext_label(const int* __restrict__ labels, int64_t base, int s, int V) {
+    const int y = (s & 1) ? labels[base + (s >> 1)] : 0;   // labels outside [0, V) cannot index a row: clamped (the reference would raise)
+    return y < 0 ? 0 : (y < V ? y : V - 1);
+}
+
+// rows: grid = ceil(B*T / 4) workgroups of 4 wavefronts, wavefront = one frame
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_rows_kernel(const float* __restrict__ logits, int64_t ld, int B, int T, int V,
+                                                              const int* __restrict__ enc_lens, const int* __restrict__ labels, int Umax,
+                                                              const int* __restrict__ label_lens, float* __restrict__ work) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row_id = (int64_t)blockIdx.x * (CTC_NT / 64) + (threadIdx.x >> 6);
+    if (row_id >= (int64_t)B * T) return;
+    const int b = (int)(row_id / T), t = (int)(row_id % T);
+    if (t >= min(max(enc_lens[b], 0), T)) return;          // frames past the utterance are never read by the recursion
+    const float* row = logits + row_id * ld;
+    float m = -INFINITY;
+    for (int c = lane * 4; c < V; c += 256) {
+        if (c + 3 < V) {
+            const f32x4 v = *(const f32x4*)(row + c);
+            m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        } else {
+            for (int k = c; k < V; ++k) m = fmaxf(m, row[k]);
+        }
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane * 4; c < V; c += 256) {              // second pass over a row that is now in L1/L2
+        if (c + 3 < V) {
+            const f32x4 v = *(const f32x4*)(row + c);
+            sum += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+        } else {
+            for (int k = c; k < V; ++k) sum += expf(row[k] - m);
+        }
+    }
+    const float lse = m + logf(wave_sum(sum));
+    const int S = 2 * min(max(label_lens[b], 0), Umax) + 1, SM = 2 * Umax + 1;
+    for (int s = lane; s < S; s += 64) work[row_id * SM + s] = row[ext_label(labels, (int64_t)b * Umax, s, V)] - lse;
+}
+
+// alpha: one workgroup per utterance
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __restrict__ work, int T, int V, const int* __restrict__ enc_lens,
+                                                               const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
+                                                               float* __restrict__ nll) {
+    __shared__ float alpha[2][CTC_MAXS + 2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int len = min(max(enc_lens[b], 0), T);
+    const int U = min(max(label_lens[b], 0), Umax);
+    const int S = 2 * U + 1, SM = 2 * Umax + 1;
+    if (len == 0) {                                        // no frames: only the empty label sequence is possible
+        if (tid == 0) nll[b] = U == 0 ? 0.f : INFINITY;
+        return;
+    }
+    const float* lp = work + (int64_t)b * T * SM;
+    bool skip[2], live[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = tid + i * CTC_NT;
+        live[i] = s < S;
+        skip[i] = false;
+        if (live[i] && s >= 2 && (s & 1)) {
+            const int z = ext_label(labels, (int64_t)b * Umax, s, V);
+            skip[i] = z != 0 && z != ext_label(labels, (int64_t)b * Umax, s - 2, V);
+        }
+    }
+    // alpha[.][0..1] are two -inf guard cells so that state s reads s-1 and s-2 without branches: state s lives at index s + 2
+    if (tid < 2) alpha[0][tid] = alpha[1][tid] = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = tid + i * CTC_NT;
+        if (live[i]) alpha[0][s + 2] = s < 2 ? lp[s] : -INFINITY;
+    }
+    constexpr int AHEAD = 4;                               // lp rows requested this many frames before they are used
+    float nxt[AHEAD][2];
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = 1 + k, s = tid + i * CTC_NT;
+            nxt[k][i] = (live[i] && t < len) ? lp[(int64_t)t * SM + s] : 0.f;
+        }
+    __syncthreads();
+    int cur = 0;
+    for (int t0 = 1; t0 < len; t0 += AHEAD) {
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            const int t = t0 + k;
+            if (t < len) {                                 // uniform
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int s = tid + i * CTC_NT;
+                    if (live[i]) {
+                        float a = logaddexp_(alpha[cur][s + 2], alpha[cur][s + 1]);
+                        if (skip[i]) a = logaddexp_(a, alpha[cur][s]);
+                        alpha[cur ^ 1][s + 2] = a + nxt[k][i];
+                        const int tn = t + AHEAD;
+                        nxt[k][i] = tn < len ? lp[(int64_t)tn * SM + s] : 0.f;
+                    }
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+    if (tid == 0) {
+        const float a = S >= 2 ? logaddexp_(alpha[cur][S + 1], alpha[cur][S]) : alpha[cur][S + 1];
+        nll[b] = -a;
+    }
+}
+
+}  // namespace
+
+extern "C" int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens,
+                           const int32_t* labels, int32_t Umax, const int32_t* label_lens, float* work, float* nll, cfm_stream_t stream) {
+    CFM_CHECK_ARG(logits && enc_lens && labels && label_lens && work && nll, "cfm_ctc_nll: null pointer");
+    CFM_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0, "cfm_ctc_nll: bad shape B=%d T=%d V=%d Umax=%d", B, T, V, Umax);
+    CFM_CHECK_ARG(2 * Umax + 1 <= CTC_MAXS, "cfm_ctc_nll: Umax=%d labels exceeds %d", Umax, (CTC_MAXS - 1) / 2);
+    CFM_CHECK_ARG(ld >= V && ld % 4 == 0, "cfm_ctc_nll: row stride %lld must be >= V and a multiple of 4", (long long)ld);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        const int64_t rows = (int64_t)B * T;
+        CfmProfScope prof("ctc_rows", s, 0.0, (double)rows * V * 4);
+        CFM_LAUNCH(cfm_ctc_rows_kernel, dim3((unsigned)((rows + CTC_NT / 64 - 1) / (CTC_NT / 64))), dim3(CTC_NT), 0, s, logits, ld, B, T, V, enc_lens,
+                   labels, Umax, label_lens, work);
+        if (int rc = cfm_launch_status("cfm_ctc_nll (rows)")) return rc;
+    }
+    CfmProfScope prof("ctc_alpha", s, 0.0, (double)B * T * (2 * Umax + 1) * 4);
+    CFM_LAUNCH(cfm_ctc_alpha_kernel, dim3(B), dim3(CTC_NT), 0, s, (const float*)work, T, V, enc_lens, labels, Umax, label_lens, nll);
+    return cfm_launch_status("cfm_ctc_nll (alpha)");
+}

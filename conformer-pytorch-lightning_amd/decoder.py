@@ -1,0 +1,55 @@
+"""CTC head -- drop-in for the class of the same name in the reference's src/decoder.py:7-23 (forward / loss evaluation only).
+
+    logits = ctc_lo(dropout(encoder_out))                      cfm_gemm, f32 logits, vocabulary padded to a multiple of 4 columns
+    loss   = CTCLoss(sum)(log_softmax(logits), labels, enc_lens, label_lens) / labels.size(1)      cfm_ctc_nll + a host-side sum
+
+Same constructor arguments and parameter names (`ctc_lo.weight`, `ctc_lo.bias`) as the reference.  Quirk Q7 is kept: the reference
+calls F.dropout with its default training=True, i.e. it drops activations even in eval mode; with dropout > 0 this module does the same
+(and is then as random as the reference), parity is defined and tested at dropout = 0.  No backward: calling it with gradients enabled
+on parameters that require them raises.
+"""
+import torch
+import torch.nn as nn
+
+import cfm
+from cfm import packing
+
+
+class CTCDecoder(nn.Module):
+
+    def __init__(self, vocab_size, encoder_dim, dropout):
+        super().__init__()
+        self.ctc_lo = nn.Linear(encoder_dim, vocab_size)
+        self.dropout = dropout
+        self._pack = packing.PackCache()
+
+    def _weights(self, prec):
+        def build():
+            V, D = self.ctc_lo.weight.shape
+            Vp = (V + 3) // 4 * 4                              # cfm_gemm wants N % 4 == 0; the pad columns are never read by cfm_ctc_nll
+            w = torch.zeros((Vp, D), dtype=torch.float32, device=self.ctc_lo.weight.device)
+            w[:V] = self.ctc_lo.weight.detach()
+            b = torch.zeros((Vp,), dtype=torch.float32, device=w.device)
+            b[:V] = self.ctc_lo.bias.detach()
+            wm, wlo = packing.matrix(w, prec)
+            return packing.Packed(w=wm, w_lo=wlo, b=b, V=V, Vp=Vp)
+        return self._pack.get([self.ctc_lo.weight, self.ctc_lo.bias], prec, build)
+
+    def nll(self, encoder_out, encoder_out_lens, padded_labels, label_lengths):
+        """Per-utterance CTC negative log-likelihood, f32 [B]."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("CTCDecoder: backward is not built yet (forward / loss evaluation only)")
+        cfm.require_hip(encoder_out)
+        prec = cfm.get_precision()
+        pk = self._weights(prec)
+        x = nn.functional.dropout(encoder_out, self.dropout)      # training=True by default, as decoder.py:19 (quirk Q7)
+        B, T, D = x.shape
+        x2 = (x if x.dtype == torch.float32 else x.float()).contiguous().view(B * T, D)
+        logits = cfm.gemm(x2, pk.w, bias=pk.b, w_lo=pk.w_lo, out_dtype=torch.float32).view(B, T, pk.Vp)
+        dev = x.device
+        i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+        return cfm.ctc_nll(logits, pk.V, i32(encoder_out_lens), i32(padded_labels), i32(label_lengths))
+
+    def forward(self, encoder_out, encoder_out_lens, padded_labels, label_lengths):
+        loss = self.nll(encoder_out, encoder_out_lens, padded_labels, label_lengths).sum()
+        return loss / padded_labels.size(1)

@@ -358,6 +358,16 @@ int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_layer_scratc
                               const float* next_b, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * CTC negative log-likelihood per utterance on top of the vocabulary projection (csrc/ctc.hip):
+ * replaces  probs = logits.transpose(0,1).log_softmax(2); nn.CTCLoss(reduction='sum')(probs, labels, enc_lens, label_lens)
+ * of CTCDecoder.forward (reference src/decoder.py:20-21; blank = 0, no zero_infinity).  logits f32 [B,T,ld>=V] (from cfm_gemm with
+ * ctc_lo.weight / bias), labels int32 [B,Umax] (padding ignored beyond label_lens[b]), work f32 scratch [B,T,2*Umax+1], nll f32 [B];
+ * the caller sums nll and divides by Umax as decoder.py:22 does.  Umax <= 255.  An impossible alignment gives +inf, like nn.CTCLoss.
+ */
+int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens,
+                const int32_t* labels, int32_t Umax, const int32_t* label_lens, float* work, float* nll, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Profiling table (aux subsystem: tracing).  When enabled, every kernel launch made through this
  * library carries a start and a stop HIP event attached to the dispatch itself (its own begin/end timestamps, the
  * duration a profiler reports); cfm_prof_collect() synchronises those events and accumulates per-kernel-name

@@ -372,6 +372,49 @@ def encoder_forward_chunk_by_chunk(P, cfg, x, decoding_chunk_size, num_decoding_
 # =============================================================================
 # algorithmic work model -- used by bench.py for the roofline figure
 # =============================================================================
+# =============================================================================
+# SURVEY 8(f) rank 1 -- CTC head.  reference src/decoder.py:18-23 (dropout p = 0: the reference applies F.dropout with
+# training=True even in eval, quirk Q7, which no deterministic restatement can follow)
+# =============================================================================
+def ctc_nll(logp, labels, blank=0):
+    """-log p(labels | logp) by the alpha recursion over the blank-extended sequence (what nn.CTCLoss computes per item).
+    logp (T,V) log-probabilities, labels a 1-D int sequence; float64 inside."""
+    lp = np.asarray(logp, dtype=np.float64)
+    z = [blank]
+    for y in np.asarray(labels).tolist():
+        z += [int(y), blank]
+    S, T = len(z), lp.shape[0]
+    if T == 0:
+        return 0.0 if S == 1 else float("inf")
+    ninf = -np.inf
+    alpha = np.full(S, ninf)
+    alpha[0] = lp[0, z[0]]
+    if S > 1:
+        alpha[1] = lp[0, z[1]]
+    for t in range(1, T):
+        prev = alpha
+        alpha = np.full(S, ninf)
+        for s in range(S):
+            a = prev[s]
+            if s >= 1:
+                a = np.logaddexp(a, prev[s - 1])
+            if s >= 2 and z[s] != blank and z[s] != z[s - 2]:
+                a = np.logaddexp(a, prev[s - 2])
+            alpha[s] = a + lp[t, z[s]]
+    tot = alpha[S - 1] if S == 1 else np.logaddexp(alpha[S - 1], alpha[S - 2])
+    return float(-tot)
+
+
+def ctc_head_loss(P, prefix, enc_out, enc_lens, labels, label_lens):
+    """CTCDecoder.forward with dropout 0: Linear -> log_softmax over the vocabulary -> sum of the per-utterance CTC negative
+    log-likelihoods / padded label length (decoder.py:19-22).  Returns (loss, per-utterance nll)."""
+    logits = linear(enc_out, _w(P, prefix, "ctc_lo.weight"), _w(P, prefix, "ctc_lo.bias"))
+    logp = torch.log_softmax(logits.double(), dim=-1).numpy()
+    lab = np.asarray(labels)
+    nll = np.array([ctc_nll(logp[b, :int(enc_lens[b])], lab[b, :int(label_lens[b])]) for b in range(logp.shape[0])])
+    return float(nll.sum() / lab.shape[1]), nll
+
+
 def encoder_flops_per_utt(T, F=80, D=256, FF=2048, K=15, L=12):
     """2*MAC of the GEMM/conv/attention contractions of one utterance's forward (elementwise/LN excluded)."""
     t1, f1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1

@@ -255,7 +255,38 @@ def gen_masks():
     save("masks", arrays, dict(note="bool arrays stored as uint8 or np.packbits"))
 
 
+def gen_ctc():
+    """CTCDecoder.forward (reference src/decoder.py:7-23) with dropout 0 (it applies dropout with training=True even in eval, quirk
+    Q7): the scalar loss the reference returns, plus the per-utterance terms from the same torch op with reduction='none'."""
+    import decoder as ref_decoder  # noqa: E402  (torch-only; imports attention / decoder_layer / utils of the reference)
+    arrays, cases = {}, []
+    for name, (V, D, B, T, Umax, seed) in dict(small=(73, 144, 3, 49, 9, 21), vocab5002=(5002, 256, 2, 60, 12, 22)).items():
+        dec = ref_decoder.CTCDecoder(V, D, 0.0).eval()
+        synth.load_synth_(dec, seed)
+        rs = np.random.RandomState(seed)
+        enc_out = torch.from_numpy(synth.normal(seed + 100, (B, T, D), 1.0))
+        enc_lens = np.sort(rs.randint(T // 2, T + 1, size=B))[::-1].astype(np.int64).copy()
+        enc_lens[0] = T
+        label_lens = rs.randint(1, Umax + 1, size=B).astype(np.int64)
+        label_lens[0] = Umax
+        labels = rs.randint(1, V, size=(B, Umax)).astype(np.int64)
+        labels[1, 1:3] = labels[1, 0]                       # repeated labels: the skip transition must be refused there
+        for b in range(B):
+            labels[b, label_lens[b]:] = 0
+        with torch.no_grad():
+            loss = dec(enc_out, torch.from_numpy(enc_lens), torch.from_numpy(labels), torch.from_numpy(label_lens))
+            probs = dec.ctc_lo(enc_out).transpose(0, 1).log_softmax(2)
+            per = torch.nn.CTCLoss(reduction="none")(probs, torch.from_numpy(labels), torch.from_numpy(enc_lens), torch.from_numpy(label_lens))
+        arrays[name + "_loss"] = t2n(loss.reshape(1))
+        arrays[name + "_nll"] = t2n(per)
+        arrays[name + "_enc_lens"], arrays[name + "_labels"], arrays[name + "_label_lens"] = enc_lens, labels, label_lens
+        cases.append(dict(name=name, V=V, D=D, B=B, T=T, Umax=Umax, wseed=seed, xseed=seed + 100,
+                          state={k: list(v.shape) for k, v in dec.state_dict().items()}))
+    save("ctc_head", arrays, dict(cases=cases))
+
+
 if __name__ == "__main__":
     gen_masks()
     gen_modules()
     gen_encoders()
+    gen_ctc()

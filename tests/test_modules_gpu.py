@@ -412,6 +412,52 @@ def test_global_cmvn_folded_into_conv1(pkg, mode, norm_var):
     assert torch.equal(c, c_ref) and torch.equal(cache, cache_ref)
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_ctc_head_matches_reference(pkg, mode):
+    """Drop-in decoder.CTCDecoder (dropout 0) against the reference's own loss and per-utterance terms (tests/golden/ctc_head.npz) and
+    against the oracle; parameter names/shapes equal the reference's manifest.  SURVEY 8(f) rank 1."""
+    import decoder
+    from oracle import conformer_oracle as O
+    g, meta = load_golden("ctc_head")
+    pkg.cfm.set_precision(mode)
+    tol = {"fp32": 2e-5, "fp16": 2e-3, "bf16": 1.5e-2}[mode]          # relative, on a loss of order 10..100
+    for c in meta["cases"]:
+        n = c["name"]
+        dec = decoder.CTCDecoder(c["V"], c["D"], 0.0).eval()
+        synth.load_synth_(dec, c["wseed"])
+        dec = dec.to(DEV)
+        assert {k: list(v.shape) for k, v in dec.state_dict().items()} == c["state"]
+        enc_out = dev(synth.normal(c["xseed"], (c["B"], c["T"], c["D"]), 1.0))
+        lens, labels, llens = (torch.from_numpy(g[n + k]).to(DEV) for k in ("_enc_lens", "_labels", "_label_lens"))
+        with torch.no_grad():
+            nll = dec.nll(enc_out, lens, labels, llens)
+            loss = dec(enc_out, lens, labels, llens)
+        ref = torch.from_numpy(g[n + "_nll"])
+        assert float(((nll.cpu() - ref).abs() / ref.abs()).max()) < tol, (n, nll.cpu(), ref)
+        assert abs(float(loss) - float(g[n + "_loss"][0])) < tol * abs(float(g[n + "_loss"][0]))
+        P = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+        o_loss, o_nll = O.ctc_head_loss(P, "", enc_out.cpu(), g[n + "_enc_lens"], g[n + "_labels"], g[n + "_label_lens"])
+        assert abs(float(loss) - o_loss) < tol * abs(o_loss)
+
+
+def test_ctc_nll_edge_cases(pkg):
+    """cfm_ctc_nll against torch's CPU ctc_loss on raw logits: empty label sequence, a single frame, repeated labels that need more
+    frames than there are (+inf, like nn.CTCLoss), labels at the vocabulary edge, a row stride wider than V."""
+    cfm = pkg.cfm
+    B, T, V, ld, Umax = 5, 11, 37, 40, 6
+    logits = dev(synth.normal(31, (B, T, ld), 2.0))
+    enc_lens = torch.tensor([11, 1, 5, 11, 7], dtype=torch.int32, device=DEV)
+    labels = torch.tensor([[3, 3, 36, 1, 1, 2], [5, 0, 0, 0, 0, 0], [7, 7, 7, 7, 0, 0], [0, 0, 0, 0, 0, 0], [36, 1, 36, 1, 0, 0]],
+                          dtype=torch.int32, device=DEV)
+    label_lens = torch.tensor([6, 1, 4, 0, 4], dtype=torch.int32, device=DEV)
+    nll = cfm.ctc_nll(logits, V, enc_lens, labels, label_lens).cpu()
+    lp = torch.log_softmax(logits[:, :, :V].cpu().double(), -1).transpose(0, 1)
+    ref = torch.nn.functional.ctc_loss(lp, labels.cpu().long(), enc_lens.cpu().long(), label_lens.cpu().long(), reduction="none")
+    assert torch.isinf(ref[2]) and torch.isinf(nll[2]) and nll[2] > 0            # 4 equal labels need 7 frames, only 5 given
+    ok = torch.isfinite(ref)
+    assert torch.allclose(nll[ok].double(), ref[ok], rtol=1e-5, atol=1e-4), (nll, ref)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):

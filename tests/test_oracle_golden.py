@@ -249,3 +249,15 @@ def test_flop_model_matches_survey():
     assert abs(O.encoder_flops_per_utt(1000, 80, 256, 2048, 15, 12) / 1e9 - 22.351) < 0.01
     assert abs(O.encoder_flops_per_utt(200, 80, 144, 576, 15, 2) / 1e9 - 0.493) < 0.001
     assert abs(O.encoder_flops_per_utt(1000, 80, 512, 2048, 15, 17) / 1e9 - 78.256) < 0.01
+
+
+def test_ctc_head_oracle_matches_reference():
+    """CTCDecoder.forward of the reference (dropout 0) vs the oracle's restatement: Linear + log-softmax + alpha recursion."""
+    g, meta = load_golden("ctc_head")
+    for c in meta["cases"]:
+        n = c["name"]
+        P = table(c["state"], c["wseed"])
+        enc_out = torch.from_numpy(synth.normal(c["xseed"], (c["B"], c["T"], c["D"]), 1.0))
+        loss, nll = O.ctc_head_loss(P, "", enc_out, g[n + "_enc_lens"], g[n + "_labels"], g[n + "_label_lens"])
+        assert np.allclose(nll, g[n + "_nll"], rtol=2e-5, atol=1e-4), (n, nll, g[n + "_nll"])
+        assert abs(loss - float(g[n + "_loss"][0])) <= 2e-5 * abs(float(g[n + "_loss"][0]))
