@@ -283,9 +283,10 @@ def test_dwconv_bn_silu(cfm, B, T, D, K, dt):
     assert y.dtype == dt and relerr(y.float(), ref) < tol
 
 
+@pytest.mark.parametrize("F", [80, 83, 40, 24, 7])           # F % 4 == 0: row-window kernel; otherwise the scattered-position kernel
 @pytest.mark.parametrize("B,T,C", [(2, 200, 144), (3, 83, 256), (1, 7, 8)])
-def test_conv1_relu(cfm, B, T, C):
-    x = rnd((B, T, 80), 60)
+def test_conv1_relu(cfm, B, T, C, F):
+    x = rnd((B, T, F), 60)
     w = rnd((C, 1, 3, 3), 61, 1 / 3)
     b = rnd((C,), 62, 0.1)
     w9c = w.reshape(C, 9).t().contiguous()
