@@ -244,6 +244,14 @@ def main():
                         "launches_per_step": e["calls"] // args.steps, "avg_launch_us": round(avg_ms * 1e3, 2),
                         "share_of_device_time": round(e["ms"] / total_ms, 4),
                         "algorithmic_gflop_per_launch": round(e["flops"] / e["calls"] / 1e9, 3)}
+            if name.startswith("chain_macaron") or name.startswith("chain_dwfinal") or name.startswith("chain_final"):
+                # what actually bounds the row chains: every CU streams the block's weights through its own
+                # vector-memory path, 64 B/clk/CU at the 2.4 GHz the MFMA peak is quoted at
+                D, FF = CFG2["encoder_dim"], CFG2["hidden_dim"]
+                wbytes = 2 * (2 * D * FF + (3 * D * D if name.startswith("chain_macaron") else D * D))
+                floor_us = wbytes / 64.0 / 2.4e9 * 1e6
+                roofline["weight_stream"] = {"bytes_per_cu_per_launch": wbytes, "path_peak": "64 B/clk/CU", "floor_us": round(floor_us, 2),
+                                             "frac": round(floor_us / (avg_ms * 1e3), 4)}
         flops_step = O.encoder_flops_per_utt(T, 80, CFG2["encoder_dim"], CFG2["hidden_dim"], CFG2["kernel_size"],
                                              CFG2["encoder_num_layers"]) * B
         if args.all_kernels:
