@@ -61,7 +61,7 @@ class ConformerEncoderLayer(nn.Module):
     def _weights(self, prec):
         if self._plist is None:
             self._plist = [t for t in list(self.parameters()) + list(self.buffers())]
-        key = (prec.name,) + tuple(t._version for t in self._plist)
+        key = (prec.name,) + tuple((t.data_ptr(), t._version) for t in self._plist)   # in-place updates bump _version; `p.data = ...` moves the pointer
         if self._fused is None or self._fused[0] != key:
             struct, keep = packing.layer_weight_struct(self, prec)
             self._fused = (key, struct, keep)

@@ -458,6 +458,30 @@ def test_ctc_nll_edge_cases(pkg):
     assert torch.allclose(nll[ok].double(), ref[ok], rtol=1e-5, atol=1e-4), (nll, ref)
 
 
+def test_weight_packs_follow_parameter_updates(pkg):
+    """The packed copies must follow every way a checkpoint / optimizer changes the parameters: in-place copy (load_state_dict,
+    optimizer steps), replacement of .data, moving the module between devices and back."""
+    g, meta = load_golden("enc_cfg1")
+    pkg.cfm.set_precision("fp32")
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    x = dev(synth.fbank(meta["xseed"], meta["batch"], meta["frames"]))
+    lens = torch.tensor(meta["lens"], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        y0, _ = enc(x, lens)
+        other = build_encoder(pkg, meta["cfg"], meta["wseed"] + 1)
+        y_other, _ = other(x, lens)
+        assert relerr(y0, y_other) > 1e-2                              # different weights, different output
+        enc.load_state_dict(other.state_dict())                        # in-place copy_
+        assert torch.equal(enc(x, lens)[0], y_other)
+        for p_dst, p_src in zip(enc.parameters(), build_encoder(pkg, meta["cfg"], meta["wseed"]).parameters()):
+            p_dst.data = p_src.data.clone()                            # pointer swap, version counters untouched
+        for b_dst, b_src in zip(enc.buffers(), build_encoder(pkg, meta["cfg"], meta["wseed"]).buffers()):
+            b_dst.data = b_src.data.clone()
+        assert torch.equal(enc(x, lens)[0], y0)
+        enc = enc.cpu().to(DEV)                                         # round trip through host memory
+        assert torch.equal(enc(x, lens)[0], y0)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
