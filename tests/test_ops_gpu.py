@@ -181,7 +181,8 @@ def attn_reference(q, k, v, p, u, vb, mask, scale):
     return o.permute(0, 2, 1, 3).reshape(q.size(0), q.size(1), -1)
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk,dk", [(32, 4, 249, 249, 64), (2, 4, 49, 49, 36), (1, 4, 16, 80, 36), (3, 8, 70, 130, 64), (2, 2, 5, 5, 8)])
+@pytest.mark.parametrize("B,H,Tq,Tk,dk", [(32, 4, 249, 249, 64), (2, 4, 49, 49, 36), (1, 4, 16, 80, 36), (3, 8, 70, 130, 64), (2, 2, 5, 5, 8),
+                                          (2, 4, 411, 411, 64), (1, 4, 16, 700, 64), (2, 4, 300, 257, 64), (1, 2, 33, 513, 36)])   # > 256 keys: several super-tiles
 @pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("pos", ["none", "broadcast", "perkey"])
 @pytest.mark.parametrize("masking", ["none", "pad", "full"])
