@@ -483,6 +483,30 @@ def test_weight_packs_follow_parameter_updates(pkg):
         assert torch.equal(enc(x, lens)[0], y0)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_streaming_dk64_long_cache_against_oracle(pkg, mode):
+    """Streaming with the config-2 head shape (d=256, h=4, d_k=64: the v2 attention kernel reading an f32 KV cache) and an UNBOUNDED
+    left context that grows past 256 keys (several attention super-tiles), chunk by chunk against the oracle's restatement of
+    encoder.py:125-153; then 3 streams in lockstep against the single-stream result."""
+    from oracle import conformer_oracle as O
+    pkg.cfm.set_precision(mode)
+    cfg = dict(input_dim=80, kernel_size=15, encoder_dim=256, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+               hidden_dim=2048, num_heads=4, encoder_num_layers=2, max_len=5000, use_relative=True)
+    enc = build_encoder(pkg, cfg, 55)
+    frames, chunk = 1300, 16
+    x = dev(synth.fbank(56, 3, frames))
+    with torch.no_grad():
+        y1, _ = enc.forward_chunk_by_chunk(x[:1], chunk, -1)
+        y3, _ = enc.forward_chunk_by_chunk(x, chunk, -1)
+    assert y1.size(1) > 256                                   # the last chunks attend to more than 256 cached keys
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    y_ref = O.encoder_forward_chunk_by_chunk(P, O.Config(**cfg), x[:1].cpu(), chunk, -1)
+    check("streaming d_k=64, unbounded cache (%d frames out)" % y1.size(1), y1, y_ref, mode)
+    assert torch.equal(y3[:1], y1)
+    y_ref2 = O.encoder_forward_chunk_by_chunk(P, O.Config(**cfg), x[2:3].cpu(), chunk, -1)
+    check("streaming d_k=64, stream 3 of 3 in lockstep", y3[2:3], y_ref2, mode)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
