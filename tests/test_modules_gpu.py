@@ -329,6 +329,7 @@ def test_config4_encoder_shape_against_oracle(pkg, mode):
     (320, 5, 1280, 15, 2, 1, 75, [75]),            # batch 1, width between the chain instances
     (384, 6, 1024, 15, 1, 4, 64, [64, 64, 33, 9]), # very short utterance in the batch (T'=1 .. 15)
     (256, 8, 1024, 15, 2, 2, 120, [120, 77]),      # d=256 but dk=32 and FF=1024: no chain instance for this FF
+    (144, 4, 576, 15, 2, 3, 90, [90, 5, 0]),       # utterances with NO valid output frame (fully masked attention rows, quirk Q2)
     (256, 4, 2048, 15, 2, 2, 1650, [1650, 1203]),  # config 3's longest utterance: T' = 411 > 256 keys (several attention super-tiles), row chains
 ])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
