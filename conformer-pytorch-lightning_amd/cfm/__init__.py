@@ -65,7 +65,7 @@ class RowChainDesc(ctypes.Structure):
                 ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p), ("ln2_b", c_p), ("out_f32", c_p), ("out16", c_p),
                 ("tail_w", c_p), ("tail_b", c_p), ("tail_out", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32),
                 ("tail_N", c_i32), ("tail_glu", c_i32), ("w_dtype", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float),
-                ("palpha", ctypes.c_float), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32)]
+                ("palpha", ctypes.c_float), ("out2_f32", c_p), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32)]
 
 
 _LAYER_W_FIELDS = [
@@ -90,7 +90,7 @@ class LayerIO(ctypes.Structure):
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64),
                 ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32), ("pending_in", c_i32), ("defer_final", c_i32), ("pend_b2", c_p), ("pend_ln_g", c_p), ("pend_ln_b", c_p),
                 ("pos_proj", c_p), ("pos_proj_ld", c_i64),
-                ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p), ("pos_shared", c_i32)]
+                ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p), ("after_g", c_p), ("after_b", c_p), ("after_out", c_p), ("pos_shared", c_i32)]
 
 
 _lib = None

@@ -80,6 +80,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
                         w->pw2_wf && cfm_rowchain_supported(D, FF);
     // ---- partial-FFN pipeline (ffnpart.hip): each CU streams HALF of an FFN's weights for 64 rows ---------------------
     const bool parts = chains && w->ffm_w2f && w->ff_w2f && s->xs2 && s->yp0 && s->yp1 && s->yq0 && s->yq1 && cfm_ffn_partial_supported(D, FF);
+    CFM_CHECK_ARG(!io->after_out || (chains && !parts && io->after_g && io->after_b), "encoder layer: after_out is honoured by the row-chain path only");
     CFM_CHECK_ARG(!io->pending_in || parts, "encoder layer: pending_in needs the partial-FFN pipeline (scratch slabs)");
     CFM_CHECK_ARG(!io->defer_final || parts, "encoder layer: defer_final needs the partial-FFN pipeline (scratch slabs)");
     if (parts) {
@@ -187,6 +188,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         if (dw_fused) { fi.dw_w = w->dw_w; fi.dw_b = w->dw_b; fi.dw_scale = w->bn_scale; fi.dw_shift = w->bn_shift; fi.dw_T = io->T; fi.dw_K = 15; } fi.head_b = w->pw2_b; fi.head_res = x_out; fi.head_mask = io->pad_valid;
         fi.ln_g = w->ln_ff_g; fi.ln_b = w->ln_ff_b; fi.w1f = w->ff_w1f; fi.w2n = w->ff_w2n; fi.b1 = w->ff_b1; fi.b2 = w->ff_b2;
         fi.ln1_g = w->ln_final_g; fi.ln1_b = w->ln_final_b; fi.out_f32 = x_out;
+        if (io->after_out) { fi.ln2_g = io->after_g; fi.ln2_b = io->after_b; fi.out2_f32 = io->after_out; }   // encoder.py:74 in the same launch
         fi.M = M; fi.D = D; fi.FF = FF; fi.w_dtype = c.w_dt; fi.alpha = 0.5f; fi.eps = eps;
         return cfm_rowchain(&fi, stream);
     }

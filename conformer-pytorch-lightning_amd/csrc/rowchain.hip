@@ -62,6 +62,7 @@ struct ChainArgs {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     float* out_f32;
     void* out16;
+    float* out2_f32;          // optional f32 copy of y2 = LN2(y1) (the encoder's after_norm on top of the last block's norm_final)
     const u16* tail_w;        // fragment-major [tail_N/16][KS][64][8]
     const float* tail_b;
     void* tail_out;           // 16-bit [M, tail_N] (GLU: [M, tail_N/2])
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                         const u32x2 pk = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
                         if constexpr (TAIL) *(u32x2*)(xn + r * XN_STRIDE + c) = pk;   // the tail's input tile
                         if (c < D && grow < a.M && a.out16) *(u32x2*)((u16*)a.out16 + grow * D + c) = pk;
+                        if (c < D && grow < a.M && a.out2_f32) *(f32x4*)(a.out2_f32 + grow * D + c) = o;
                     }
                 }
         }
@@ -708,7 +710,7 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     a.dw_w = d->dw_w; a.dw_b = d->dw_b; a.dw_scale = d->dw_scale; a.dw_shift = d->dw_shift; a.dw_T = d->dw_T;
     a.head_mask = d->head_mask; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_mask = d->ln_mask; a.w1f = (const u16*)d->w1f; a.w2n = (const u16*)d->w2n;
     a.b1 = d->b1; a.b2 = d->b2; a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32;
-    a.out16 = d->out16; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M;
+    a.out16 = d->out16; a.out2_f32 = d->out2_f32; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M;
     a.tail_N = d->tail_N; a.out16_dtype = d->w_dtype; a.alpha = d->alpha; a.eps = d->eps;
     a.py0 = d->py0; a.py1 = d->py1; a.pb2 = d->pb2; a.pln_g = d->pln_g; a.pln_b = d->pln_b; a.palpha = d->palpha;
     CFM_CHECK_ARG(!d->py0 || (d->py1 && d->pb2 && !head), "cfm_rowchain: the reduce input needs both slabs and the bias, and no head");

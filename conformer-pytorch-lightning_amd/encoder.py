@@ -43,10 +43,11 @@ class ConformerEncoder(nn.Module):
         self.static_chunk_size = static_chunk_size
 
     # ------------------------------------------------------------------------------------------------------------
-    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from, pos_shared=False):
+    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from, pos_shared=False, proj=None):
         """x (B,T',D) f32 -> after_norm(blocks(x)); returns (y, [trimmed per-layer caches] | None)."""
         n = len(self.encoders)
-        proj = self._project_positions(pos_embed, x)
+        if proj is None:
+            proj = self._project_positions(pos_embed, x)
         bufs = [torch.empty_like(x), torch.empty_like(x)]
         new_caches = [] if caches is not None else None
         cur, ready = x, False
@@ -54,6 +55,10 @@ class ConformerEncoder(nn.Module):
         handover = (self.encoders[0]._use_partial_ffn and cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
                     bool(cfm.lib().cfm_ffn_partial_supported(self.encoder_dim, self.encoders[0].hidden_dim)))
         pending = None
+        # after_norm rides in the last block's final chain when that block runs on the row chains (one launch less)
+        fuse_after = (not handover and cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
+                      self.after_norm.weight.dtype == torch.float32 and self.after_norm.eps == 1e-5)
+        y_after = torch.empty_like(x) if fuse_after else None
         for i, block in enumerate(self.encoders):
             nxt = self.encoders[i + 1].norm_ff_macaron if i + 1 < n else None
             cache_i = None
@@ -64,11 +69,15 @@ class ConformerEncoder(nn.Module):
             pp = None if proj is None else (proj[:, i * self.encoder_dim:], proj.stride(0))
             out, nc = block.fused_forward(cur, attn_mask, pos_embed, pad_mask, cache_i, xn_ready=ready, next_norm=nxt,
                                           out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pending=pending,
-                                          defer_final=handover and i + 1 < n, pos_shared=pos_shared)
+                                          defer_final=handover and i + 1 < n, pos_shared=pos_shared,
+                                          after=(self.after_norm.weight.detach(), self.after_norm.bias.detach(), y_after)
+                                          if fuse_after and i + 1 == n else None)
             pending = block.pending_handover(prec) if handover and i + 1 < n else None
             if new_caches is not None:
                 new_caches.append(nc[:, :, keep_from:, :])
             cur, ready = out, nxt is not None
+        if fuse_after:
+            return y_after, new_caches
         y, _ = cfm.layernorm(cur.view(-1, cur.size(-1)), self.after_norm.weight.detach(), self.after_norm.bias.detach(),
                              eps=self.after_norm.eps)
         return y.view_as(cur), new_caches
@@ -110,6 +119,8 @@ class ConformerEncoder(nn.Module):
         x, pos_embed = self.position_encoding(x, 0)
         # (~make_pad_mask(len, T))[:, None, :][:, :, 2::2][:, :, 2::2]  ==  (6 + 4 j < len), built in one launch
         pad_mask = cfm.valid_mask(input_lengths, x.size(1), first=6, stride=4).unsqueeze(1)
+        # (Tried: positional projection + mask on a side stream beside the front-end.  Under graph replay the fork/join costs more
+        # than the ~11 us it hides and the concurrent kernels slow the first convolution: 1.697 vs 1.668 ms per step.)
         attn_mask = make_attn_mask(x, pad_mask, self.use_dynamic_chunk_size, self.use_dynamic_left_chunk,
                                    decoding_chunk_size, self.static_chunk_size, num_decoding_chunk_size)
         y, _ = self._run_blocks(x, attn_mask, pos_embed, pad_mask, None, 0)

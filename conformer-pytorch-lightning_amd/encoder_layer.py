@@ -68,7 +68,7 @@ class ConformerEncoderLayer(nn.Module):
         return self._fused[1]
 
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
-                      want_cache=True, pos_proj=None, pending=None, defer_final=False, pos_shared=False):
+                      want_cache=True, pos_proj=None, pending=None, defer_final=False, pos_shared=False, after=None):
         """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified."""
         _inference_only(self, "ConformerEncoderLayer")
         if self.training:
@@ -133,6 +133,8 @@ class ConformerEncoderLayer(nn.Module):
             io.pos_proj, io.pos_proj_ld = pos_proj[0].data_ptr(), pos_proj[1]
         io.attn_cache, io.cache_T = cfm.ptr(cache), Tc
         io.pos_shared = 1 if pos_shared else 0
+        if after is not None:                          # (gain, bias, f32 output [B,T,D]): the encoder's after_norm in the final chain
+            io.after_g, io.after_b, io.after_out = after[0].data_ptr(), after[1].data_ptr(), after[2].data_ptr()
         io.new_cache = cfm.ptr(new_cache)
         if pending is not None:                        # (w_2.bias f32, norm_final) of the PREVIOUS block: its last FFN is unfinished
             io.pending_in = 1

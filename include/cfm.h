@@ -162,6 +162,8 @@ typedef struct {
     int32_t D, FF, tail_N, tail_glu;
     int32_t w_dtype;
     float alpha, eps, palpha;
+    float* out2_f32; /* optional f32 [M,D]: y2 = LN2(y1) as well (ln2_g required) -- e.g. the encoder's after_norm (encoder.py:74) applied to
+                        the last block's output in the same launch */
     /* optional depthwise input stage of the "final" chain (head + feed-forward, no tail): head_a is the GLU output and
      *   a = SiLU( (DepthwiseConv15(head_a) + dw_b) * dw_scale + dw_shift )      rows [B, dw_T] flattened, zero padding at
      * utterance edges -- exactly cfm_dwconv_bn_silu (convolution.py:43-45) without its launch and its round trip. */
@@ -346,6 +348,9 @@ typedef struct {
     const float* attn_cache;  /* f32 [B,H,Tc,2dk] or NULL */
     int32_t cache_T;
     float* new_cache;         /* f32 [B,H,Tc+T,2dk] or NULL (not materialised) */
+    const float *after_g, *after_b; /* optional, chain path only: ALSO write LN(x_out; after_g, after_b) to after_out (f32 [B*T,D]) -- the
+                                       encoder's after_norm fused into the last block's final chain */
+    float* after_out;
     int32_t pos_shared;       /* 1: the pos_rows == Tk positional rows are the SAME for every batch item (batched streaming step: all
                                  streams at one offset).  Beyond the reference, whose forward_chunk only works at batch 1
                                  (attention.py:78-88); per item it equals that batch-1 call. */
