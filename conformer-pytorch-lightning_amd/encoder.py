@@ -126,12 +126,14 @@ class ConformerEncoder(nn.Module):
         y, _ = self._run_blocks(x, attn_mask, pos_embed, pad_mask, None, 0)
         return y.to(inputs.dtype), pad_mask
 
-    def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK):
+    def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None):
         """One streaming step.  Batch 1 as in the reference: attn_cache (L,H,Tc,2dk) or empty; returns (chunk output, new attn
         cache (L,H,Tc',2dk), cnn cache (L,0,0,0) -- the reference keeps no conv context).
         Batch B > 1 (beyond the reference, whose forward_chunk only works at batch 1: SURVEY 8 row S): B streams in lockstep at
         the same `offset`, attn_cache (L,B,H,Tc,2dk) or empty, returned cache (L,B,H,Tc',2dk); item b of the result equals the
-        batch-1 call on inputs[b:b+1] with attn_cache[:, b]."""
+        batch-1 call on inputs[b:b+1] with attn_cache[:, b].
+        pos_rows (cached + chunk, 1, D): the positional rows for this step in a caller-owned buffer instead of a slice taken at `offset`
+        (StreamingSession replays one captured graph per step and refreshes that buffer between replays)."""
         inputs, cmvn = self._cmvn_args(inputs)
         cfm.require_hip(inputs)
         dev = inputs.device
@@ -144,7 +146,9 @@ class ConformerEncoder(nn.Module):
             raise RuntimeError("forward_chunk with %d streams needs attn_cache of shape (L,B,H,Tc,2dk)" % inputs.size(0))
         cached = attn_cache.size(-2) if have else 0
         span = cached + x.size(1)
-        pos_embed = self.embed.position_encoding(offset=offset - cached, size=span)
+        pos_embed = pos_rows if pos_rows is not None else self.embed.position_encoding(offset=offset - cached, size=span)
+        if pos_embed.size(0) != span:
+            raise RuntimeError("forward_chunk: %d positional rows for %d keys" % (pos_embed.size(0), span))
         if required_cache_size < 0:
             keep_from = 0
         elif required_cache_size == 0:
@@ -173,3 +177,64 @@ class ConformerEncoder(nn.Module):
             offset += y.size(1)
         out = torch.cat(pieces, 1)
         return out, torch.ones((out.size(0), 1, out.size(1)))
+
+
+class StreamingSession:
+    """B streams advanced in lockstep, chunk by chunk, with ONE captured HIP graph per steady-state step.
+
+    The eager streaming step is launch-bound (~70 launches for a 16-frame chunk).  Once the left-context cache is full every step has
+    the same shapes, so the step is captured once -- static buffers for the feature window, the positional rows and the KV cache,
+    the new cache copied back into the static one inside the graph -- and replayed; only the window and the positional rows are
+    refreshed between replays.  Results are those of ConformerEncoder.forward_chunk (bit for bit: the same kernels on the same data).
+    `step` returns a buffer that the next step overwrites."""
+
+    def __init__(self, encoder, decoding_chunk_size, num_decoding_left_chunks):
+        if num_decoding_left_chunks <= 0:
+            raise ValueError("StreamingSession needs a bounded left context (num_decoding_left_chunks > 0): the step shapes must settle")
+        self.enc = encoder
+        self.chunk = decoding_chunk_size
+        self.need = decoding_chunk_size * num_decoding_left_chunks
+        self.window = (decoding_chunk_size - 1) * 4 + 7
+        self.hop = 4 * decoding_chunk_size
+        self.offset = 0
+        self.cache = None
+        self.graph = None
+
+    def step(self, frames):
+        """frames (B, window, F) on the GPU -> (B, chunk, D)."""
+        if frames.size(1) != self.window:
+            raise ValueError("StreamingSession.step wants windows of %d frames" % self.window)
+        dev = frames.device
+        empty = torch.zeros((0, 0, 0, 0), device=dev)
+        if self.graph is None:
+            cache = self.cache if self.cache is not None else empty
+            y, self.cache, _ = self.enc.forward_chunk(frames, self.offset, self.need, cache, empty)
+            self.offset += y.size(1)
+            if self.cache.size(-2) == self.need:
+                self._capture(frames)
+            return y
+        self.x.copy_(frames)
+        self.pos.copy_(self.enc.embed.position_encoding(offset=self.offset - self.need, size=self.need + self.chunk))
+        self.graph.replay()
+        self.offset += self.chunk
+        return self.y
+
+    def _capture(self, frames):
+        enc, dev = self.enc, frames.device
+        empty = torch.zeros((0, 0, 0, 0), device=dev)
+        self.x = frames.clone()
+        self.kv = self.cache.clone()
+        self.pos = enc.embed.position_encoding(offset=self.offset - self.need, size=self.need + self.chunk).clone()
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(stream):
+            enc.forward_chunk(self.x, self.offset, self.need, self.kv, empty, pos_rows=self.pos)      # sizes the scratch arena
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                y, new_kv, _ = enc.forward_chunk(self.x, self.offset, self.need, self.kv, empty, pos_rows=self.pos)
+                self.kv.copy_(new_kv)
+            self.y = y
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        self.kv.copy_(self.cache)                                  # the capture pass and its warm-up advanced the static cache: restore
+        self.graph = graph

@@ -25,3 +25,18 @@ steady = sorted(times[10:])
 ms = 1e3 * steady[len(steady) // 2]
 print("streams %d  chunk %d  cache %s: %.3f ms per step (median of steady state, eager launches) = %.0f input frames/s over all streams (%.1f x real time per stream at 10 ms frames)"
       % (B, chunk, tuple(cache.shape), ms, B * hop / (ms * 1e-3), hop * 10.0 / ms))
+
+# ---- the same steps through encoder.StreamingSession: one captured HIP graph per steady-state step
+import encoder as enc_mod
+sess = enc_mod.StreamingSession(enc, chunk, left)
+times = []
+with torch.no_grad():
+    for step in range(40):
+        win = x[:, step * hop: step * hop + window].contiguous()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y = sess.step(win)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+steady = sorted(times[12:])
+ms = 1e3 * steady[len(steady) // 2]
+print("streams %d  graph session: %.3f ms per step (median of replayed steps) = %.0f input frames/s over all streams (%.1f x real time per stream)"
+      % (B, ms, B * hop / (ms * 1e-3), hop * 10.0 / ms))

@@ -508,6 +508,29 @@ def test_streaming_dk64_long_cache_against_oracle(pkg, mode):
     check("streaming d_k=64, stream 3 of 3 in lockstep", y3[2:3], y_ref2, mode)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_streaming_session_graph_equals_eager(pkg, mode):
+    """encoder.StreamingSession (one captured HIP graph per steady-state step) against the eager forward_chunk loop it wraps: same
+    kernels on the same data, so bit for bit, through the warm-up steps, the capture step and the replayed steps."""
+    g, meta = load_golden("enc_cfg1_stream")
+    pkg.cfm.set_precision(mode)
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    B, chunk, left, steps = 4, 4, 2, 9
+    hop, window, need = 4 * chunk, (chunk - 1) * 4 + 7, chunk * left
+    x = dev(synth.fbank(91, B, window + hop * steps))
+    empty = torch.zeros((0, 0, 0, 0), device=DEV)
+    sess = pkg.encoder.StreamingSession(enc, chunk, left)
+    with torch.no_grad():
+        cache, offset = empty, 0
+        for s in range(steps):
+            win = x[:, s * hop: s * hop + window].contiguous()
+            y_ref, cache, _ = enc.forward_chunk(win, offset, need, cache, empty)
+            offset += y_ref.size(1)
+            y = sess.step(win)
+            assert torch.equal(y, y_ref), (s, relerr(y, y_ref))
+        assert sess.graph is not None and sess.offset == offset and torch.equal(sess.kv, cache)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
