@@ -80,7 +80,12 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
                         w->pw2_wf && cfm_rowchain_supported(D, FF);
     // ---- partial-FFN pipeline (ffnpart.hip): each CU streams HALF of an FFN's weights for 64 rows ---------------------
     const bool parts = chains && w->ffm_w2f && w->ff_w2f && s->xs2 && s->yp0 && s->yp1 && s->yq0 && s->yq1 && cfm_ffn_partial_supported(D, FF);
-    CFM_CHECK_ARG(!io->after_out || (chains && !parts && io->after_g && io->after_b), "encoder layer: after_out is honoured by the row-chain path only");
+    CFM_CHECK_ARG(!io->after_out || (!parts && io->after_g && io->after_b), "encoder layer: after_out needs after_g / after_b and is not available in the partial-FFN pipeline");
+    // after_out outside the chain path: one more LayerNorm launch at the end (same result, nothing fused)
+    auto after_tail = [&]() -> int {
+        if (!io->after_out) return CFM_OK;
+        return cfm_layernorm(x_out, io->after_g, io->after_b, io->after_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, eps, M, D, stream);
+    };
     CFM_CHECK_ARG(!io->pending_in || parts, "encoder layer: pending_in needs the partial-FFN pipeline (scratch slabs)");
     CFM_CHECK_ARG(!io->defer_final || parts, "encoder layer: defer_final needs the partial-FFN pipeline (scratch slabs)");
     if (parts) {
@@ -201,9 +206,11 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, io->pad_valid));
 
     // (4) feed-forward + (5) norm_final: in place on x_out (a workgroup reads its 32 rows completely before writing them)
-    if (fused_ffn)
-        return ffn_fused(c, x_out, w->ln_ff_g, w->ln_ff_b, w->ff_w1f, w->ff_w2f, w->ff_b1, w->ff_b2, w->ln_final_g, w->ln_final_b,
-                         nullptr, nullptr, x_out, nullptr);
+    if (fused_ffn) {
+        CFM_TRY(ffn_fused(c, x_out, w->ln_ff_g, w->ln_ff_b, w->ff_w1f, w->ff_w2f, w->ff_b1, w->ff_b2, w->ln_final_g, w->ln_final_b,
+                          nullptr, nullptr, x_out, nullptr));
+        return after_tail();
+    }
     CFM_TRY(cfm_layernorm(x_out, w->ln_ff_g, w->ln_ff_b, nullptr, 0, nullptr, nullptr, s->xn, adt, nullptr, eps, M, D, stream));
     CFM_TRY(gemm(c, s->xn, adt, D, w->ff_w1, w->ff_w1_lo, w->ff_b1, s->hid, adt, FF, M, FF, D, CFM_ACT_SILU, nullptr, 0.f, nullptr));
     CFM_TRY(gemm(c, s->hid, adt, FF, w->ff_w2, w->ff_w2_lo, w->ff_b2, x_out, CFM_F32, D, M, D, FF, CFM_ACT_NONE, x_out, 0.5f, nullptr));
@@ -213,5 +220,5 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         CFM_TRY(cfm_layernorm(x_out, w->ln_final_g, w->ln_final_b, x_out, CFM_F32, next_g, next_b, s->xn, adt, nullptr, eps, M, D, stream));
     else
         CFM_TRY(cfm_layernorm(x_out, w->ln_final_g, w->ln_final_b, x_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, eps, M, D, stream));
-    return CFM_OK;
+    return after_tail();
 }

@@ -531,6 +531,26 @@ def test_streaming_session_graph_equals_eager(pkg, mode):
         assert sess.graph is not None and sess.offset == offset and torch.equal(sess.kv, cache)
 
 
+def test_general_path_matches_chain_path_including_after_norm(pkg):
+    """cfm_encoder_layer_forward picks the row chains when every fragment-major pack is present; with those packs withheld the same
+    block runs on the general path (separate GEMMs, LayerNorm and depthwise kernels).  Both must agree, including the encoder's
+    after_norm riding in the last block (fused into the final chain on one path, an extra LayerNorm launch on the other)."""
+    pkg.cfm.set_precision("fp32" if False else "bf16")
+    enc = build_encoder(pkg, CFG2 | dict(encoder_num_layers=2), 77)
+    x = dev(synth.fbank(78, 3, 300))
+    lens = torch.tensor([300, 211, 120], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        y_chain, m = enc(x, lens)
+        for blk in enc.encoders:                                   # withhold the packs on the cached weight structs
+            w = blk._weights(pkg.cfm.get_precision())
+            for f in ("ffm_w1f", "ffm_w2f", "ff_w1f", "ff_w2f", "ffm_w2n", "ff_w2n", "qkv_wf", "out_wf", "pw1_wf", "pw2_wf"):
+                setattr(w, f, None)
+        y_general, m2 = enc(x, lens)
+    assert torch.equal(m, m2)
+    assert relerr(y_general, y_chain) < 2e-2                        # bf16: different kernels, different rounding points
+    assert relerr(y_general, y_chain) > 0                           # ... and it really was another path
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
