@@ -329,6 +329,8 @@ def test_config4_encoder_shape_against_oracle(pkg, mode):
     (320, 5, 1280, 15, 2, 1, 75, [75]),            # batch 1, width between the chain instances
     (384, 6, 1024, 15, 1, 4, 64, [64, 64, 33, 9]), # very short utterance in the batch (T'=1 .. 15)
     (256, 8, 1024, 15, 2, 2, 120, [120, 77]),      # d=256 but dk=32 and FF=1024: no chain instance for this FF
+    (256, 4, 2048, 31, 2, 2, 150, [150, 99]),      # row chains with a 31-tap depthwise conv: NOT fused into the final chain
+    (144, 4, 576, 7, 2, 2, 110, [110, 64]),        # same at d=144 with 7 taps
     (144, 4, 576, 15, 2, 3, 90, [90, 5, 0]),       # utterances with NO valid output frame (fully masked attention rows, quirk Q2)
     (256, 4, 2048, 15, 2, 2, 1650, [1650, 1203]),  # config 3's longest utterance: T' = 411 > 256 keys (several attention super-tiles), row chains
 ])
