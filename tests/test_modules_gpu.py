@@ -553,6 +553,28 @@ def test_general_path_matches_chain_path_including_after_norm(pkg):
     assert relerr(y_general, y_chain) > 0                           # ... and it really was another path
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_chunked_attention_masks_d256_against_oracle(pkg, mode):
+    """Chunk masks (B,T',T') at the config-2 width: dynamic chunk 8 with 3 left chunks, full context, and a static chunk size, ragged
+    batch -- the full-mask attention variant behind the row chains, against the oracle (the d=144 variants are pinned by goldens)."""
+    from oracle import conformer_oracle as O
+    pkg.cfm.set_precision(mode)
+    base = dict(input_dim=80, kernel_size=15, encoder_dim=256, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+                hidden_dim=2048, num_heads=4, encoder_num_layers=2, max_len=5000, use_relative=True)
+    x = dev(synth.fbank(61, 2, 420))
+    lens = [420, 333]
+    lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    for extra, fw in ((dict(use_dynamic_chunk_size=True), (8, 3)), (dict(use_dynamic_chunk_size=True), (-1, -1)), (dict(static_chunk_size=5), (0, -1))):
+        cfg = dict(base, **extra)
+        enc = build_encoder(pkg, base, 62, **extra)
+        with torch.no_grad():
+            y, m = enc(x, lt, fw[0], fw[1])
+        P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+        y_ref, m_ref = O.encoder_forward(P, O.Config(**cfg), x.cpu(), lens, fw[0], fw[1])
+        assert np.array_equal(m.cpu().numpy(), np.asarray(m_ref))
+        check("d=256 chunk masks %s %s" % (extra, fw), y, y_ref, mode)
+
+
 def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
