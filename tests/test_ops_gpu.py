@@ -386,7 +386,7 @@ def test_ffn_fused(cfm, M, D, FF, wdt, act):
     assert torch.equal(o32, o32b)
 
 
-@pytest.mark.parametrize("M,D,FF", [(7968, 256, 2048), (98, 144, 576), (33, 256, 2048)])
+@pytest.mark.parametrize("M,D,FF", [(7968, 256, 2048), (98, 144, 576), (33, 256, 2048), (1, 256, 2048), (31, 144, 576), (32, 256, 2048)])
 @pytest.mark.parametrize("wdt", ["bf16", "fp16"])
 def test_rowchain_three_roles(cfm, M, D, FF, wdt):
     """The macaron / conv-in / final chains of a conformer block, each one launch, against the same chain in torch."""
@@ -443,7 +443,7 @@ def test_rowchain_three_roles(cfm, M, D, FF, wdt):
     assert torch.equal(xi, xj)          # bitwise reproducible
 
 
-@pytest.mark.parametrize("B,T,D,FF", [(32, 249, 256, 2048), (3, 41, 144, 576), (2, 5, 256, 2048), (5, 32, 256, 2048)])
+@pytest.mark.parametrize("B,T,D,FF", [(32, 249, 256, 2048), (3, 41, 144, 576), (2, 5, 256, 2048), (5, 32, 256, 2048), (1, 1, 256, 2048), (4, 3, 144, 576)])
 @pytest.mark.parametrize("wdt", ["bf16", "fp16"])
 def test_rowchain_depthwise_input_stage(cfm, B, T, D, FF, wdt):
     """final chain with the depthwise conv + BatchNorm + SiLU (convolution.py:43-45) in its input stage == cfm_dwconv_bn_silu, then the
