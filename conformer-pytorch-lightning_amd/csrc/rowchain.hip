@@ -197,6 +197,38 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             for (int kk = 0; kk < KS1; ++kk) twr[nf * KS1 + kk] = twp[((int64_t)t_clamp(t_frag0(0) + nf) * KS1 + kk) * 64];
     };
 
+    // ---- requests of the LayerNorm phase, issued at kernel entry so that their latency hides behind the head GEMM / the FFN ring
+    //      fill: the wavefront's own rows (when they come from memory), the norm parameters, the pad-mask bytes
+    f32x4 xres[RPW][VPL];                                  // this wavefront's rows of x: the residual, kept in registers
+    int64_t ln_rows[RPW];
+    f32x4 ln_gam[VPL], ln_bet[VPL];
+    bool ln_keep[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int64_t gr = row0 + wave * RPW + rr;
+        ln_rows[rr] = gr < a.M ? gr : a.M - 1;
+        ln_keep[rr] = true;
+        if constexpr (!HEAD) {
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                xres[rr][it] = c < D ? *(const f32x4*)(a.x + ln_rows[rr] * D + c) : zero4;
+            }
+        }
+    }
+    if (a.ln_g) {
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            ln_gam[it] = c < D ? *(const f32x4*)(a.ln_g + c) : zero4;
+            ln_bet[it] = c < D ? *(const f32x4*)(a.ln_b + c) : zero4;
+        }
+    }
+    if (a.ln_mask) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) ln_keep[rr] = a.ln_mask[ln_rows[rr]] != 0;
+    }
+
     // ================= HEAD: x = res + mask(A . Wh^T + bh) =====================================================
     if constexpr (HEAD) {
         const u32x4* wp = (const u32x4*)a.head_w + lane;
@@ -379,36 +411,18 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     }
 
     // ================= rows -> LN_in -> xn ======================================================================
-    f32x4 xres[RPW][VPL];                                  // this wavefront's rows of x: the residual, kept in registers
     {
-        int64_t grows[RPW];
+        int64_t (&grows)[RPW] = ln_rows;
+        f32x4 (&gam)[VPL] = ln_gam, (&bet)[VPL] = ln_bet;
+        bool (&keep)[RPW] = ln_keep;
+        if constexpr (HEAD) {                              // rows produced by the head GEMM: out of the f32 x tile in LDS
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {                 // all of this wavefront's rows are requested before any is used
-            const int r = wave * RPW + rr;
-            const int64_t gr = row0 + r;
-            grows[rr] = gr < a.M ? gr : a.M - 1;
+            for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-            for (int it = 0; it < VPL; ++it) {
-                const int c = (lane + 64 * it) * 4;
-                if constexpr (HEAD) xres[rr][it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : zero4;
-                else xres[rr][it] = c < D ? *(const f32x4*)(a.x + grows[rr] * D + c) : zero4;
-            }
-        }
-        f32x4 gam[VPL], bet[VPL];
-        bool keep[RPW];
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) keep[rr] = true;
-        if (a.ln_g) {
-#pragma unroll
-            for (int it = 0; it < VPL; ++it) {
-                const int c = (lane + 64 * it) * 4;
-                gam[it] = c < D ? *(const f32x4*)(a.ln_g + c) : zero4;
-                bet[it] = c < D ? *(const f32x4*)(a.ln_b + c) : zero4;
-            }
-        }
-        if (a.ln_mask) {
-#pragma unroll
-            for (int rr = 0; rr < RPW; ++rr) keep[rr] = a.ln_mask[grows[rr]] != 0;
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    xres[rr][it] = c < D ? *(const f32x4*)(xs + (wave * RPW + rr) * XS_STRIDE + c) : zero4;
+                }
         }
         if constexpr (!HEAD) {
             if (a.py0) {                                   // pending partial FFN of the previous kernel (+ its norm_final)
