@@ -132,7 +132,7 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
 #pragma unroll
         for (int it = 0; it < VPL; ++it)
             if ((lane + 64 * it) * 4 < D) s += (v[rr][it].x + v[rr][it].y) + (v[rr][it].z + v[rr][it].w);
-        mean[rr] = wave_sum(s) / (float)D;
+        mean[rr] = wave_sum(s) * (1.0f / (float)D);
     }
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
@@ -143,7 +143,7 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
                 const f32x4 d = v[rr][it] - mean[rr];
                 q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
-        rstd[rr] = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+        rstd[rr] = __builtin_amdgcn_rsqf(wave_sum(q) * (1.0f / (float)D) + eps);   // v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequences
     }
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr)
