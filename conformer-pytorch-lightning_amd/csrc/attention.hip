@@ -287,7 +287,7 @@ constexpr int MLSTR = SK + 4;  // mask row stride in bytes
 // 8 consecutive elements -> 16-bit x8.  The element type is a template argument: a run-time branch around each load makes the
 // compiler wait at every join, which serialised the 16 K/V loads of a thread (6 k cycles to ISSUE them, measured).
 template <typename HT, bool F32>
-__device__ __forceinline__ u32x4 load_row8(const void* base, int64_t off) {
+__device__ __forceinline__ u32x4 load_row8(const void* base, unsigned off) {
     if constexpr (F32) {
         const f32x4 a = *(const f32x4*)((const float*)base + off);
         const f32x4 b = *(const f32x4*)((const float*)base + off + 4);
@@ -330,6 +330,13 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
         if constexpr (PMODE == 1) praw[kk] = *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + h * dk + d0);
     }
     u32x4 kr[8], vr[8], pr[PMODE == 2 ? 8 : 1];
+    // (b, h) bases are wave-uniform (scalar 64-bit arithmetic); what varies per thread is a 32-bit element offset -- the host checks
+    // that Tk * stride fits.  The first version did three 64-bit VALU multiply-adds per load: 66 of them per thread.
+    using kv_t = std::conditional_t<KVF32, float, u16>;
+    const kv_t* const kbase = (const kv_t*)a.k + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh);
+    const kv_t* const vbase = (const kv_t*)a.v + ((int64_t)b * a.v_sb + (int64_t)h * a.v_sh);
+    const u16* const pbase = PMODE == 2 ? (const u16*)a.p + ((int64_t)b * a.p_sb + (int64_t)h * dk) : nullptr;
+    const unsigned kst = (unsigned)a.k_st, vst = (unsigned)a.v_st, pst = (unsigned)a.p_st;
     auto stage_load = [&](int ks) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -337,10 +344,10 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
             const int key = id >> 3, c = id & 7;
             const int kj = ks + key;
             const bool ok = kj < a.Tk;
-            const int64_t kc = ok ? kj : 0;
-            kr[i] = load_row8<HT, KVF32>(a.k, (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + kc * a.k_st + c * 8);
-            vr[i] = load_row8<HT, KVF32>(a.v, (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + kc * a.v_st + c * 8);
-            if constexpr (PMODE == 2) pr[i] = *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + kc * a.p_st + h * dk + c * 8);
+            const unsigned kc = ok ? (unsigned)kj : 0u;
+            kr[i] = load_row8<HT, KVF32>(kbase, kc * kst + c * 8);
+            vr[i] = load_row8<HT, KVF32>(vbase, kc * vst + c * 8);
+            if constexpr (PMODE == 2) pr[i] = *(const u32x4*)(pbase + (kc * pst + c * 8));
             if (!ok) {                                     // keys past Tk: clamped address, zeroed value (no branch around the load)
                 kr[i] = (u32x4){0u, 0u, 0u, 0u};
                 vr[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
     CFM_ASTAMP(3);
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? __builtin_amdgcn_rcpf(l_tot) : 0.f;
     if (qi < a.Tq) {
         const int64_t ob = ((int64_t)b * a.Tq + qi) * ((int64_t)a.H * dk) + (int64_t)h * dk;
 #pragma unroll
@@ -593,7 +600,8 @@ extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
     const bool al8 = (d->q_sb % 8 == 0) && (d->q_st % 8 == 0) && (d->k_sb % 4 == 0) && (d->k_st % 8 == 0) && (d->k_sh % 8 == 0) &&
                      (d->v_sb % 4 == 0) && (d->v_st % 8 == 0) && (d->v_sh % 8 == 0) && (!pos || ((d->p_sb % 8 == 0) && (d->p_st % 8 == 0)));
     if (!d->split && d->dk == 64 && d->q_dtype == d->mma_dtype && (!pos || d->p_dtype == d->mma_dtype) &&
-        (d->kv_dtype == d->mma_dtype || d->kv_dtype == CFM_F32) && al8 && !getenv("CFM_ATTN_V1")) {
+        (d->kv_dtype == d->mma_dtype || d->kv_dtype == CFM_F32) && al8 && !getenv("CFM_ATTN_V1") &&
+        (int64_t)d->Tk * d->k_st < ((int64_t)1 << 31) && (int64_t)d->Tk * d->v_st < ((int64_t)1 << 31) && (int64_t)d->Tk * d->p_st < ((int64_t)1 << 31)) {
         if (d->mma_dtype == CFM_BF16) return launch_attn2<BF16>(a, s, pos ? "attn2_rel_bf16" : "attn2_bf16");
         return launch_attn2<F16>(a, s, pos ? "attn2_rel_f16" : "attn2_f16");
     }
