@@ -39,7 +39,7 @@ int main() {
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    const int nb = 4 * H * B;
+    const int nb = 4 * H * B;   // (1-D grid of the same size when B*H is a multiple of 8)
     std::vector<long long> h(2048 * 8);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(cfm_attn_stamps), sizeof(long long) * 2048 * 8);
     printf("attention B=%d H=%d T=%d: %.2f us/launch back-to-back, %d workgroups\n", B, H, T, ms * 1000.f / reps, nb);
