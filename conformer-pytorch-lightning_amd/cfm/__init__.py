@@ -132,6 +132,7 @@ def lib():
         L.cfm_encoder_layer_forward.argtypes = [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerScratch),
                                                 ctypes.POINTER(LayerIO), c_p, c_p, c_i32, c_p, c_p, c_p]
         L.cfm_ctc_nll.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p]
+        L.cfm_joint_act.argtypes = [c_p, c_i64, c_p, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_prof_enable.argtypes = [c_i32]
         L.cfm_prof_enable.restype = None
         L.cfm_prof_reset.restype = None
@@ -140,7 +141,7 @@ def lib():
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_ffn_partial", "cfm_ffn_partial_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
-                     "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_prof_entry"):
+                     "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib

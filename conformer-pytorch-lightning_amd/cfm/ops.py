@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "ctc_nll", "valid_mask", "chunk_mask",
+__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -287,6 +287,20 @@ def ctc_nll(logits, V, enc_lens, labels, label_lens):
     work = scratch("ctc_lp", B * T * (2 * labels.size(1) + 1), torch.float32, logits.device)
     _c.check(_c.lib().cfm_ctc_nll(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
                                   _c.ptr(work), _c.ptr(out), _c.stream()), "cfm_ctc_nll")
+    return out
+
+
+def joint_act(enc, pred, B, T, U, out_dtype):
+    """tanh(enc[b*T+t] + pred[b*U+u]) for every (b,t,u) as a row-major [B*T*U, J] operand (include/cfm.h cfm_joint_act).
+    enc f32 [B*T,J], pred f32 [B*U,J] with unit inner stride."""
+    _c.require_hip(enc, pred)
+    enc, pred = _rows2d(enc, "joint_act(enc)"), _rows2d(pred, "joint_act(pred)")
+    J = enc.shape[1]
+    if enc.dtype != torch.float32 or pred.dtype != torch.float32 or tuple(enc.shape) != (B * T, J) or tuple(pred.shape) != (B * U, J):
+        raise ValueError("cfm.joint_act: enc must be f32 [%d,J] and pred f32 [%d,J], got %s %s" % (B * T, B * U, tuple(enc.shape), tuple(pred.shape)))
+    out = torch.empty((B * T * U, J), dtype=out_dtype, device=enc.device)
+    _c.check(_c.lib().cfm_joint_act(_c.ptr(enc), enc.stride(0), _c.ptr(pred), pred.stride(0), _c.ptr(out), _c.dt_code(out), B, T, U, J,
+                                    _c.stream()), "cfm_joint_act")
     return out
 
 

@@ -47,6 +47,7 @@ static inline bool cfm_is16(int dt) { return dt == CFM_BF16 || dt == CFM_F16; }
 // assumes that.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

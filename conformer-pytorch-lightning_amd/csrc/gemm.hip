@@ -286,8 +286,11 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int col = n0 + wc * (BN / 2) + j * 16 + q4;
-        bias_r[j] = (g.bias && col < g.N) ? *(const f32x4*)(g.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (g.bias && col + 3 < g.N) bias_r[j] = *(const f32x4*)(g.bias + col);
+        else if (g.bias && col + 1 < g.N) bias_r[j] = (f32x4){g.bias[col], g.bias[col + 1], 0.f, 0.f};   // N % 4 == 2: the last pair
+        else bias_r[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    const bool vec4 = (g.ldc & 3) == 0;                  // rows 16-byte aligned (f32) / 8-byte aligned (16 bit): one store per lane
     bool keep_r[FM];
     f32x4 res_r[FM][FN];
 #pragma unroll
@@ -336,12 +339,23 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             if (!keep && g.mask_mode == 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (g.res) v = res_r[i][j] + g.alpha * v;
             const int64_t o = (int64_t)row * g.ldc + ocol;
-            if (g.c_dtype == CFM_F32) {
-                *(f32x4*)((float*)g.C + o) = v;
-            } else if (g.c_dtype == CFM_BF16) {
-                *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])};
+            if (vec4 && col + 3 < g.N) {
+                if (g.c_dtype == CFM_F32) {
+                    *(f32x4*)((float*)g.C + o) = v;
+                } else if (g.c_dtype == CFM_BF16) {
+                    *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])};
+                } else {
+                    *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3])};
+                }
             } else {
-                *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3])};
+                // N or ldc only a multiple of 2 (a vocabulary of 5002 columns written with its own row stride): column PAIRS
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (col + 2 * h + 1 >= g.N) break;
+                    if (g.c_dtype == CFM_F32) *(f32x2*)((float*)g.C + o + 2 * h) = (f32x2){v[2 * h], v[2 * h + 1]};
+                    else if (g.c_dtype == CFM_BF16) *(unsigned*)((u16*)g.C + o + 2 * h) = pack2<BF16>(v[2 * h], v[2 * h + 1]);
+                    else *(unsigned*)((u16*)g.C + o + 2 * h) = pack2<F16>(v[2 * h], v[2 * h + 1]);
+                }
             }
         }
     }
@@ -395,14 +409,16 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d && d->A && d->W && d->C, "cfm_gemm: null pointer");
     CFM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "cfm_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
     CFM_CHECK_ARG(d->K % 8 == 0, "cfm_gemm: K=%d must be a multiple of 8", d->K);
-    CFM_CHECK_ARG(d->N % 4 == 0, "cfm_gemm: N=%d must be a multiple of 4", d->N);
+    CFM_CHECK_ARG(d->N % 2 == 0, "cfm_gemm: N=%d must be a multiple of 2", d->N);
+    const bool n4 = d->N % 4 == 0 && d->ldc % 4 == 0;    // otherwise: pair stores, and no epilogue that reads 4-column vectors
+    CFM_CHECK_ARG(n4 || (!d->residual && d->act != CFM_ACT_GLU), "cfm_gemm: residual / GLU need N and ldc to be multiples of 4");
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_gemm: w_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(d->a_dtype == CFM_F32 || d->a_dtype == d->w_dtype, "cfm_gemm: a_dtype must be f32 or equal w_dtype");
     CFM_CHECK_ARG(d->c_dtype >= CFM_F32 && d->c_dtype <= CFM_F16, "cfm_gemm: bad c_dtype");
     CFM_CHECK_ARG(d->act >= CFM_ACT_NONE && d->act <= CFM_ACT_GLU, "cfm_gemm: bad activation");
     CFM_CHECK_ARG(d->mask_mode == 0 || d->mask_mode == 1, "cfm_gemm: bad mask_mode");
     CFM_CHECK_ARG(d->act != CFM_ACT_GLU || d->N % 32 == 0, "cfm_gemm: GLU needs N %% 32 == 0 (N=%d)", d->N);
-    CFM_CHECK_ARG(d->ldc % 4 == 0, "cfm_gemm: ldc=%lld must be a multiple of 4", (long long)d->ldc);
+    CFM_CHECK_ARG(d->ldc % 2 == 0, "cfm_gemm: ldc=%lld must be a multiple of 2", (long long)d->ldc);
     CFM_CHECK_ARG(!d->residual || (d->ldr % 4 == 0), "cfm_gemm: ldr must be a multiple of 4");
     const bool split = d->W_lo != nullptr;
     CFM_CHECK_ARG(!split || (d->a_dtype == CFM_F32 && d->w_dtype == CFM_BF16),

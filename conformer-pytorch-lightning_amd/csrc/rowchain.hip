@@ -245,7 +245,6 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             // computed here instead of in a launch of its own.  A (32 + 14)-row halo tile goes to region A; a thread owns TWO
             // channels of FOUR consecutive frames: 30 taps in registers, an 18-frame register window read once from LDS, packed
             // fp32 FMAs in the tap order of cfm_dwconv_bn_silu (bit-identical results), 16-bit results into the xn tile.
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
             u16* const halo = (u16*)lds_a;
             constexpr int C8 = D / 8, CP = D / 2, RG = RBM / 4;
             static_assert(CP * RG <= NT, "one (channel pair, frame group) per thread");

@@ -67,7 +67,8 @@ int cfm_device_ok(void);
  *  conv     when conv_C > 0, A is a channels-last image [B, T1, F1, C] and row m = (b, t2, f2) of the
  *           3x3 stride-2 convolution output [B, T2, F2, N]; K = 9*C ordered (kt, kf, c).
  *
- * constraints: K % 8 == 0, lda % 8 == 0 (elements), ldc % 4 == 0, N % 4 == 0 (GLU: N % 32 == 0).
+ * constraints: K % 8 == 0, lda % 8 == 0 (elements), ldc % 2 == 0, N % 2 == 0 (residual: both % 4; GLU: N % 32 == 0).
+ * N or ldc not a multiple of 4 (a vocabulary of 5002 columns) is written with column-pair stores.
  */
 typedef struct {
     const void* A;
@@ -371,6 +372,16 @@ int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_layer_scratc
  */
 int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens,
                 const int32_t* labels, int32_t Umax, const int32_t* label_lens, float* work, float* nll, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Transducer joint, activation operand (csrc/joint.hip):  replaces
+ *     out = enc_out.unsqueeze(2) + pred_out.unsqueeze(1);  out = tanh(out)        (reference src/joint.py:31-37)
+ * enc f32 [B*T, ld_e >= J] = enc_ffn(encoder_out), pred f32 [B*U, ld_p >= J] = pred_ffn(predictor_out) (both from cfm_gemm);
+ * out [B*T*U, J] row-major in out_dtype (f32 / bf16 / f16), row (b*T + t)*U + u = tanh(enc[b*T+t] + pred[b*U+u]).
+ * The vocabulary projection ffn_out is then cfm_gemm over these rows (N = vocab_size may be any multiple of 2).  J % 8 == 0.
+ */
+int cfm_joint_act(const float* enc, int64_t ld_e, const float* pred, int64_t ld_p, void* out, int32_t out_dtype, int32_t B,
+                  int32_t T, int32_t U, int32_t J, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling table (aux subsystem: tracing).  When enabled, every kernel launch made through this

@@ -415,6 +415,19 @@ def ctc_head_loss(P, prefix, enc_out, enc_lens, labels, label_lens):
     return float(nll.sum() / lab.shape[1]), nll
 
 
+def joint_forward(P, prefix, enc_out, pred_out, pre_project=True):
+    """TransducerJoint.forward (joint.py:20-38): enc_ffn / pred_ffn projections (unless already projected), broadcast sum over
+    (B, T, 1, J) + (B, 1, U, J), tanh, ffn_out -> logits (B, T, U, V).  3-D inputs get the singleton axis as joint.py:29-33 does."""
+    if pre_project:
+        enc_out = linear(enc_out, _w(P, prefix, "enc_ffn.weight"), _w(P, prefix, "enc_ffn.bias"))
+        pred_out = linear(pred_out, _w(P, prefix, "pred_ffn.weight"), _w(P, prefix, "pred_ffn.bias"))
+    if enc_out.dim() != 4:
+        enc_out = enc_out.unsqueeze(2)
+    if pred_out.dim() != 4:
+        pred_out = pred_out.unsqueeze(1)
+    return linear(torch.tanh(enc_out + pred_out), _w(P, prefix, "ffn_out.weight"), _w(P, prefix, "ffn_out.bias"))
+
+
 def encoder_flops_per_utt(T, F=80, D=256, FF=2048, K=15, L=12):
     """2*MAC of the GEMM/conv/attention contractions of one utterance's forward (elementwise/LN excluded)."""
     t1, f1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1

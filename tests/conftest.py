@@ -24,6 +24,30 @@ def load_golden(name):
     return arrays, meta
 
 
+def joint_case_inputs(c):
+    """Encoder / predictor outputs of a tests/golden/joint.npz case (tests/golden/make_golden.py gen_joint), as torch f32 tensors."""
+    import synth
+    import torch
+    enc = torch.from_numpy(synth.normal(c["eseed"], (c["B"], c["T"], c["E"]), 1.0))
+    pred = torch.from_numpy(synth.normal(c["pseed"], (c["B"], c["U"], c["P"]), 1.0))
+    return enc, pred
+
+
+def check_joint_case(g, c, out):
+    """max|d| / max|ref| of a (B,T,U,V) joint output against what the fixture holds for the case: the full tensor, or 512 sampled
+    logits plus the per-(b,t,u) sums over the vocabulary."""
+    n = c["name"]
+    out = np.asarray(out, dtype=np.float64)
+    assert out.shape == (c["B"], c["T"], c["U"], c["V"]), out.shape
+    if n + "_out" in g:
+        ref = g[n + "_out"].astype(np.float64)
+        return float(np.abs(out - ref).max() / np.abs(ref).max())
+    scale = float(np.abs(g[n + "_vals"]).max())
+    e = float(np.abs(out.reshape(-1)[g[n + "_idx"]] - g[n + "_vals"]).max() / scale)
+    es = float(np.abs(out.sum(-1) - g[n + "_rowsum"]).max() / float(g[n + "_rowabs"].max()))
+    return max(e, es)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

@@ -285,8 +285,39 @@ def gen_ctc():
     save("ctc_head", arrays, dict(cases=cases))
 
 
+def gen_joint():
+    """TransducerJoint.forward (reference src/joint.py:4-38): full (B,T,U,V) logits for a small case, and for the vocabulary of
+    BASELINE config 4 (5002, join_dim 512) a few hundred sampled logits plus per-(b,t,u) sums -- the full tensor would be 12 MB --
+    and the (1,1,1,V) step shape of the greedy search (model.py:250)."""
+    import joint as ref_joint  # noqa: E402
+    arrays, cases = {}, []
+    for name, (V, E, Pd, J, B, T, U, seed) in dict(small=(74, 144, 96, 64, 2, 7, 5, 31), vocab5002=(5002, 256, 256, 512, 2, 12, 6, 32),
+                                                   oddvocab=(73, 144, 96, 64, 2, 5, 3, 34), step=(5002, 256, 256, 512, 1, 1, 1, 33)).items():
+        jn = ref_joint.TransducerJoint(V, E, Pd, J).eval()
+        synth.load_synth_(jn, seed)
+        enc = torch.from_numpy(synth.normal(seed + 100, (B, T, E), 1.0))
+        pred = torch.from_numpy(synth.normal(seed + 200, (B, U, Pd), 1.0))
+        with torch.no_grad():
+            out = jn(enc, pred)
+            out_np = jn(jn.enc_ffn(enc), jn.pred_ffn(pred), pre_project=False)      # same numbers through the other entry
+        assert tuple(out.shape) == (B, T, U, V) and torch.equal(out, out_np)
+        if out.numel() <= 200000:
+            arrays[name + "_out"] = t2n(out)
+        else:
+            rs = np.random.RandomState(seed)
+            idx = rs.randint(0, out.numel(), size=512).astype(np.int64)
+            arrays[name + "_idx"] = idx
+            arrays[name + "_vals"] = t2n(out.reshape(-1)[torch.from_numpy(idx)])
+            arrays[name + "_rowsum"] = t2n(out.double().sum(-1).float())
+            arrays[name + "_rowabs"] = t2n(out.double().abs().sum(-1).float())
+        cases.append(dict(name=name, V=V, E=E, P=Pd, J=J, B=B, T=T, U=U, wseed=seed, eseed=seed + 100, pseed=seed + 200,
+                          state={k: list(v.shape) for k, v in jn.state_dict().items()}))
+    save("joint", arrays, dict(cases=cases))
+
+
 if __name__ == "__main__":
     gen_masks()
     gen_modules()
     gen_encoders()
     gen_ctc()
+    gen_joint()

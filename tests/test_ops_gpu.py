@@ -132,6 +132,45 @@ def test_gemm_conv3x3s2(cfm, B, T1, F1, C, N):
     assert relerr(out, ref) < 4e-5
 
 
+@pytest.mark.parametrize("M,N,K,ldc", [(300, 5002, 512, 5002), (129, 70, 64, 70), (77, 130, 72, 134), (64, 128, 64, 130), (5, 2, 8, 2)])
+@pytest.mark.parametrize("tile", [0, 1, 3])
+def test_gemm_pair_stores(cfm, M, N, K, ldc, tile):
+    """N or the output row stride only a multiple of 2 (a vocabulary of 5002 columns written in the reference's own layout):
+    column-pair stores, the last pair of a row predicated; nothing outside [M, N] is written."""
+    a = rnd((M, K), 61).bfloat16()
+    w = rnd((N, K), 62, K ** -0.5).bfloat16()
+    bias = rnd((N,), 63, 0.1)
+    ref = a.float() @ w.float().t() + bias
+    for odt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1e-2), (torch.float16, 2e-3)):
+        buf = torch.full((M, ldc), 7.0, dtype=odt, device="cuda")
+        out = cfm.gemm(a, w, bias=bias, out=buf[:, :N], tile=tile)
+        assert relerr(out.float(), ref) < tol, (odt, relerr(out.float(), ref))
+        assert bool((buf[:, N:] == 7.0).all())
+    if N % 4 or ldc % 4:
+        with pytest.raises(RuntimeError, match="multiples of 4"):
+            cfm.gemm(a, w, bias=bias, out=torch.empty((M, ldc), device="cuda")[:, :N], residual=torch.zeros((M, ldc), device="cuda")[:, :N])
+    with pytest.raises(RuntimeError, match="multiple of 2"):
+        cfm.gemm(a, rnd((N + 1, K), 64).bfloat16())
+
+
+@pytest.mark.parametrize("B,T,U,J", [(2, 7, 5, 64), (1, 1, 1, 512), (3, 33, 9, 512), (2, 5, 3, 72)])
+def test_joint_act(cfm, B, T, U, J):
+    """cfm_joint_act: tanh(enc[b,t] + pred[b,u]) as a [B*T*U, J] operand, against torch (joint.py:31-37)."""
+    enc, pred = rnd((B * T, J), 71, 1.5), rnd((B * U, J), 72, 1.5)
+    enc[0, :4] = torch.tensor([40.0, -40.0, 0.0, 1e-4])     # saturation and the small-argument end
+    ref = torch.tanh(enc.view(B, T, 1, J).double() + pred.view(B, 1, U, J).double()).view(B * T * U, J)
+    out = cfm.joint_act(enc, pred, B, T, U, torch.float32)
+    assert float((out.double() - ref).abs().max()) < 5e-7
+    for odt, tol in ((torch.bfloat16, 4e-3), (torch.float16, 5e-4)):
+        out = cfm.joint_act(enc, pred, B, T, U, odt)
+        assert out.dtype == odt and float((out.double() - ref).abs().max()) < tol
+    wide = torch.zeros((B * T, J + 8), device="cuda")
+    wide[:, :J] = enc
+    assert torch.equal(cfm.joint_act(wide[:, :J], pred, B, T, U, torch.float32), cfm.joint_act(enc, pred, B, T, U, torch.float32))
+    with pytest.raises(ValueError):
+        cfm.joint_act(enc, pred, B, T + 1, U, torch.float32)
+
+
 def test_gemm_rejects_bad_arguments(cfm):
     a = rnd((8, 12), 1).bfloat16()
     w = rnd((8, 12), 2).bfloat16()

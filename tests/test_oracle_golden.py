@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import synth
-from conftest import load_golden
+from conftest import check_joint_case, joint_case_inputs, load_golden
 from oracle import conformer_oracle as O
 
 TOL = 2e-5
@@ -261,3 +261,17 @@ def test_ctc_head_oracle_matches_reference():
         loss, nll = O.ctc_head_loss(P, "", enc_out, g[n + "_enc_lens"], g[n + "_labels"], g[n + "_label_lens"])
         assert np.allclose(nll, g[n + "_nll"], rtol=2e-5, atol=1e-4), (n, nll, g[n + "_nll"])
         assert abs(loss - float(g[n + "_loss"][0])) <= 2e-5 * abs(float(g[n + "_loss"][0]))
+
+
+def test_joint_oracle_matches_reference():
+    """TransducerJoint.forward of the reference (tests/golden/joint.npz) vs the oracle's restatement, both entry forms."""
+    g, meta = load_golden("joint")
+    assert [c["name"] for c in meta["cases"]] == ["small", "vocab5002", "oddvocab", "step"]
+    for c in meta["cases"]:
+        P = table(c["state"], c["wseed"])
+        enc, pred = joint_case_inputs(c)
+        out = O.joint_forward(P, "", enc, pred)
+        assert check_joint_case(g, c, out.numpy()) < 2e-6, c["name"]
+        e = O.linear(enc, P["enc_ffn.weight"], P["enc_ffn.bias"]).unsqueeze(2)
+        p = O.linear(pred, P["pred_ffn.weight"], P["pred_ffn.bias"]).unsqueeze(1)
+        assert torch.equal(O.joint_forward(P, "", e, p, pre_project=False), out)
