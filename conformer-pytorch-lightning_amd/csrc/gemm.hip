@@ -20,6 +20,11 @@
 
 #include "cfm_common.h"
 
+// vector types whose address is only known to be dword aligned (rows of a [M, ldc] matrix with ldc % 4 == 2)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned int u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
 struct GemmArgs {
     const void* A;
     const u16* W;
@@ -268,6 +273,24 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     prologue(std::integral_constant<int, 0>{});
     prologue(std::integral_constant<int, 1>{});
     if constexpr (PF > 2) prologue(std::integral_constant<int, 2>{});
+    // The epilogue's bias and row-mask reads are requested HERE, behind the first K tiles: issued in the epilogue they expose one more
+    // full memory latency per workgroup (microseconds on a loaded chip, against a 4-8 us K loop at K = 256..512).
+    const bool glu = g.act == CFM_ACT_GLU;
+    const int q4 = (lane >> 4) * 4;
+    f32x4 bias_r[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wc * (BN / 2) + j * 16 + q4;
+        if (g.bias && col + 3 < g.N) bias_r[j] = *(const f32x4*)(g.bias + col);
+        else if (g.bias && col + 1 < g.N) bias_r[j] = (f32x4){g.bias[col], g.bias[col + 1], 0.f, 0.f};   // N % 4 == 2: the last pair
+        else bias_r[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bool keep_r[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
+        keep_r[i] = (g.mask && row < g.M) ? (g.mask[row] != 0) : true;
+    }
     for (int kt0 = 0; kt0 < nkt; kt0 += PF) {
         body(kt0, std::integral_constant<int, 0>{});
         if (kt0 + 1 < nkt) body(kt0 + 1, std::integral_constant<int, 1>{});
@@ -280,23 +303,10 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     // All global READS of the epilogue are issued in one batch before the first store: C may alias `residual`
     // (in-place accumulate) and the compiler cannot prove it does not alias `bias`, so a load placed after a store is
     // serialised behind it -- 16 fragments x one exposed L2 latency each (measured: +6 us per launch for the bias alone).
-    const bool glu = g.act == CFM_ACT_GLU;
-    const int q4 = (lane >> 4) * 4;
-    f32x4 bias_r[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int col = n0 + wc * (BN / 2) + j * 16 + q4;
-        if (g.bias && col + 3 < g.N) bias_r[j] = *(const f32x4*)(g.bias + col);
-        else if (g.bias && col + 1 < g.N) bias_r[j] = (f32x4){g.bias[col], g.bias[col + 1], 0.f, 0.f};   // N % 4 == 2: the last pair
-        else bias_r[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const bool vec4 = (g.ldc & 3) == 0;                  // rows 16-byte aligned (f32) / 8-byte aligned (16 bit): one store per lane
-    bool keep_r[FM];
     f32x4 res_r[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
-        keep_r[i] = (g.mask && row < g.M) ? (g.mask[row] != 0) : true;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int cb = n0 + wc * (BN / 2) + j * 16;
@@ -339,25 +349,199 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             if (!keep && g.mask_mode == 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (g.res) v = res_r[i][j] + g.alpha * v;
             const int64_t o = (int64_t)row * g.ldc + ocol;
-            if (vec4 && col + 3 < g.N) {
+            if (col + 3 < g.N) {
+                // one 16-byte (f32) / 8-byte (16 bit) store per lane.  When ldc is only a multiple of 2 the address is 8- / 4-byte aligned:
+                // the under-aligned vector types keep it ONE global_store_dwordx4 / dwordx2 (global memory needs dword alignment only);
+                // splitting into pairs cost 10 % on the joint's vocabulary projection (2224 -> 2028 us at ldc 5002 vs 5004)
                 if (g.c_dtype == CFM_F32) {
-                    *(f32x4*)((float*)g.C + o) = v;
+                    *(f32x4_a4*)((float*)g.C + o) = v;
                 } else if (g.c_dtype == CFM_BF16) {
-                    *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])};
+                    *(u32x2_a4*)((u16*)g.C + o) = (u32x2){pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])};
                 } else {
-                    *(u32x2*)((u16*)g.C + o) = (u32x2){pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3])};
+                    *(u32x2_a4*)((u16*)g.C + o) = (u32x2){pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3])};
                 }
-            } else {
-                // N or ldc only a multiple of 2 (a vocabulary of 5002 columns written with its own row stride): column PAIRS
+            } else if (col + 1 < g.N) {
+                // N % 4 == 2 (a vocabulary of 5002 columns): the last column pair of the row
+                if (g.c_dtype == CFM_F32) *(f32x2_a4*)((float*)g.C + o) = (f32x2){v[0], v[1]};
+                else if (g.c_dtype == CFM_BF16) *(unsigned*)((u16*)g.C + o) = pack2<BF16>(v[0], v[1]);
+                else *(unsigned*)((u16*)g.C + o) = pack2<F16>(v[0], v[1]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PERSISTENT variant for short-K products with many tiles (the transducer joint's vocabulary projection: M = B*T'*U = 163 k rows,
+// K = 512, N = 5002 -> 51 k tiles of 8 K steps).  Measured on the kernel above (scripts/exp_gemm_k.py, 128 x 128 tile, two
+// workgroups per CU): a workgroup lives 6.8 us + 1.19 us per K step -- launch, the first loads' latency and the epilogue are 40 % of
+// its life at K = 512 and the other resident workgroup cannot use what it leaves idle.  Here 512 workgroups (two per CU) stay resident
+// and walk the tile list b, b + 512, b + 1024, ... of the same XCD-aware order; the register prefetch ring runs ACROSS tile boundaries
+// (the first K steps of the next tile are requested while the current tile still computes), the bias of a tile is requested at its
+// first K step, and the epilogue is stores only.  16-bit operands, bias + SiLU/ReLU epilogues; same K order per output as the kernel
+// above (bit-identical results).  Every lambda is force-inlined: left to the inliner's heuristics the state they capture (the
+// prefetch ring, the accumulators) went to scratch memory and the kernel ran 10x slower.
+template <typename HT, int BM, int BN, int BK>
+__global__ __launch_bounds__(256, 2) void cfm_gemm_pers_kernel(const GemmArgs g) {
+    constexpr int CPR = BK / 8, RPP = 256 / CPR, ACH = BM / RPP, WCH = BN / RPP, FM = BM / 32, FN = BN / 32, RPB = 16 / CPR;
+    constexpr int A_PLANE = BM * CPR, W_PLANE = BN * CPR, BUF = A_PLANE + W_PLANE, PF = 3;
+    __shared__ u32x4 smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kc = tid % CPR, rl = tid / CPR;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int per_group = 8 * tiles_n;
+    const int total_vb = ((tiles_m + 7) / 8) * per_group;       // tile ids of the XCD-aware order, the last group padded
+    const int G = gridDim.x;                                    // a multiple of 8: a workgroup's tiles all sit on its own XCD
+    auto decode = [&](int vb, int& m0, int& n0) __attribute__((always_inline)) {
+        const int grp = vb / per_group, rem = vb - grp * per_group;
+        const int tm = grp * 8 + (rem & 7);
+        m0 = tm * BM;
+        n0 = (rem >> 3) * BN;
+        return tm < tiles_m;
+    };
+    int ntile = ((int)blockIdx.x < total_vb) ? (total_vb - 1 - (int)blockIdx.x) / G + 1 : 0;
+    if (ntile > 0) {                                            // padding ids exist only in the last group = this workgroup's last id
+        int m0_, n0_;
+        if (!decode((int)blockIdx.x + (ntile - 1) * G, m0_, n0_)) --ntile;
+    }
+    const int nkt = (g.K + BK - 1) / BK;
+    const int V = ntile * nkt;                                  // K steps of this workgroup over all its tiles
+    if (V == 0) return;
+
+    auto lds_idx = [](int row, int c) __attribute__((always_inline)) { return row * CPR + (c ^ ((row / RPB) % CPR)); };
+
+    // ---- load side: runs PF K steps ahead of the compute side, across tile boundaries -------------------------------------------
+    int l_vb = blockIdx.x, l_kt = 0;
+    unsigned a_off[ACH], w_off[WCH];
+    auto l_setup = [&]() __attribute__((always_inline)) {
+        int m0, n0;
+        decode(l_vb, m0, n0);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (col + 2 * h + 1 >= g.N) break;
-                    if (g.c_dtype == CFM_F32) *(f32x2*)((float*)g.C + o + 2 * h) = (f32x2){v[2 * h], v[2 * h + 1]};
-                    else if (g.c_dtype == CFM_BF16) *(unsigned*)((u16*)g.C + o + 2 * h) = pack2<BF16>(v[2 * h], v[2 * h + 1]);
-                    else *(unsigned*)((u16*)g.C + o + 2 * h) = pack2<F16>(v[2 * h], v[2 * h + 1]);
+        for (int i = 0; i < ACH; ++i) {
+            int m = m0 + i * RPP + rl;
+            m = m < g.M ? m : g.M - 1;
+            a_off[i] = (unsigned)((int64_t)m * g.lda);
+        }
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {
+            int n = n0 + j * RPP + rl;
+            n = n < g.N ? n : g.N - 1;
+            w_off[j] = (unsigned)n * (unsigned)g.K;
+        }
+    };
+    l_setup();
+    u32x4 ra[PF][ACH], rw[PF][WCH];
+    auto gload = [&](auto slot_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_c)::value;
+        // UNCONDITIONAL loads (K % BK == 0 is required, rows are clamped, and past the last tile the ring re-reads clamped rows that
+        // nobody stages): a predicated or branched-around load makes the compiler's s_waitcnt bookkeeping merge paths and fall back
+        // to vmcnt(0) before every LDS store -- a prefetch distance of ONE K step instead of PF
+        const int k0 = l_kt * BK + kc * 8;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) ra[S][i] = *(const u32x4*)((const u16*)g.A + (a_off[i] + (unsigned)k0));
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) rw[S][j] = *(const u32x4*)(g.W + (w_off[j] + (unsigned)k0));
+        if (++l_kt == nkt) {                                    // uniform
+            l_kt = 0;
+            l_vb += G;
+            l_setup();
+        }
+    };
+    auto lstore = [&](int buf, auto slot_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_c)::value;
+        u32x4* As = smem + buf * BUF;
+        u32x4* Ws = As + A_PLANE;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) As[lds_idx(i * RPP + rl, kc)] = ra[S][i];
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) Ws[lds_idx(j * RPP + rl, kc)] = rw[S][j];
+    };
+
+    // ---- compute side ---------------------------------------------------------------------------------------------------------------
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const u32x4* As = smem + buf * BUF;
+        const u32x4* Ws = As + A_PLANE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            const int c = kk * 4 + (lane >> 4);
+            u32x4 af[FM], wf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = As[lds_idx(wr * (BM / 2) + i * 16 + (lane & 15), c)];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) wf[j] = Ws[lds_idx(wc * (BN / 2) + j * 16 + (lane & 15), c)];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = HT::mfma(wf[j], af[i], acc[i][j]);
+        }
+    };
+    int c_vb = blockIdx.x, c_kt = 0, c_m0 = 0, c_n0 = 0;
+    const int q4 = (lane >> 4) * 4;
+    f32x4 bias_r[FN];
+    auto tile_begin = [&]() __attribute__((always_inline)) {                                   // the tile's coordinates and its bias, requested a whole K loop early
+        decode(c_vb, c_m0, c_n0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int col = c_n0 + wc * (BN / 2) + j * 16 + q4;
+            if (g.bias && col + 3 < g.N) bias_r[j] = *(const f32x4*)(g.bias + col);
+            else if (g.bias && col + 1 < g.N) bias_r[j] = (f32x4){g.bias[col], g.bias[col + 1], 0.f, 0.f};
+            else bias_r[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto tile_end = [&]() __attribute__((always_inline)) {                                     // stores only
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = c_m0 + wr * (BM / 2) + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int col = c_n0 + wc * (BN / 2) + j * 16 + q4;
+                f32x4 v = acc[i][j] + bias_r[j];
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (g.act == CFM_ACT_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = siluf_(v[r]);
+                } else if (g.act == CFM_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (row >= g.M) continue;
+                const int64_t o = (int64_t)row * g.ldc + col;
+                if (col + 3 < g.N) {
+                    if (g.c_dtype == CFM_F32) *(f32x4_a4*)((float*)g.C + o) = v;
+                    else if (g.c_dtype == CFM_BF16) *(u32x2_a4*)((u16*)g.C + o) = (u32x2){pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])};
+                    else *(u32x2_a4*)((u16*)g.C + o) = (u32x2){pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3])};
+                } else if (col + 1 < g.N) {
+                    if (g.c_dtype == CFM_F32) *(f32x2_a4*)((float*)g.C + o) = (f32x2){v[0], v[1]};
+                    else if (g.c_dtype == CFM_BF16) *(unsigned*)((u16*)g.C + o) = pack2<BF16>(v[0], v[1]);
+                    else *(unsigned*)((u16*)g.C + o) = pack2<F16>(v[0], v[1]);
                 }
             }
         }
+    };
+    auto body = [&](int v, auto s) __attribute__((always_inline)) {                            // K step v of the workgroup lives in register slot v % PF
+        lstore(v & 1, s);
+        gload(s);
+        __syncthreads();
+        if (c_kt == 0) tile_begin();
+        compute(v & 1);
+        if (++c_kt == nkt) {
+            tile_end();
+            c_kt = 0;
+            c_vb += G;
+        }
+    };
+    gload(std::integral_constant<int, 0>{});
+    gload(std::integral_constant<int, 1>{});
+    gload(std::integral_constant<int, 2>{});
+    for (int v0 = 0; v0 < V; v0 += PF) {
+        body(v0, std::integral_constant<int, 0>{});
+        if (v0 + 1 < V) body(v0 + 1, std::integral_constant<int, 1>{});
+        if (v0 + 2 < V) body(v0 + 2, std::integral_constant<int, 2>{});
     }
 }
 
@@ -365,6 +549,8 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
 // host dispatch
 // ---------------------------------------------------------------------------------------------
 namespace {
+
+constexpr int CFM_PERSIST_GRID = 512;   // two resident workgroups on each of the 256 CUs (a multiple of 8: XCD round-robin)
 
 template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV, bool WDIR = false>
 int launch(const GemmArgs& a, hipStream_t s, const char* name) {
@@ -378,9 +564,30 @@ int launch(const GemmArgs& a, hipStream_t s, const char* name) {
     return cfm_launch_status(nm.c_str());
 }
 
+template <typename HT>
+int launch_persistent(const GemmArgs& a, hipStream_t s, const char* name) {
+    constexpr int BM = 128, BN = 128;
+    const int total = (((a.M + BM - 1) / BM + 7) / 8) * 8 * ((a.N + BN - 1) / BN);
+    const int grid = total < CFM_PERSIST_GRID ? total : CFM_PERSIST_GRID;
+    static const std::string nm = std::string(name) + "_persistent_128x128";
+    CfmProfScope prof(nm.c_str(), s, 2.0 * a.M * (double)a.N * a.K,
+                      (double)a.M * a.K * 2 + (double)a.N * a.K * 2 + (double)a.M * a.N * (a.c_dtype == CFM_F32 ? 4 : 2));
+    CFM_LAUNCH((cfm_gemm_pers_kernel<HT, BM, BN, 64>), dim3(grid), dim3(256), 0, s, a);
+    return cfm_launch_status(nm.c_str());
+}
+
 template <typename HT, bool A_F32, bool SPLIT, bool CONV>
 int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
     constexpr int BK = SPLIT ? 32 : 64;
+    if constexpr (!SPLIT && !A_F32 && !CONV) {
+        // persistent workgroups: plain 16-bit products whose tiles are short (K <= 1024) and many (>= 8 per resident workgroup)
+        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && !a.Wf;
+        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        if (tile == 7 || (tile == 0 && plain && a.K % BK == 0 && a.K <= 1024 && t128 >= 8L * CFM_PERSIST_GRID)) {
+            if (!plain || a.K % BK) return cfm_fail(CFM_ERR_ARG, "cfm_gemm: the persistent tile takes bias / SiLU / ReLU epilogues only and K %% 64 == 0");
+            return launch_persistent<HT>(a, s, base);
+        }
+    }
     if (tile == 0) {
         // fill the 256 CUs: prefer the biggest tile that still yields >= ~1 workgroup per CU
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);

@@ -153,6 +153,27 @@ def test_gemm_pair_stores(cfm, M, N, K, ldc, tile):
         cfm.gemm(a, rnd((N + 1, K), 64).bfloat16())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 2304, 192), (20000, 1000, 576), (300, 5002, 512), (70000, 1282, 64), (100, 100, 64)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+def test_gemm_persistent_matches_tiled(cfm, M, N, K, wdt):
+    """Persistent-workgroup GEMM (tile id 7: 512 resident workgroups walking the tile list, prefetch ring across tile boundaries) is
+    bit-identical to the one-tile-per-workgroup kernel: several tiles per workgroup, K tails, ragged M / N edges, N % 4 == 2."""
+    a = rnd((M, K), 81).to(W_DT[wdt])
+    w = rnd((N, K), 82, K ** -0.5).to(W_DT[wdt])
+    bias = rnd((N,), 83, 0.1)
+    for odt in (torch.float32, W_DT[wdt]):
+        for act in (cfm.ACT_NONE, cfm.ACT_SILU):
+            ref = cfm.gemm(a, w, bias=bias, out_dtype=odt, act=act, tile=1)
+            out = cfm.gemm(a, w, bias=bias, out_dtype=odt, act=act, tile=7)
+            assert torch.equal(out, ref), (odt, act)
+    assert torch.equal(cfm.gemm(a, w, out_dtype=torch.float32, tile=7), cfm.gemm(a, w, out_dtype=torch.float32, tile=1))
+    with pytest.raises(RuntimeError, match="K % 64"):
+        cfm.gemm(a[:, :K - 8], w[:, :K - 8].contiguous(), out_dtype=torch.float32, tile=7)
+    with pytest.raises(RuntimeError, match="persistent"):
+        cfm.gemm(a, w, out_dtype=torch.float32, tile=7, residual=torch.zeros((M, N), device="cuda")) if N % 4 == 0 else cfm.gemm(
+            a, w, out_dtype=torch.float32, tile=7, row_mask=torch.ones(M, dtype=torch.uint8, device="cuda"))
+
+
 @pytest.mark.parametrize("B,T,U,J", [(2, 7, 5, 64), (1, 1, 1, 512), (3, 33, 9, 512), (2, 5, 3, 72)])
 def test_joint_act(cfm, B, T, U, J):
     """cfm_joint_act: tanh(enc[b,t] + pred[b,u]) as a [B*T*U, J] operand, against torch (joint.py:31-37)."""
