@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "cfm_common.h"
+#include "gemm256.h"
 
 // vector types whose address is only known to be dword aligned (rows of a [M, ldc] matrix with ldc % 4 == 2)
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -653,6 +654,27 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
     hipStream_t s = (hipStream_t)stream;
     const bool a32 = d->a_dtype == CFM_F32;
+    {   // 256 x 256 tile with LDS-DMA staging (gemm256.hip): tile id 8, or chosen by a two-line cost model when it can run
+        const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->W_frag;
+        Gemm256Args b;
+        b.A = (const u16*)d->A; b.W = (const u16*)d->W; b.bias = d->bias; b.C = d->C; b.lda = d->lda; b.ldc = d->ldc;
+        b.M = d->M; b.N = d->N; b.K = d->K; b.c_dtype = d->c_dtype; b.act = d->act;
+        b.convC = d->conv_C; b.T1 = d->conv_T1; b.F1 = d->conv_F1; b.T2 = d->conv_T2; b.F2 = d->conv_F2;
+        if (d->tile == 8) {
+            CFM_CHECK_ARG(can256, "cfm_gemm: the 256x256 tile takes 16-bit operands and bias / SiLU / ReLU epilogues only");
+            return cfm_gemm256_launch(b, d->w_dtype == CFM_BF16, s);
+        }
+        if (d->tile == 0 && can256 && cfm_gemm256_eligible(b, d->w_dtype == CFM_BF16)) {
+            // measured on MI355X (scripts/exp_gemm_k.py): a 256 x 256 tile takes ~7 us + 1.8 us per K step and 256 run at a time (whole
+            // rounds: one workgroup per CU); a 128 x 128 tile ~6.8 us + 1.19 us per K step, 512 at a time, dealt continuously
+            const double nk = d->K / 64.0;
+            const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256), t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+            const double c256 = (double)((t256 + 255) / 256) * (7.0 + 1.8 * nk);
+            const double r128 = t128 / 512.0;
+            const double c128 = (r128 < 1.0 ? 1.0 : r128) * (6.8 + 1.19 * nk);
+            if (t256 >= 128 && c256 < c128) return cfm_gemm256_launch(b, d->w_dtype == CFM_BF16, s);
+        }
+    }
     if (split) {
         return conv ? pick_tile<BF16, true, true, true>(a, d->tile, s, "gemm_conv_bf16x3")
                     : pick_tile<BF16, true, true, false>(a, d->tile, s, "gemm_bf16x3");

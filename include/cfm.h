@@ -85,7 +85,9 @@ typedef struct {
     float alpha;
     int32_t conv_C, conv_T1, conv_F1, conv_T2, conv_F2; /* conv_C == 0: plain GEMM */
     int32_t tile;                                       /* 0 = auto; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64, 5: 32x64, 6: 32x128,
-                                                           7: 128x128 persistent workgroups (16-bit plain products; auto for short K, many tiles) */
+                                                           7: 128x128 persistent workgroups (16-bit plain products, K %% 64 == 0),
+                                                           8: 256x256 with LDS-DMA staging (csrc/gemm256.hip: 16-bit operands, K %% 64 == 0, bias / SiLU /
+                                                              ReLU epilogues; auto when a cost model says its whole rounds beat the 128x128 tiles) */
     int32_t mask_mode;                                  /* 0: row_mask zeroes the OUTPUT row (after act, before residual);
                                                            1: row_mask zeroes the INPUT row (acc = 0, bias/act still apply) */
     const void* W_frag; /* optional: the same weights fragment-major (see cfm_rowchain), K %% 32 == 0, N %% 16 == 0.  16-bit, non-split

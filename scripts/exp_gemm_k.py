@@ -23,8 +23,10 @@ def run(M, N, K, odt=torch.bfloat16, tile=1):
 for K in (64, 128, 256, 512, 1024, 2048, 4096):
     run(16 * 249 * 41 // 2, 5120, K)
     run(16 * 249 * 41 // 2, 5120, K, tile=7)
-for K in (64, 512, 2048):
-    run(16 * 249 * 41 // 2, 5120, K, torch.float32)
+    run(16 * 249 * 41 // 2, 5120, K, tile=8)
+for K in (512,):
+    run(16 * 249 * 41, 5002, K, torch.float32, tile=7)
+    run(16 * 249 * 41, 5002, K, torch.float32, tile=8)
+    run(16 * 249 * 41, 5002, K, torch.bfloat16, tile=8)
 # one round only: 512 tiles (latency of a lone workgroup pair per CU)
-for K in (64, 512, 2048):
-    run(128 * 32, 128 * 16, K)
+

@@ -174,6 +174,40 @@ def test_gemm_persistent_matches_tiled(cfm, M, N, K, wdt):
             a, w, out_dtype=torch.float32, tile=7, row_mask=torch.ones(M, dtype=torch.uint8, device="cuda"))
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 2304, 192), (20000, 1000, 576), (300, 5002, 512), (7000, 1282, 64), (100, 100, 64), (257, 514, 128)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+def test_gemm_256_tile_matches_tiled(cfm, M, N, K, wdt):
+    """256 x 256 tile with LDS-DMA staging (tile id 8, csrc/gemm256.hip) is bit-identical to the 128 x 128 register-staged kernel:
+    ragged M / N edges, N % 4 == 2, one K tile, every output dtype and epilogue it takes."""
+    a = rnd((M, K), 91).to(W_DT[wdt])
+    w = rnd((N, K), 92, K ** -0.5).to(W_DT[wdt])
+    bias = rnd((N,), 93, 0.1)
+    for odt in (torch.float32, W_DT[wdt]):
+        for act in (cfm.ACT_NONE, cfm.ACT_SILU, cfm.ACT_RELU):
+            ref = cfm.gemm(a, w, bias=bias, out_dtype=odt, act=act, tile=1)
+            out = cfm.gemm(a, w, bias=bias, out_dtype=odt, act=act, tile=8)
+            assert torch.equal(out, ref), (odt, act)
+    assert torch.equal(cfm.gemm(a, w, out_dtype=torch.float32, tile=8), cfm.gemm(a, w, out_dtype=torch.float32, tile=1))
+    with pytest.raises(RuntimeError, match="K % 64"):
+        cfm.gemm(a[:, :K - 8], w[:, :K - 8].contiguous(), out_dtype=torch.float32, tile=8)
+    with pytest.raises(RuntimeError, match="256x256"):
+        cfm.gemm(a, w, out_dtype=torch.float32, tile=8, row_mask=torch.ones(M, dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.parametrize("B,T1,F1,C,N", [(2, 21, 17, 64, 64), (3, 45, 39, 256, 256), (1, 9, 9, 128, 320)])
+def test_gemm_256_tile_conv(cfm, B, T1, F1, C, N):
+    """The implicit 3x3 / stride-2 convolution through the 256 x 256 tile equals the 128 x 128 kernel bit for bit."""
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    img = rnd((B, T1, F1, C), 95).bfloat16()
+    w = rnd((N, 9 * C), 96, (9 * C) ** -0.5).bfloat16()
+    bias = rnd((N,), 97, 0.1)
+    conv = (C, T1, F1, T2, F2, B * T2 * F2)
+    for odt in (torch.float32, torch.bfloat16):
+        ref = cfm.gemm(img, w, bias=bias, act=cfm.ACT_RELU, conv=conv, out_dtype=odt, tile=1)
+        out = cfm.gemm(img, w, bias=bias, act=cfm.ACT_RELU, conv=conv, out_dtype=odt, tile=8)
+        assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("B,T,U,J", [(2, 7, 5, 64), (1, 1, 1, 512), (3, 33, 9, 512), (2, 5, 3, 72)])
 def test_joint_act(cfm, B, T, U, J):
     """cfm_joint_act: tanh(enc[b,t] + pred[b,u]) as a [B*T*U, J] operand, against torch (joint.py:31-37)."""
