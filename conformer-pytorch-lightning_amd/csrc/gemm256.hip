@@ -1,10 +1,10 @@
 // gemm256.hip -- C = act(A[M,K] . W[N,K]^T + bias) on 256 x 256 tiles with LDS-DMA staging (gfx950).
 //
 // The 128 x 128 kernel of gemm.hip is bound by the bytes it moves per MFMA, not by the MFMA pipe: per K step a CU spends ~512 clk
-// of its vector-memory path on the global loads, ~768 clk of LDS on the register->LDS writes and the fragment reads, and those
-// add up (measured 1 420 clk per K step against 512 clk of MFMA, scripts/exp_gemm_k.py).  This kernel quarters the LDS reads per MFMA
-// (a wavefront owns 128 x 64 of the output: 24 fragment reads per 64 MFMAs instead of 16 per 32... per 16 x 16 x 32 MFMA: 0.375
-// against 0.5 KB) and drops the register round trip of the staging altogether:
+// of its vector-memory path on the global loads and ~768 clk of LDS on the register->LDS writes and the fragment reads, and those
+// add up (measured 1 420 clk per K step against 512 clk of MFMA, scripts/exp_gemm_k.py).  This kernel moves fewer bytes per MFMA -- a
+// wavefront owns 128 x 64 of the output, 0.375 KB of fragment reads per MFMA instead of 0.5, and a 256 x 256 tile loads half the
+// global bytes per MFMA of a 128 x 128 one -- and drops the register round trip of the staging altogether:
 //   * 512 threads = 8 wavefronts as 2 (M) x 4 (N); tile 256 x 256, BK = 64; one workgroup per CU (128 KB of LDS, two K tiles);
 //   * operands go global -> LDS directly (global_load_lds_dwordx4: no VGPR destination, no ds_write); the LDS image of an operand
 //     tile is lane-linear ([256 rows][8 x 16 B]), so the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is
@@ -185,10 +185,16 @@ __global__ __launch_bounds__(512) void cfm_gemm256_kernel(const Gemm256Args g) {
         __syncthreads();                                    // retires the DMA of K tile kt+1 and this step's reads
     }
     epilogue(m0, n0);
-    // A PERSISTENT form of this kernel (one workgroup per CU walking the tile list, the next tile's first K tile requested during the
-    // last K step, epilogue inside the loop) was built and measured SLOWER: 618 vs 588 us at K = 512, 1 409 vs 1 307 us on the joint's
-    // projection, 238 vs 227 us on the front-end convolution -- the in-loop epilogue costs ~20 spilled registers and its stores sit in
-    // front of the vmcnt(0) of the next barrier, which is worse than a fresh workgroup's launch + first-tile latency.
+    // Two deeper-pipelined forms were built, verified bit-identical and measured SLOWER; neither is kept:
+    //  * BK = 32 with FOUR LDS buffers, the DMA of K step t+3 requested while step t computes, a counted `s_waitcnt vmcnt(8)` and a raw
+    //    s_barrier (two K steps stay in flight across every barrier): 1 752 vs 1 582 us at K = 2 048, 239 vs 227 us on the front-end
+    //    convolution -- twice the barriers per MFMA cost more than the longer prefetch distance gains, i.e. the step is not waiting for
+    //    memory but for its own lock-step of LDS reads and MFMAs (all 8 wavefronts read, then all multiply);
+    //  * a PERSISTENT form (one workgroup per CU walking the tile list, the next tile's first K tile requested during the last K step,
+    //    epilogue inside the loop): 618 vs 588 us at K = 512, 1 409 vs 1 307 us on the joint's projection, 238 vs 227 us on the front-end
+    //    convolution -- the in-loop epilogue costs ~20 spilled registers and its stores sit in front of the vmcnt(0) of the next barrier, which is worse than a fresh workgroup's launch + first-tile latency.
+    // What is left on the table is the ping-pong schedule (the two wavefronts of a SIMD half a step apart, one reading fragments while the
+    // other multiplies), which needs half-tile staging and per-phase counted waits.
 }
 
 template <typename HT, bool CONV>
