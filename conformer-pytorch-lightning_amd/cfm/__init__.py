@@ -124,6 +124,7 @@ def lib():
         L.cfm_kv_cache_pack.argtypes = [c_p, c_i32, c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_dwconv_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_conv1_relu.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
+        L.cfm_conv1_relu_mma.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_valid_mask.argtypes = [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_chunk_mask.argtypes = [c_p, c_i32, c_i32, c_i32, c_p]
         L.cfm_attn_mask.argtypes = [c_p, c_p, c_p, c_i32, c_i32, c_p]
@@ -139,7 +140,7 @@ def lib():
         L.cfm_prof_collect.restype = ctypes.c_int
         L.cfm_prof_entry.argtypes = [c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_ffn_partial", "cfm_ffn_partial_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu",
+        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_ffn_partial", "cfm_ffn_partial_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry"):
             getattr(L, name).restype = ctypes.c_int

@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
+__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -248,9 +248,14 @@ def dwconv_bn_silu(x, w, dw_bias, bn_scale, bn_shift, out=None, out_dtype=None):
     return out
 
 
-def conv1_relu(x, w9c, bias, out_dtype, cmvn=None):
+def conv1_relu_mma_supported(C, out_dtype):
+    return C % 16 == 0 and C <= 256 and out_dtype in (torch.bfloat16, torch.float16)
+
+
+def conv1_relu(x, w9c, bias, out_dtype, cmvn=None, mma=False):
     """x [B,T,F] f32 -> relu(conv3x3 s2) channels-last [B,T1,F1,C].  cmvn = (mean [F], istd [F] | None): global CMVN folded into the
-    tap loads, (x - mean) * istd, bit-identical to normalising first."""
+    tap loads, (x - mean) * istd, bit-identical to normalising first.  mma=True: the 9 taps as an MFMA contraction on operands rounded
+    to out_dtype (16-bit; include/cfm.h cfm_conv1_relu_mma) instead of f32 FMAs."""
     _c.require_hip(x, w9c, bias)
     mean = istd = None
     if cmvn is not None:
@@ -265,9 +270,9 @@ def conv1_relu(x, w9c, bias, out_dtype, cmvn=None):
     C = w9c.shape[1]
     T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
     out = torch.empty((B, T1, F1, C), dtype=out_dtype, device=x.device)
-    _c.check(_c.lib().cfm_conv1_relu(_c.ptr(x), _c.ptr(w9c), _c.ptr(bias), _c.ptr(out), _c.dt_code(out), B, T, F, C, _c.ptr(mean), _c.ptr(istd),
-                                     _c.stream()),
-             "cfm_conv1_relu")
+    fn = _c.lib().cfm_conv1_relu_mma if mma else _c.lib().cfm_conv1_relu
+    _c.check(fn(_c.ptr(x), _c.ptr(w9c), _c.ptr(bias), _c.ptr(out), _c.dt_code(out), B, T, F, C, _c.ptr(mean), _c.ptr(istd), _c.stream()),
+             "cfm_conv1_relu_mma" if mma else "cfm_conv1_relu")
     return out
 
 

@@ -371,6 +371,109 @@ __global__ __launch_bounds__(256) void cfm_conv1_rows_kernel(const float* __rest
     }
 }
 
+// Third form, on the matrix pipe: the 9 taps are a K = 32 contraction (3 taps of one input row in each of three 8-wide K groups, the
+// rest zero), the 16 x 16 x 32 MFMA takes the weights as its A operand (16 channel fragments of 4 VGPRs, built once per wavefront and
+// kept in registers) and 16 output positions as its B operand, so a lane ends up with 4 consecutive channels of one position per
+// fragment.  The FMA forms above spend ~55 us of VALU time on 9 x 159 M multiply-adds at config 2; here the arithmetic is 4 us of MFMA
+// and what remains is the 319 MB write.  Inputs and weights are ROUNDED TO THE 16-BIT OPERAND TYPE (the FMA forms multiply in f32):
+// used by the bf16 / fp16 precision modes, whose conv1 output is 16-bit anyway; the f32-accurate mode keeps the FMA form.
+template <typename HT>
+__global__ __launch_bounds__(256) void cfm_conv1_mma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, u16* __restrict__ y, int B, int T, int F,
+                                                            int T1, int F1, int C, const float* __restrict__ cm_mean,
+                                                            const float* __restrict__ cm_istd) {
+    constexpr int MAXF = 16;                               // channel fragments (C <= 256)
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int nfr = C >> 4, cq = C >> 2;
+    const unsigned npos = (unsigned)B * (unsigned)T1 * (unsigned)F1;   // < 2^31 (host check)
+    const unsigned nfrag = (npos + 15u) >> 4;
+    const unsigned wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    // Weights: the MFMA's output row i = 4q + r of channel fragment j is made channel q*(C/4) + 4j + r, so that the lane that ends up with
+    // rows 4q .. 4q+3 of every fragment holds C/4 CONSECUTIVE channels of its position: 16-byte stores, 128 contiguous bytes per lane at
+    // C = 256.  A-operand lane (row l15, K group kg) holds taps 3kg .. 3kg+2 of its channel, then five zeros; K group 3 is zero.
+    u32x4 wf[MAXF];
+    f32x4 bs[MAXF];
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j) {
+        wf[j] = (u32x4){0u, 0u, 0u, 0u};
+        bs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < nfr) {
+            const int ch = (l15 >> 2) * cq + 4 * j + (l15 & 3);
+            if (kg < 3) {
+                const float a = w[(3 * kg) * C + ch], b = w[(3 * kg + 1) * C + ch], c = w[(3 * kg + 2) * C + ch];
+                wf[j].x = pack2<HT>(a, b);
+                wf[j].y = pack2<HT>(c, 0.f);
+            }
+            bs[j] = *(const f32x4*)(bias + kg * cq + 4 * j);    // the 4 channels this lane ends up with (as an output lane, q = kg)
+        }
+    }
+    // one fragment = 16 consecutive output positions; lanes of K group kg read input row 2 t1 + kg, columns 2 f1 .. 2 f1 + 2
+    auto gather = [&](unsigned fr, unsigned& p_out, bool& live_out) __attribute__((always_inline)) {
+        unsigned p = fr * 16u + (unsigned)l15;
+        live_out = p < npos;
+        p = live_out ? p : npos - 1u;
+        p_out = p;
+        const unsigned f1 = p % (unsigned)F1, bt = p / (unsigned)F1;
+        const unsigned t1 = bt % (unsigned)T1, b = bt / (unsigned)T1;
+        u32x4 xf = (u32x4){0u, 0u, 0u, 0u};
+        if (kg < 3) {
+            const float* xr = x + (((int64_t)b * T + 2 * t1 + kg) * F + 2 * f1);
+            float v0 = xr[0], v1 = xr[1], v2 = xr[2];
+            if (cm_mean) {
+                const unsigned f = 2 * f1;
+                v0 -= cm_mean[f]; v1 -= cm_mean[f + 1]; v2 -= cm_mean[f + 2];
+                if (cm_istd) { v0 *= cm_istd[f]; v1 *= cm_istd[f + 1]; v2 *= cm_istd[f + 2]; }
+            }
+            xf.x = pack2<HT>(v0, v1);
+            xf.y = pack2<HT>(v2, 0.f);
+        }
+        return xf;
+    };
+    extern __shared__ __attribute__((aligned(16))) u16 conv1_lds[];
+    const int rs = C + 8;                                  // LDS row stride in 16-bit elements (C * 2 + 16 bytes)
+    u16* const tile = conv1_lds + (threadIdx.x >> 6) * (16 * rs);
+    unsigned p = 0;
+    bool live = false;
+    auto emit = [&](unsigned fr, const u32x4& xf) __attribute__((always_inline)) {
+        // results go through a per-wavefront LDS tile [16 positions][C] (rows padded by 16 B: conflict-free 16-byte writes) so that the
+        // global stores are whole 1 KB runs: 64 lanes x 16 B = two positions' 512-byte channel vectors per instruction.  Stored straight
+        // from the MFMA layout, every instruction touched 16 (8-byte pieces) or 64 (16-byte pieces) different 128-byte lines:
+        // 119 and 256 us against 105 us for the FMA form.
+        u16* const tp = tile + l15 * rs + kg * cq;
+#pragma unroll
+        for (int j = 0; j < MAXF; j += 2) {
+            if (j < nfr) {
+                f32x4 a = HT::mfma(wf[j], xf, bs[j]);        // bias rides in as the accumulator
+                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                if (j + 1 < nfr) {
+                    f32x4 c = HT::mfma(wf[j + 1], xf, bs[j + 1]);
+                    c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                    *(u32x4*)(tp + 4 * j) = pack8<HT>(a, c);
+                } else {
+                    *(u32x2*)(tp + 4 * j) = (u32x2){pack2<HT>(a.x, a.y), pack2<HT>(a.z, a.w)};
+                }
+            }
+        }
+        // the fragment's 16 positions are consecutive in memory: 16 * C contiguous 16-bit values starting at position fr * 16
+        const unsigned pbase = fr * 16u;
+        const int cpp = C >> 3;                              // 16-byte chunks per position
+        for (int ch = lane; ch < 16 * cpp; ch += 64) {
+            const int pi = ch / cpp, cc = ch - pi * cpp;
+            if (pbase + (unsigned)pi < npos) *(u32x4*)(y + ((int64_t)(pbase + pi) * C + cc * 8)) = *(const u32x4*)(tile + pi * rs + cc * 8);
+        }
+    };
+    // two fragments per trip: both gathers are in flight before the first fragment's MFMAs and stores
+    for (unsigned fr = wave0; fr < nfrag; fr += 2 * nwaves) {
+        const unsigned fr2 = fr + nwaves;
+        const u32x4 xa = gather(fr, p, live);
+        u32x4 xb = (u32x4){0u, 0u, 0u, 0u};
+        if (fr2 < nfrag) xb = gather(fr2, p, live);
+        emit(fr, xa);
+        if (fr2 < nfrag) emit(fr2, xb);
+    }
+}
+
 __global__ void cfm_cast_kernel(const void* src, int sdt, void* dst, int ddt, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         store_from_f32(dst, i, ddt, load_as_f32(src, i, sdt));
@@ -460,6 +563,26 @@ extern "C" int cfm_conv1_relu(const float* x, const float* w, const float* bias,
     else
         CFM_LAUNCH((cfm_conv1_kernel<false>), grid, block, 0, s, x, w, bias, y, y_dtype, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd);
     return cfm_launch_status("cfm_conv1_relu");
+}
+
+extern "C" int cfm_conv1_relu_mma(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B, int32_t T, int32_t F,
+                                  int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream) {
+    CFM_CHECK_ARG(cmvn_mean || !cmvn_istd, "cfm_conv1_relu_mma: cmvn_istd without cmvn_mean");
+    CFM_CHECK_ARG(x && w && bias && y, "cfm_conv1_relu_mma: null pointer");
+    CFM_CHECK_ARG(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 16 == 0 && C <= 256, "cfm_conv1_relu_mma: bad shape B=%d T=%d F=%d C=%d (C %% 16 == 0, C <= 256)", B, T, F, C);
+    CFM_CHECK_ARG(y_dtype == CFM_BF16 || y_dtype == CFM_F16, "cfm_conv1_relu_mma: the output (= operand) type must be bf16 or fp16");
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const int64_t npos = (int64_t)B * T1 * F1, nfrag = (npos + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nb = (nfrag + 3) / 4;
+    if (nb > 256 * 4) nb = 256 * 4;                          // 4 workgroups of 4 wavefronts per CU (LDS), each wavefront strides over the fragments
+    const size_t lds = (size_t)4 * 16 * (C + 8) * 2;         // one [16][C + 8] 16-bit tile per wavefront
+    CfmProfScope prof("conv1_relu_mma", s, 2.0 * 9 * (double)npos * C, (double)B * T * F * 4 + (double)npos * C * 2);
+    if (y_dtype == CFM_BF16)
+        CFM_LAUNCH((cfm_conv1_mma_kernel<BF16>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, (u16*)y, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd);
+    else
+        CFM_LAUNCH((cfm_conv1_mma_kernel<F16>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, (u16*)y, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd);
+    return cfm_launch_status("cfm_conv1_relu_mma");
 }
 
 extern "C" int cfm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, cfm_stream_t stream) {

@@ -278,6 +278,13 @@ int cfm_dwconv_bn_silu(const void* x, int x_dtype, const float* w, const float* 
 int cfm_conv1_relu(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B,
                    int32_t T, int32_t F, int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream);
 
+/* The same convolution on the matrix pipe (csrc/convmod.hip cfm_conv1_mma_kernel): the 9 taps as a K = 32 MFMA contraction.  Inputs
+ * (after the optional CMVN, applied in f32) and weights are ROUNDED to the 16-bit type y_dtype (bf16 / f16), products accumulate in
+ * f32 on top of the bias; cfm_conv1_relu multiplies in f32.  For the 16-bit precision modes, whose conv1 output is 16-bit anyway.
+ * C % 16 == 0, C <= 256.  Same arguments otherwise. */
+int cfm_conv1_relu_mma(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B, int32_t T, int32_t F,
+                       int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Masks -- integer/bool, bit-exact with the reference.
  *  cfm_valid_mask     out[b,t] = (t*stride + first) < len[b]     (uint8 0/1), t in [0,T)

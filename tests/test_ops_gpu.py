@@ -392,6 +392,35 @@ def test_conv1_relu(cfm, B, T, C, F):
     assert relerr(y.float(), ref.bfloat16().float()) < 1e-2
 
 
+@pytest.mark.parametrize("F", [80, 83, 7])
+@pytest.mark.parametrize("B,T,C", [(2, 200, 144), (3, 83, 256), (1, 7, 16), (32, 1000, 256)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+def test_conv1_relu_mma(cfm, B, T, C, F, wdt):
+    """First convolution on the matrix pipe: equals the f32 convolution of the 16-bit-ROUNDED inputs and weights (what the MFMA
+    multiplies), output rounded once; with CMVN folded in (applied in f32 before the rounding); close to the f32 FMA form."""
+    if B == 32 and F != 80:
+        pytest.skip("full config-2 size once")
+    dt = W_DT[wdt]
+    x = rnd((B, T, F), 60)
+    w = rnd((C, 1, 3, 3), 61, 1 / 3)
+    b = rnd((C,), 62, 0.1)
+    w9c = w.reshape(C, 9).t().contiguous()
+    assert cfm.conv1_relu_mma_supported(C, dt)
+    y = cfm.conv1_relu(x, w9c, b, dt, mma=True)
+    ref = torch.relu(torch.nn.functional.conv2d(x.to(dt).double()[:, None], w.to(dt).double(), b.double(), stride=2)).permute(0, 2, 3, 1)
+    tol = 6e-3 if wdt == "bf16" else 8e-4                     # one output rounding
+    assert y.dtype == dt and relerr(y.double(), ref) < tol
+    fma = cfm.conv1_relu(x, w9c, b, dt)
+    assert relerr(y.float(), fma.float()) < (2e-2 if wdt == "bf16" else 3e-3)
+    mean, istd = rnd((F,), 63, 0.5), (1.0 + 0.2 * rnd((F,), 64)).abs() + 0.5
+    yn = cfm.conv1_relu(x, w9c, b, dt, cmvn=(mean, istd), mma=True)
+    xn = ((x - mean) * istd).to(dt).double()
+    refn = torch.relu(torch.nn.functional.conv2d(xn[:, None], w.to(dt).double(), b.double(), stride=2)).permute(0, 2, 3, 1)
+    assert relerr(yn.double(), refn) < tol
+    with pytest.raises(RuntimeError, match="bf16 or fp16"):
+        cfm.conv1_relu(x, w9c, b, torch.float32, mma=True)
+
+
 def test_masks_bit_exact(cfm):
     from oracle import conformer_oracle as O
     lens = torch.tensor([200, 163, 7, 0, 1000], dtype=torch.int32, device="cuda")
