@@ -37,6 +37,7 @@ struct GemmArgs {
     void* C;
     int64_t lda, ldc, ldr;
     int M, N, K;
+    int m_begin;     // first row this launch computes (rows [m_begin, M)); 0 except for the tail of a split launch (see cfm_gemm)
     int c_dtype, act, mask_mode;
     float alpha;
     int convC, T1, F1, T2, F2;
@@ -76,12 +77,12 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     // them over the fabric (measured on the front-end conv: 1.49 GB of HBM traffic per launch for 0.34 GB of compulsory bytes).
     // Speed only -- any placement computes the same result.
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int tiles_m = (g.M + BM - 1) / BM;
+    const int tiles_m = (g.M - g.m_begin + BM - 1) / BM;
     const int per_group = 8 * tiles_n;
     const int grp = blockIdx.x / per_group, rem = blockIdx.x % per_group;
     const int tile_m = grp * 8 + (rem % 8);
     if (tile_m >= tiles_m) return;                      // padding blocks of the last group (uniform: before any barrier)
-    const int m0 = tile_m * BM;
+    const int m0 = g.m_begin + tile_m * BM;
     const int n0 = (rem / 8) * BN;
 
     auto lds_idx = [](int row, int c) { return row * CPR + (c ^ ((row / RPB) % CPR)); };
@@ -555,11 +556,12 @@ constexpr int CFM_PERSIST_GRID = 512;   // two resident workgroups on each of th
 
 template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV, bool WDIR = false>
 int launch(const GemmArgs& a, hipStream_t s, const char* name) {
-    const int tiles = (((a.M + BM - 1) / BM + 7) / 8) * 8 * ((a.N + BN - 1) / BN);   // M tiles padded to a multiple of 8 (XCD groups)
+    const int tiles = (((a.M - a.m_begin + BM - 1) / BM + 7) / 8) * 8 * ((a.N + BN - 1) / BN);   // M tiles padded to a multiple of 8 (XCD groups)
     static const std::string nm = std::string(name) + (WDIR ? "_wdir_" : "_") + std::to_string(BM) + "x" + std::to_string(BN);
-    const double flops = 2.0 * a.M * (double)a.N * a.K;  // algorithmic (the 3 passes of SPLIT are not counted)
-    const double bytes = (double)a.M * a.K * (A_F32 ? 4 : 2) + (double)a.N * a.K * 2 * (SPLIT ? 2 : 1) +
-                         (double)a.M * a.N * (a.c_dtype == CFM_F32 ? 4 : 2);
+    const double rows = a.M - a.m_begin;
+    const double flops = 2.0 * rows * (double)a.N * a.K;  // algorithmic (the 3 passes of SPLIT are not counted)
+    const double bytes = rows * a.K * (A_F32 ? 4 : 2) + (double)a.N * a.K * 2 * (SPLIT ? 2 : 1) +
+                         rows * a.N * (a.c_dtype == CFM_F32 ? 4 : 2);
     CfmProfScope prof(nm.c_str(), s, flops, bytes);
     CFM_LAUNCH((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV, WDIR>), dim3(tiles), dim3(256), 0, s, a);
     return cfm_launch_status(nm.c_str());
@@ -582,7 +584,7 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
     constexpr int BK = SPLIT ? 32 : 64;
     if constexpr (!SPLIT && !A_F32 && !CONV) {
         // persistent workgroups: plain 16-bit products whose tiles are short (K <= 1024) and many (>= 8 per resident workgroup)
-        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && !a.Wf;
+        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && !a.Wf && a.m_begin == 0;
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         if (tile == 7 || (tile == 0 && plain && a.K % BK == 0 && a.K <= 1024 && t128 >= 8L * CFM_PERSIST_GRID)) {
             if (!plain || a.K % BK) return cfm_fail(CFM_ERR_ARG, "cfm_gemm: the persistent tile takes bias / SiLU / ReLU epilogues only and K %% 64 == 0");
@@ -591,8 +593,8 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
     }
     if (tile == 0) {
         // fill the 256 CUs: prefer the biggest tile that still yields >= ~1 workgroup per CU
-        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-        const long t64x128 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+        const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
+        const long t64x128 = (long)((a.M - a.m_begin + 63) / 64) * ((a.N + 127) / 128);
         tile = t128 >= 224 ? 1 : (t64x128 >= 224 ? 2 : 3);
     }
     if constexpr (!SPLIT && !A_F32) {            // weights straight from a fragment-major pack (big tiles only)
@@ -650,10 +652,11 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     a.Wf = (split || d->a_dtype == CFM_F32) ? nullptr : (const u16*)d->W_frag;
     a.A = d->A; a.W = (const u16*)d->W; a.Wlo = (const u16*)d->W_lo; a.bias = d->bias; a.res = d->residual;
     a.mask = d->row_mask; a.C = d->C; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
-    a.M = d->M; a.N = d->N; a.K = d->K; a.c_dtype = d->c_dtype; a.act = d->act; a.alpha = d->alpha; a.mask_mode = d->mask_mode;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.m_begin = 0; a.c_dtype = d->c_dtype; a.act = d->act; a.alpha = d->alpha; a.mask_mode = d->mask_mode;
     a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
     hipStream_t s = (hipStream_t)stream;
     const bool a32 = d->a_dtype == CFM_F32;
+    long head256 = 0;
     {   // 256 x 256 tile with LDS-DMA staging (gemm256.hip): tile id 8, or chosen by a two-line cost model when it can run
         const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->W_frag;
         Gemm256Args b;
@@ -672,9 +675,27 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
             const double c256 = (double)((t256 + 255) / 256) * (7.0 + 1.8 * nk);
             const double r128 = t128 / 512.0;
             const double c128 = (r128 < 1.0 ? 1.0 : r128) * (6.8 + 1.19 * nk);
-            if (t256 >= 128 && c256 < c128) return cfm_gemm256_launch(b, d->w_dtype == CFM_BF16, s);
+            // third option: whole rounds on the 256 x 256 tile, the partial last round (e.g. 592 tiles on 256 CUs = 2.3 rounds) as
+            // 128 x 128 tiles over the remaining rows -- two launches, split at an M-tile boundary
+            const long tn256 = (d->N + 255) / 256;
+            const long full_mt = ((t256 / 256) * 256) / tn256;                 // 256-row M tiles covered by the whole rounds
+            const long rem_rows = d->M - full_mt * 256;
+            double chyb = 1e30;
+            if (full_mt >= 8 && rem_rows > 0) {
+                const double rr = (double)((rem_rows + 127) / 128) * ((d->N + 127) / 128) / 512.0;
+                chyb = (double)(t256 / 256) * (7.0 + 1.8 * nk) + (rr < 1.0 ? 1.0 : rr) * (6.8 + 1.19 * nk);
+            }
+            if (t256 >= 128 && chyb < c256 && chyb < c128) {
+                head256 = full_mt * 256;                                      // rows [0, head256) here, the rest below on 128 x 128 tiles
+                Gemm256Args h = b;
+                h.M = (int)head256;
+                if (int rc = cfm_gemm256_launch(h, d->w_dtype == CFM_BF16, s)) return rc;
+            } else if (t256 >= 128 && c256 < c128) {
+                return cfm_gemm256_launch(b, d->w_dtype == CFM_BF16, s);
+            }
         }
     }
+    a.m_begin = (int)head256;
     if (split) {
         return conv ? pick_tile<BF16, true, true, true>(a, d->tile, s, "gemm_conv_bf16x3")
                     : pick_tile<BF16, true, true, false>(a, d->tile, s, "gemm_bf16x3");

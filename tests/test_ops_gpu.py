@@ -194,6 +194,28 @@ def test_gemm_256_tile_matches_tiled(cfm, M, N, K, wdt):
         cfm.gemm(a, w, out_dtype=torch.float32, tile=8, row_mask=torch.ones(M, dtype=torch.uint8, device="cuda"))
 
 
+def test_gemm_auto_split_matches_single_kernel(cfm):
+    """tile=0 on a shape whose 256 x 256 tiles make 2.3 rounds on 256 CUs (the front-end convolution at config 2; a plain product of the
+    same M, N): whole rounds go to the 256 x 256 kernel, the remaining rows to 128 x 128 tiles -- two launches, one result, bit-identical
+    to either kernel alone."""
+    B, T1, F1, C, N = 32, 499, 39, 256, 256
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    img = rnd((B, T1, F1, C), 101).bfloat16()
+    w = rnd((N, 9 * C), 102, (9 * C) ** -0.5).bfloat16()
+    bias = rnd((N,), 103, 0.1)
+    conv = (C, T1, F1, T2, F2, B * T2 * F2)
+    ref = cfm.gemm(img, w, bias=bias, act=cfm.ACT_RELU, conv=conv, out_dtype=torch.bfloat16, tile=1)
+    cfm.prof_reset(); cfm.prof_enable(True)
+    out = cfm.gemm(img, w, bias=bias, act=cfm.ACT_RELU, conv=conv, out_dtype=torch.bfloat16)
+    torch.cuda.synchronize(); cfm.prof_enable(False)
+    assert torch.equal(out, ref)
+    names = set(cfm.prof_table())
+    assert any(n.endswith("256x256") for n in names) and any(n.endswith("128x128") for n in names), names
+    a = rnd((B * T2 * F2, 512), 104).bfloat16()
+    w2 = rnd((N, 512), 105, 512 ** -0.5).bfloat16()
+    assert torch.equal(cfm.gemm(a, w2, bias=bias, out_dtype=torch.float32), cfm.gemm(a, w2, bias=bias, out_dtype=torch.float32, tile=1))
+
+
 @pytest.mark.parametrize("B,T1,F1,C,N", [(2, 21, 17, 64, 64), (3, 45, 39, 256, 256), (1, 9, 9, 128, 320)])
 def test_gemm_256_tile_conv(cfm, B, T1, F1, C, N):
     """The implicit 3x3 / stride-2 convolution through the 256 x 256 tile equals the 128 x 128 kernel bit for bit."""
