@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void cfm_conv1_rows_kernel(const float* __rest
 }
 
 // Third form, on the matrix pipe: the 9 taps are a K = 32 contraction (3 taps of one input row in each of three 8-wide K groups, the
-// rest zero), the 16 x 16 x 32 MFMA takes the weights as its A operand (16 channel fragments of 4 VGPRs, built once per wavefront and
+// bias in the fourth, the rest zero), the 16 x 16 x 32 MFMA takes the weights as its A operand (16 channel fragments of 4 VGPRs, built once per wavefront and
 // kept in registers) and 16 output positions as its B operand, so a lane ends up with 4 consecutive channels of one position per
 // fragment.  The FMA forms above spend ~55 us of VALU time on 9 x 159 M multiply-adds at config 2; here the arithmetic is 4 us of MFMA
 // and what remains is the 319 MB write.  Inputs and weights are ROUNDED TO THE 16-BIT OPERAND TYPE (the FMA forms multiply in f32):
@@ -381,33 +381,40 @@ template <typename HT>
 __global__ __launch_bounds__(256) void cfm_conv1_mma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, u16* __restrict__ y, int B, int T, int F,
                                                             int T1, int F1, int C, const float* __restrict__ cm_mean,
-                                                            const float* __restrict__ cm_istd) {
+                                                            const float* __restrict__ cm_istd, int NH) {
     constexpr int MAXF = 16;                               // channel fragments (C <= 256)
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, kg = lane >> 4;
     const int nfr = C >> 4, cq = C >> 2;
+    const int nfh = nfr / NH, cqh = cq / NH, Ch = C / NH;  // per pass (NH = 2: the channels go through the LDS tile in two halves)
     const unsigned npos = (unsigned)B * (unsigned)T1 * (unsigned)F1;   // < 2^31 (host check)
     const unsigned nfrag = (npos + 15u) >> 4;
     const unsigned wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
-    // Weights: the MFMA's output row i = 4q + r of channel fragment j is made channel q*(C/4) + 4j + r, so that the lane that ends up with
-    // rows 4q .. 4q+3 of every fragment holds C/4 CONSECUTIVE channels of its position: 16-byte stores, 128 contiguous bytes per lane at
-    // C = 256.  A-operand lane (row l15, K group kg) holds taps 3kg .. 3kg+2 of its channel, then five zeros; K group 3 is zero.
+    // Weights: the MFMA's output row i = 4q + r of channel fragment j (pass h = j / nfh, jh = j % nfh) is made channel
+    // h*(C/NH) + q*(C/4/NH) + 4 jh + r, so that within a pass the lane that ends up with rows 4q .. 4q+3 of every fragment holds CONSECUTIVE
+    // channels of its position (16-byte LDS writes) and the pass as a whole covers C/NH consecutive channels (whole 128-byte lines in
+    // memory).  A-operand lane (row l15, K group kg) holds taps 3kg .. 3kg+2 of its channel, then five zeros.
+    // The BIAS rides in the contraction too: K group 3 multiplies the constants (1, 1) by (bias_hi, bias_lo), the 16-bit hi/lo split of the
+    // f32 bias (exact to ~16 mantissa bits), so the accumulator starts at zero and no 64 bias registers are carried: 151 -> ~90 VGPRs,
+    // four resident workgroups per CU instead of three.
     u32x4 wf[MAXF];
-    f32x4 bs[MAXF];
 #pragma unroll
     for (int j = 0; j < MAXF; ++j) {
         wf[j] = (u32x4){0u, 0u, 0u, 0u};
-        bs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (j < nfr) {
-            const int ch = (l15 >> 2) * cq + 4 * j + (l15 & 3);
+            const int ch = (j / nfh) * Ch + (l15 >> 2) * cqh + 4 * (j % nfh) + (l15 & 3);
             if (kg < 3) {
                 const float a = w[(3 * kg) * C + ch], b = w[(3 * kg + 1) * C + ch], c = w[(3 * kg + 2) * C + ch];
                 wf[j].x = pack2<HT>(a, b);
                 wf[j].y = pack2<HT>(c, 0.f);
+            } else {
+                const float bv = bias[ch];
+                const float hi = HT::to_f32(HT::from_f32(bv));
+                wf[j].x = pack2<HT>(hi, bv - hi);
             }
-            bs[j] = *(const f32x4*)(bias + kg * cq + 4 * j);    // the 4 channels this lane ends up with (as an output lane, q = kg)
         }
     }
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one fragment = 16 consecutive output positions; lanes of K group kg read input row 2 t1 + kg, columns 2 f1 .. 2 f1 + 2
     auto gather = [&](unsigned fr, unsigned& p_out, bool& live_out) __attribute__((always_inline)) {
         unsigned p = fr * 16u + (unsigned)l15;
@@ -427,40 +434,45 @@ __global__ __launch_bounds__(256) void cfm_conv1_mma_kernel(const float* __restr
             }
             xf.x = pack2<HT>(v0, v1);
             xf.y = pack2<HT>(v2, 0.f);
+        } else {
+            xf.x = pack2<HT>(1.0f, 1.0f);                   // times (bias_hi, bias_lo)
         }
         return xf;
     };
     extern __shared__ __attribute__((aligned(16))) u16 conv1_lds[];
-    const int rs = C + 8;                                  // LDS row stride in 16-bit elements (C * 2 + 16 bytes)
+    const int rs = Ch + 8;                                 // LDS row stride in 16-bit elements (one pass of channels + 16 bytes)
     u16* const tile = conv1_lds + (threadIdx.x >> 6) * (16 * rs);
     unsigned p = 0;
     bool live = false;
     auto emit = [&](unsigned fr, const u32x4& xf) __attribute__((always_inline)) {
-        // results go through a per-wavefront LDS tile [16 positions][C] (rows padded by 16 B: conflict-free 16-byte writes) so that the
-        // global stores are whole 1 KB runs: 64 lanes x 16 B = two positions' 512-byte channel vectors per instruction.  Stored straight
-        // from the MFMA layout, every instruction touched 16 (8-byte pieces) or 64 (16-byte pieces) different 128-byte lines:
-        // 119 and 256 us against 105 us for the FMA form.
-        u16* const tp = tile + l15 * rs + kg * cq;
+        // results go through a per-wavefront LDS tile [16 positions][C/NH] (rows padded by 16 B: conflict-free 16-byte writes) so that the
+        // global stores are whole runs of consecutive bytes: a position's C/NH channels (256 or 512 B) per 16 or 32 lanes.  Stored
+        // straight from the MFMA layout, every instruction touched 16 (8-byte pieces) or 64 (16-byte pieces) different 128-byte lines:
+        // 119 and 256 us against 105 us for the FMA form.  Two passes halve the tile: more wavefronts fit a CU.
+        u16* const tp = tile + l15 * rs + kg * cqh;
+        const unsigned pbase = fr * 16u;                     // the fragment's 16 positions are consecutive in memory
+        const int cpp = Ch >> 3;                             // 16-byte chunks per position and pass
+        for (int h = 0; h < NH; ++h) {
+            const int j0 = h * nfh, j1 = j0 + nfh;           // this pass's fragments (j0 even: NH = 2 only when nfr % 4 == 0)
 #pragma unroll
-        for (int j = 0; j < MAXF; j += 2) {
-            if (j < nfr) {
-                f32x4 a = HT::mfma(wf[j], xf, bs[j]);        // bias rides in as the accumulator
-                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-                if (j + 1 < nfr) {
-                    f32x4 c = HT::mfma(wf[j + 1], xf, bs[j + 1]);
-                    c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
-                    *(u32x4*)(tp + 4 * j) = pack8<HT>(a, c);
-                } else {
-                    *(u32x2*)(tp + 4 * j) = (u32x2){pack2<HT>(a.x, a.y), pack2<HT>(a.z, a.w)};
+            for (int j = 0; j < MAXF; j += 2) {              // static register indices; the pass test is wave-uniform
+                if (j >= j0 && j < j1) {
+                    f32x4 a = HT::mfma(wf[j], xf, zero4);
+                    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                    if (j + 1 < j1) {
+                        f32x4 c = HT::mfma(wf[j + 1 < MAXF ? j + 1 : j], xf, zero4);
+                        c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                        *(u32x4*)(tp + 4 * (j - j0)) = pack8<HT>(a, c);
+                    } else {
+                        *(u32x2*)(tp + 4 * (j - j0)) = (u32x2){pack2<HT>(a.x, a.y), pack2<HT>(a.z, a.w)};
+                    }
                 }
             }
-        }
-        // the fragment's 16 positions are consecutive in memory: 16 * C contiguous 16-bit values starting at position fr * 16
-        const unsigned pbase = fr * 16u;
-        const int cpp = C >> 3;                              // 16-byte chunks per position
-        for (int ch = lane; ch < 16 * cpp; ch += 64) {
-            const int pi = ch / cpp, cc = ch - pi * cpp;
-            if (pbase + (unsigned)pi < npos) *(u32x4*)(y + ((int64_t)(pbase + pi) * C + cc * 8)) = *(const u32x4*)(tile + pi * rs + cc * 8);
+            for (int ch = lane; ch < 16 * cpp; ch += 64) {
+                const int pi = ch / cpp, cc = ch - pi * cpp;
+                if (pbase + (unsigned)pi < npos)
+                    *(u32x4*)(y + ((int64_t)(pbase + pi) * C + h * Ch + cc * 8)) = *(const u32x4*)(tile + pi * rs + cc * 8);
+            }
         }
     };
     // two fragments per trip: both gathers are in flight before the first fragment's MFMAs and stores
@@ -574,14 +586,17 @@ extern "C" int cfm_conv1_relu_mma(const float* x, const float* w, const float* b
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
     const int64_t npos = (int64_t)B * T1 * F1, nfrag = (npos + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
+    // channel passes through the LDS tile: 1.  Two passes (half the tile, five resident workgroups per CU instead of four) measured
+    // slower, 87 vs 75 us: 256-byte instead of 512-byte runs per position and twice the store loops
+    const int NH = 1;
     int64_t nb = (nfrag + 3) / 4;
     if (nb > 256 * 4) nb = 256 * 4;                          // 4 workgroups of 4 wavefronts per CU (LDS), each wavefront strides over the fragments
-    const size_t lds = (size_t)4 * 16 * (C + 8) * 2;         // one [16][C + 8] 16-bit tile per wavefront
+    const size_t lds = (size_t)4 * 16 * (C / NH + 8) * 2;    // one [16][C/NH + 8] 16-bit tile per wavefront
     CfmProfScope prof("conv1_relu_mma", s, 2.0 * 9 * (double)npos * C, (double)B * T * F * 4 + (double)npos * C * 2);
     if (y_dtype == CFM_BF16)
-        CFM_LAUNCH((cfm_conv1_mma_kernel<BF16>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, (u16*)y, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd);
+        CFM_LAUNCH((cfm_conv1_mma_kernel<BF16>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, (u16*)y, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd, NH);
     else
-        CFM_LAUNCH((cfm_conv1_mma_kernel<F16>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, (u16*)y, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd);
+        CFM_LAUNCH((cfm_conv1_mma_kernel<F16>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, (u16*)y, B, T, F, T1, F1, C, cmvn_mean, cmvn_istd, NH);
     return cfm_launch_status("cfm_conv1_relu_mma");
 }
 
