@@ -214,6 +214,17 @@ def test_gemm_auto_split_matches_single_kernel(cfm):
     a = rnd((B * T2 * F2, 512), 104).bfloat16()
     w2 = rnd((N, 512), 105, 512 ** -0.5).bfloat16()
     assert torch.equal(cfm.gemm(a, w2, bias=bias, out_dtype=torch.float32), cfm.gemm(a, w2, bias=bias, out_dtype=torch.float32, tile=1))
+    # two N tiles of 256, fp16 operands, SiLU, a ragged last M tile: 548 tiles of 256 x 256 = 2.14 rounds -> split at row 65 536
+    a = rnd((70000, 512), 106).half()
+    w3 = rnd((512, 512), 107, 512 ** -0.5).half()
+    b3 = rnd((512,), 108, 0.1)
+    for odt in (torch.float32, torch.float16):
+        cfm.prof_reset(); cfm.prof_enable(True)
+        out = cfm.gemm(a, w3, bias=b3, act=cfm.ACT_SILU, out_dtype=odt)
+        torch.cuda.synchronize(); cfm.prof_enable(False)
+        names = set(cfm.prof_table())
+        assert len(names) == 2 and any(n.endswith("256x256") for n in names), names      # the tail picks its own (smaller) tile
+        assert torch.equal(out, cfm.gemm(a, w3, bias=b3, act=cfm.ACT_SILU, out_dtype=odt, tile=1))
 
 
 @pytest.mark.parametrize("B,T1,F1,C,N", [(2, 21, 17, 64, 64), (3, 45, 39, 256, 256), (1, 9, 9, 128, 320)])
