@@ -212,8 +212,11 @@ def mhsa(P, prefix, x, mask, cache=None, n_heads=4):
 # =============================================================================
 # Row E -- convolution module.  reference src/convolution.py:34-49
 # =============================================================================
-def conv_module(P, prefix, x, valid_mask, bn_eps=1e-5):
-    """x (B,T,D) time-major.  Channels-last restatement of
+def conv_module(P, prefix, x, valid_mask, bn_eps=1e-5, train=False, bn_out=None, momentum=0.1):
+    """x (B,T,D) time-major.  train=True: BatchNorm1d in training mode (convolution.py:44 under module.train()) -- batch mean and
+    BIASED variance over ALL B*T positions of each channel, padded frames included (quirk Q6); the running statistics it would
+    leave behind (momentum 0.1, UNBIASED variance, torch's rule) are returned through bn_out[prefix] = (mean, var).
+    Channels-last restatement of
     mask -> pointwise(D->2D) -> GLU -> depthwise k (zero pad only at the tensor edges) -> BatchNorm(eval) -> SiLU
     -> pointwise(D->D) -> mask.   Quirk Q5: masking precedes pw1, so padded frames carry GLU(bias) into the halo.
     """
@@ -234,7 +237,17 @@ def conv_module(P, prefix, x, valid_mask, bn_eps=1e-5):
     for tap in range(K):                                                    # cross-correlation, like nn.Conv1d
         z = z + ypad[:, tap:tap + T] * wd[:, tap]
     z = z + _w(P, prefix, "depthwise_conv.bias")
-    z = (z - _w(P, prefix, "norm.running_mean")) / torch.sqrt(_w(P, prefix, "norm.running_var") + bn_eps)
+    if train:
+        n = B * T
+        mu = z.reshape(n, D).mean(0)
+        var = ((z.reshape(n, D) - mu) ** 2).mean(0)
+        if bn_out is not None:
+            rm, rv = _w(P, prefix, "norm.running_mean"), _w(P, prefix, "norm.running_var")
+            bn_out[prefix] = ((1 - momentum) * rm + momentum * mu.detach().to(rm.dtype),
+                              (1 - momentum) * rv + momentum * (var.detach() * n / max(n - 1, 1)).to(rv.dtype))
+        z = (z - mu) / torch.sqrt(var + bn_eps)
+    else:
+        z = (z - _w(P, prefix, "norm.running_mean")) / torch.sqrt(_w(P, prefix, "norm.running_var") + bn_eps)
     z = z * _w(P, prefix, "norm.weight") + _w(P, prefix, "norm.bias")
     z = silu(z)
     w2 = _w(P, prefix, "pointwise_conv2.weight")[:, :, 0]
@@ -278,7 +291,8 @@ def subsampling(P, prefix, x, valid_mask, pe_table, offset=0, relative=True):
 # =============================================================================
 # Row A -- one conformer block.  reference src/encoder_layer.py:49-71
 # =============================================================================
-def encoder_layer(P, prefix, x, attn_msk, pos_embed, pad_msk=None, attn_cache=None, n_heads=4, relative=True):
+def encoder_layer(P, prefix, x, attn_msk, pos_embed, pad_msk=None, attn_cache=None, n_heads=4, relative=True, train=False, bn_out=None):
+    """train=True is module.train() with every dropout probability 0: the only difference is the BatchNorm of the conv module."""
     def ln(name, t):
         return layer_norm(t, _w(P, prefix, name + ".weight"), _w(P, prefix, name + ".bias"))
     x = x + 0.5 * ffn(P, prefix + "feed_forward_macaron.", ln("norm_ff_macaron", x))
@@ -287,7 +301,7 @@ def encoder_layer(P, prefix, x, attn_msk, pos_embed, pad_msk=None, attn_cache=No
     else:
         a, new_cache = mhsa(P, prefix + "self_attn.", ln("norm_mha", x), attn_msk, attn_cache, n_heads)
     x = x + a
-    x = x + conv_module(P, prefix + "conv_module.", ln("norm_conv", x), pad_msk)
+    x = x + conv_module(P, prefix + "conv_module.", ln("norm_conv", x), pad_msk, train=train, bn_out=bn_out)
     x = x + 0.5 * ffn(P, prefix + "feed_forward.", ln("norm_ff", x))
     return ln("norm_final", x), new_cache
 
@@ -310,7 +324,7 @@ class Config:
 
 
 def encoder_forward(P, cfg, x, lengths, decoding_chunk_size=0, num_decoding_left_chunks=-1,
-                    rand_chunk=None, rand_left=None, collect=None):
+                    rand_chunk=None, rand_left=None, collect=None, train=False, bn_out=None):
     """Whole-utterance forward.  Returns (y (B,T',D), valid mask (B,1,T') bool)."""
     T = x.size(1)
     valid = torch.from_numpy(~pad_mask(np.asarray(lengths), T)).unsqueeze(1)
@@ -321,7 +335,7 @@ def encoder_forward(P, cfg, x, lengths, decoding_chunk_size=0, num_decoding_left
                                                          decoding_chunk_size, cfg.static_chunk,
                                                          num_decoding_left_chunks, rand_chunk, rand_left)))
     for li in range(cfg.layers):
-        h, _ = encoder_layer(P, "encoders.%d." % li, h, am, pos, valid_s, None, cfg.h, cfg.relative)
+        h, _ = encoder_layer(P, "encoders.%d." % li, h, am, pos, valid_s, None, cfg.h, cfg.relative, train=train, bn_out=bn_out)
         if collect is not None:
             collect["layer_out_%d" % li] = h
     y = layer_norm(h, P["after_norm.weight"], P["after_norm.bias"])
@@ -403,6 +417,79 @@ def ctc_nll(logp, labels, blank=0):
             alpha[s] = a + lp[t, z[s]]
     tot = alpha[S - 1] if S == 1 else np.logaddexp(alpha[S - 1], alpha[S - 2])
     return float(-tot)
+
+
+def ctc_nll_and_grad(logp, labels, blank=0):
+    """(nll, d nll / d logits) of one utterance by the alpha-beta recursions in float64.  logp (T,V) = log_softmax(logits).
+    d nll / d logits[t,c] = softmax[t,c] - (1/P) sum_{s: z_s = c} alpha_t(s) beta_t(s) / y[t,c]   (Graves et al. 2006, eq. 16;
+    what nn.CTCLoss differentiates to, decoder.py:20-21).  An impossible alignment has nll = inf and (as torch without
+    zero_infinity) an undefined gradient: returned as zeros here."""
+    lp = np.asarray(logp, dtype=np.float64)
+    z = [blank]
+    for y in np.asarray(labels).tolist():
+        z += [int(y), blank]
+    S, T = len(z), lp.shape[0]
+    ninf = -np.inf
+    alpha = np.full((T, S), ninf)
+    beta = np.full((T, S), ninf)
+    alpha[0, 0] = lp[0, z[0]]
+    if S > 1:
+        alpha[0, 1] = lp[0, z[1]]
+    for t in range(1, T):
+        for s in range(S):
+            a = alpha[t - 1, s]
+            if s >= 1:
+                a = np.logaddexp(a, alpha[t - 1, s - 1])
+            if s >= 2 and z[s] != blank and z[s] != z[s - 2]:
+                a = np.logaddexp(a, alpha[t - 1, s - 2])
+            alpha[t, s] = a + lp[t, z[s]]
+    beta[T - 1, S - 1] = lp[T - 1, z[S - 1]]
+    if S > 1:
+        beta[T - 1, S - 2] = lp[T - 1, z[S - 2]]
+    for t in range(T - 2, -1, -1):
+        for s in range(S):
+            a = beta[t + 1, s]
+            if s + 1 < S:
+                a = np.logaddexp(a, beta[t + 1, s + 1])
+            if s + 2 < S and z[s + 2] != blank and z[s + 2] != z[s]:
+                a = np.logaddexp(a, beta[t + 1, s + 2])
+            beta[t, s] = a + lp[t, z[s]]
+    tot = alpha[T - 1, S - 1] if S == 1 else np.logaddexp(alpha[T - 1, S - 1], alpha[T - 1, S - 2])
+    grad = np.exp(lp)
+    if not np.isfinite(tot):
+        return float("inf"), np.zeros_like(grad)
+    occ = np.zeros_like(grad)
+    with np.errstate(under="ignore"):
+        for s in range(S):
+            occ[:, z[s]] += np.exp(alpha[:, s] + beta[:, s] - lp[:, z[s]] - tot)
+    return float(-tot), grad - occ
+
+
+class _CTCHead(torch.autograd.Function):
+    """sum_b nll_b as a differentiable function of the logits (B,T,V): forward and backward are the float64 numpy recursions above."""
+
+    @staticmethod
+    def forward(ctx, logits, enc_lens, labels, label_lens):
+        logp = torch.log_softmax(logits.detach().double(), dim=-1).numpy()
+        grad = np.zeros(logp.shape, dtype=np.float64)
+        total = 0.0
+        for b in range(logp.shape[0]):
+            n, u = int(enc_lens[b]), int(label_lens[b])
+            nll, g = ctc_nll_and_grad(logp[b, :n], np.asarray(labels)[b, :u])
+            grad[b, :n] = g
+            total += nll
+        ctx.grad = torch.from_numpy(grad).to(logits.dtype)
+        return logits.new_tensor(total)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ctx.grad * gout, None, None, None
+
+
+def ctc_head_loss_autograd(P, prefix, enc_out, enc_lens, labels, label_lens):
+    """Differentiable CTCDecoder.forward (dropout 0): loss = sum_b nll_b / padded label length (decoder.py:19-22)."""
+    logits = linear(enc_out, _w(P, prefix, "ctc_lo.weight"), _w(P, prefix, "ctc_lo.bias"))
+    return _CTCHead.apply(logits, np.asarray(enc_lens), np.asarray(labels), np.asarray(label_lens)) / np.asarray(labels).shape[1]
 
 
 def ctc_head_loss(P, prefix, enc_out, enc_lens, labels, label_lens):

@@ -51,3 +51,27 @@ def check_joint_case(g, c, out):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+# ---- gradient fixtures (tests/golden/make_golden.py pack_grad): full tensors, or sampled entries + float64 statistics ----
+def grad_ref_max(g, key):
+    """max|ref| of a packed tensor."""
+    if key in g:
+        return float(np.abs(g[key]).max()) if g[key].size else 0.0
+    return float(g[key + "__stats"][3])
+
+
+def grad_err(g, key, got, floor=0.0):
+    """max|got - ref| / max(max|ref|, floor) over what the fixture holds for `key`: every entry of a small tensor, or the sampled
+    entries of a big one together with its sum and sum of squares (scaled by the sum of |ref| / of ref^2)."""
+    a = np.asarray(got, dtype=np.float64).reshape(-1)
+    scale = max(grad_ref_max(g, key), floor, 1e-30)
+    if key in g:
+        ref = g[key].astype(np.float64).reshape(-1)
+        assert a.size == ref.size, (key, a.size, ref.size)
+        return float(np.abs(a - ref).max() / scale)
+    idx, vals, st = g[key + "__idx"], g[key + "__vals"].astype(np.float64), g[key + "__stats"]
+    e = float(np.abs(a[idx] - vals).max() / scale)
+    e_sum = abs(a.sum() - st[0]) / max(st[1], floor * a.size, 1e-30)
+    e_sq = abs((a * a).sum() - st[2]) / max(st[2], (floor ** 2) * a.size, 1e-30)
+    return max(e, float(e_sum), float(e_sq) / 2)       # d(x^2)/x^2 = 2 dx/x

@@ -315,9 +315,132 @@ def gen_joint():
     save("joint", arrays, dict(cases=cases))
 
 
+# ----------------------------------------------------------------------------- training (config 3): losses and gradients
+GRAD_SAMPLES = 1024
+
+
+def pack_grad(arrays, key, t, seed):
+    """Small tensors in full; big ones as GRAD_SAMPLES sampled entries (indices from RandomState(seed)) plus float64 sum / |sum| / sum of
+    squares -- enough to pin every gradient without storing 35 M floats."""
+    a = t2n(t).astype(np.float32).reshape(-1)
+    if a.size <= 4096:
+        arrays[key] = a.reshape(tuple(t.shape))
+        return
+    idx = np.random.RandomState(seed).randint(0, a.size, size=GRAD_SAMPLES).astype(np.int64)
+    arrays[key + "__idx"] = idx
+    arrays[key + "__vals"] = a[idx]
+    a64 = a.astype(np.float64)
+    arrays[key + "__stats"] = np.array([a64.sum(), np.abs(a64).sum(), (a64 * a64).sum(), np.abs(a64).max()], dtype=np.float64)
+
+
+def ctc_batch(rs, B, V, Umax, enc_valid):
+    """labels int64 [B,Umax] in [1,V), lengths <= the number of valid encoder frames / 2 so that an alignment exists."""
+    label_lens = np.array([max(1, min(Umax, int(rs.randint(max(1, Umax // 2), Umax + 1)), int(enc_valid[b]) // 2)) for b in range(B)], dtype=np.int64)
+    label_lens[0] = min(Umax, int(enc_valid[0]) // 2)
+    labels = rs.randint(1, V, size=(B, Umax)).astype(np.int64)
+    labels[-1, 1] = labels[-1, 0]                            # one repeated label
+    for b in range(B):
+        labels[b, label_lens[b]:] = 0
+    return labels, label_lens
+
+
+def gen_train():
+    """Train mode (module.train(), every dropout probability 0): CTC loss (decoder.py:18-23 on top of encoder.py:54-75), d loss / d
+    parameter for every parameter, and the BatchNorm running statistics after the step (batch statistics over ALL B*T' positions,
+    padded ones included -- quirk Q6)."""
+    import decoder as ref_decoder  # noqa: E402
+    zero_drop = dict(dropout=0.0, attention_dropout=0.0, pos_enc_dropout=0.0)
+    cases = {
+        "train_cfg1": (dict(CFG1, **zero_drop), 11, 21, 2, 200, [200, 163], 73, 9, 51, {}),
+        "train_cfg1_chunk": (dict(CFG1, **zero_drop), 11, 21, 2, 200, [200, 163], 73, 9, 51,
+                             dict(ctor=dict(use_dynamic_chunk_size=True), fw=dict(decoding_chunk_size=4, num_decoding_chunk_size=2))),
+        "train_cfg2s": (dict(CFG2, **zero_drop), 12, 22, 3, 120, [120, 97, 64], 5002, 7, 52, {}),
+    }
+    for name, (cfg, wseed, xseed, B, T, lens, V, Umax, cseed, extra) in cases.items():
+        enc = build_encoder(cfg, wseed, **extra.get("ctor", {})).train()
+        dec = synth.load_synth_(ref_decoder.CTCDecoder(V, cfg["encoder_dim"], 0.0), cseed).train()
+        x = torch.from_numpy(synth.fbank(xseed, B, T))
+        y, m = enc(x, torch.tensor(lens, dtype=torch.int32), **extra.get("fw", {}))
+        enc_lens = m.squeeze(1).sum(1)
+        labels, label_lens = ctc_batch(np.random.RandomState(cseed), B, V, Umax, enc_lens.numpy())
+        loss = dec(y, enc_lens, torch.from_numpy(labels), torch.from_numpy(label_lens))
+        loss.backward()
+        arrays = dict(loss=t2n(loss.reshape(1)), labels=labels, label_lens=label_lens, enc_lens=t2n(enc_lens))
+        pack_grad(arrays, "y", y, 7)
+        gi = 0
+        for pre, mod in (("enc.", enc), ("ctc.", dec)):
+            for k, p in mod.named_parameters():
+                assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+                pack_grad(arrays, "grad:" + pre + k, p.grad, 1000 + gi)
+                gi += 1
+        for k, v in enc.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+                arrays["bn:" + k] = t2n(v)
+        save(name, arrays, dict(cfg=cfg, wseed=wseed, xseed=xseed, batch=B, frames=T, lens=lens, V=V, Umax=Umax, cseed=cseed,
+                                ctor=extra.get("ctor", {}), fw=extra.get("fw", {}), grad_samples=GRAD_SAMPLES))
+
+    # ---- module level: out = m(x); (out * G).sum().backward() -> out, d/dx, d/dparam (D=144 modules of gen_modules) ----
+    D, H, FF, K, B, T = 144, 4, 576, 15, 3, 37
+    lens = [37, 30, 19]
+    pad = ~ref_utils.make_pad_mask(torch.tensor(lens, dtype=torch.int32), T).unsqueeze(1)
+    chunk_all = ref_utils.subsequent_chunk_mask(T, 5, 1, torch.device("cpu")).unsqueeze(0).expand(B, T, T)   # no fully-masked row
+    chunk_pad = chunk_all & pad                                                                                # has fully-masked rows
+    rpe = ref_attention.RelativePositionalEncoding(D, 0.0)
+    pos_b = rpe.pe[0:B]
+    arrays = {}
+
+    def run(tag, mod, x, call, gseed, pseed0):
+        mod.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        out = call(mod, xr)
+        G = torch.from_numpy(synth.normal(gseed, tuple(out.shape)))
+        (out * G).sum().backward()
+        pack_grad(arrays, tag + ":out", out, pseed0)
+        if xr.grad is not None:
+            pack_grad(arrays, tag + ":dx", xr.grad, pseed0 + 1)
+        for i, (k, p) in enumerate(mod.named_parameters()):
+            if p.grad is not None:
+                arrays[tag + ":finite:" + k] = np.array([int(torch.isfinite(p.grad).all())], dtype=np.int64)
+                pack_grad(arrays, tag + ":grad:" + k, torch.nan_to_num(p.grad, nan=0.0), pseed0 + 2 + i)
+        return out
+
+    x = torch.from_numpy(synth.normal(41, (B, T, D)))
+    m = synth.load_synth_(ref_feedforward.PositionwiseFeedForwardModule(D, 0.0, FF).train(), 31)
+    run("ffn", m, x, lambda mod, xr: mod(xr), 61, 2000)
+
+    x = torch.from_numpy(synth.normal(42, (B, T, D)))
+    m = synth.load_synth_(ref_attention.RelativeMultiHeadSelfAttentionModule(D, H, 0.0).train(), 32)
+    run("relmhsa_pad", m, x, lambda mod, xr: mod(xr, xr, xr, pad, pos_b)[0], 62, 2100)
+    run("relmhsa_chunk", m, x, lambda mod, xr: mod(xr, xr, xr, chunk_all, pos_b)[0], 63, 2200)
+    run("relmhsa_chunkpad", m, x, lambda mod, xr: mod(xr, xr, xr, chunk_pad, pos_b)[0], 64, 2300)   # reference: NaN gradients (recorded)
+    m = synth.load_synth_(ref_attention.MultiHeadSelfAttentionModule(D, H, 0.0).train(), 36)
+    run("mhsa_pad", m, x, lambda mod, xr: mod(xr, xr, xr, pad)[0], 65, 2400)
+
+    x = torch.from_numpy(synth.normal(43, (B, T, D)))
+    m = synth.load_synth_(ref_convolution.ConvolutionModule(D, K, FF).train(), 33)
+    run("conv_pad", m, x, lambda mod, xr: mod(xr, pad)[0], 66, 2500)
+    arrays["conv_pad:running_mean"], arrays["conv_pad:running_var"] = t2n(m.norm.running_mean), t2n(m.norm.running_var)
+    arrays["conv_pad:num_batches_tracked"] = t2n(m.norm.num_batches_tracked).reshape(1)
+
+    xf = torch.from_numpy(synth.fbank(44, 3, 83))
+    padf = ~ref_utils.make_pad_mask(torch.tensor([83, 60, 7], dtype=torch.int32), 83).unsqueeze(1)
+    m = synth.load_synth_(ref_convolution.ConvolutionSubSampling(80, D, ref_attention.RelativePositionalEncoding(D, 0.0)).train(), 34)
+    run("sub", m, xf, lambda mod, xr: mod(xr, padf)[0], 67, 2600)
+
+    x = torch.from_numpy(synth.normal(45, (B, T, D)))
+    m = synth.load_synth_(ref_encoder_layer.ConformerEncoderLayer(D, K, 0.0, 0.0, FF, H, True).train(), 35)
+    run("layer", m, x, lambda mod, xr: mod(xr, pad, pos_b, pad)[0], 68, 2700)
+    m = synth.load_synth_(ref_encoder_layer.ConformerEncoderLayer(D, K, 0.0, 0.0, FF, H, False).train(), 37)
+    run("layer_norel", m, x, lambda mod, xr: mod(xr, pad, None, pad)[0], 69, 2800)
+    save("train_mods_d144", arrays, dict(D=D, H=H, FF=FF, K=K, B=B, T=T, lens=lens, sub_lens=[83, 60, 7], grad_samples=GRAD_SAMPLES,
+                                         seeds=dict(ffn=(31, 41, 61), relmhsa=(32, 42, 62, 63, 64), mhsa=(36, 42, 65), conv=(33, 43, 66),
+                                                    sub=(34, 44, 67), layer=(35, 45, 68), layer_norel=(37, 45, 69))))
+
+
 if __name__ == "__main__":
     gen_masks()
     gen_modules()
     gen_encoders()
     gen_ctc()
     gen_joint()
+    gen_train()
