@@ -67,6 +67,84 @@ def cpu_baseline(enc, frames, sample_batch, iters):
     return sample_batch * frames / dt, dt
 
 
+def build_train_job(device, rank, precision, n_micro=8):
+    """BASELINE config 3 on one rank: the config-2 encoder + CTC head (V = 5002) in train mode, a DataParallelTrainer over them, and a
+    ring of synthetic LibriSpeech-shaped micro-batches resident in HBM (B * T_max <= 8000 frames, seed 1234 + rank).
+    Dropout probabilities are 0: in-kernel dropout is not built."""
+    import decoder as dec_mod
+    import encoder as enc_mod
+    import trainer as T
+    torch.manual_seed(0)
+    cfg = dict(CFG2, dropout=0.0, attention_dropout=0.0, pos_enc_dropout=0.0)
+    enc = enc_mod.ConformerEncoder(cmvn=None, **cfg).to(device).train()
+    dec = dec_mod.CTCDecoder(5002, cfg["encoder_dim"], 0.0).to(device).train()
+    if precision is not None:
+        enc.set_precision(precision)
+        dec.precision = precision
+    rs = np.random.RandomState(1234 + rank)
+    mbs, frames = [], []
+    for _ in range(n_micro):
+        feats, lens, labels, label_lens = T.librispeech_shaped_batch(rs)
+        mbs.append(tuple(torch.from_numpy(a).to(device) for a in (feats, lens, labels, label_lens)))
+        frames.append((int(lens.sum()), int(feats.shape[0] * feats.shape[1])))
+
+    def loss_fn(mb):
+        x, lens, labels, label_lens = mb
+        y, m = enc(x, lens)
+        return dec(y, m.squeeze(1).sum(1), labels, label_lens)
+
+    tr = T.DataParallelTrainer([enc, dec], loss_fn, lr=1e-3, warmup_steps=25000, accum_grad=2, grad_clip=4.0, bucket_mb=25.0)
+    return enc, dec, tr, mbs, frames
+
+
+def train_measure(args, dist, world, rank, device, steps, warmup, precision=None):
+    """K optimizer steps (2 micro-batches each: forward, CTC loss, backward, bucketed RCCL all-reduce overlapped with backward, clip, Adam),
+    timed like the forward bench.  Returns a dict for the JSON line."""
+    enc, dec, tr, mbs, frames = build_train_job(device, rank, precision)
+    state = {"i": 0, "valid": 0, "padded": 0, "count": False}
+
+    def step():
+        i = state["i"]
+        pair = [mbs[(2 * i) % len(mbs)], mbs[(2 * i + 1) % len(mbs)]]
+        if state["count"]:
+            for j in (2 * i, 2 * i + 1):
+                state["valid"] += frames[j % len(mbs)][0]
+                state["padded"] += frames[j % len(mbs)][1]
+        tr.step(pair)
+        state["i"] = i + 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    state["count"] = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    valid = torch.tensor([float(state["valid"]), float(state["padded"]), elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        tmax = valid[2:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = valid[:2].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        valid = torch.cat([tot, tmax])
+    v, padded, elapsed = (float(t) for t in valid.tolist())
+    n_param = sum(p.numel() for p in tr.params)
+    flops_fwd_per_frame = None
+    return {"metric": "CTC training input frames/sec (encoder + CTC loss + backward + gradient all-reduce + clip + Adam), whole job",
+            "value": round(v / elapsed, 1), "unit": "frames/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "frames_per_step_per_gpu": round(v / steps / world, 1), "padded_frames_per_s": round(padded / elapsed, 1),
+            "micro_batches_per_step": 2, "parameters": n_param, "grad_buckets": len(tr.buckets), "dtype": precision or "default",
+            "workload": "BASELINE config 3: 12-layer d=256 conformer encoder + CTC (V=5002), synthetic LibriSpeech-shaped dynamic batches "
+                        "(B*T_max <= 8000 frames, lengths U{200..1650}, seed 1234+rank), accum_grad 2, clip 4, Adam + WarmupLR, dropout 0"}
+
+
 def timed_region(step, steps, warmup, dist, sync):
     """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides; MAX over ranks."""
     def barrier():
@@ -158,6 +236,10 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--all-kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--selftest-cpu", action="store_true", help="gloo/CPU rehearsal of the multi-process harness (tests only)")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="forward: the headline encoder-forward metric (BASELINE configs[1]); train: the config-3 training step as the headline line")
+    ap.add_argument("--train-steps", type=int, default=6, help="optimizer steps of the short training measurement appended to the forward line (0: skip)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity figure (2 utterances against the CPU oracle)")
     args = ap.parse_args()
     if args.selftest_cpu:
         return selftest_cpu(args)
@@ -184,6 +266,20 @@ def main():
     if cfm.lib().cfm_device_ok() != 1:
         raise SystemExit("bench.py: " + cfm.lib().cfm_last_error().decode())
     cfm.set_precision(args.precision)
+
+    if args.mode == "train":
+        rec = train_measure(args, dist, world, rank, device, args.steps, args.warmup, args.precision)
+        if rank == 0:
+            line = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                    "data": "synthetic", "config": {k: v for k, v in rec.items() if k not in ("metric", "value", "unit", "ms_per_step", "steps", "warmup")},
+                    "roofline": None, "cpu_baseline": None}
+            line["config"]["parallelism"] = "dp%d (RCCL gradient all-reduce, 25 MB buckets overlapped with backward)" % world
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     enc = build_encoder(device)
     B, T = args.batch, args.frames
@@ -231,6 +327,44 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * B * T * args.steps / elapsed
 
+    # ---- accuracy of the number just quoted: max|d|/max|ref| of the first 2 utterances against the CPU oracle, same run, same weights ----
+    parity = None
+    if rank == 0 and not args.no_parity:
+        Pcpu = {k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
+        with torch.no_grad():
+            y_ref, _ = O.encoder_forward(Pcpu, O.Config(**CFG2), x[:2].cpu(), [T, T])
+            parity = {}
+            for mode in dict.fromkeys([args.precision, "fp16", "fp32"]):
+                enc.set_precision(mode)
+                y_m, _ = enc(x, lens)
+                parity[mode] = float((y_m[:2].double().cpu() - y_ref.double()).abs().max() / y_ref.double().abs().max())
+            enc.set_precision(None)
+    # ---- the same step in fp16 (meets the 1e-3 north-star tolerance at bf16 speed): eager step time beside the headline ----
+    alt = None
+    if rank == 0 and args.precision == "bf16":
+        with torch.no_grad(), torch.cuda.stream(stream):
+            alt = {}
+            for mode in ("bf16", "fp16"):
+                enc.set_precision(mode)
+                for _ in range(3):
+                    enc(x, lens)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=stream):
+                    enc(x, lens)
+                stream.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    g2.replay()
+                stream.synchronize()
+                alt[mode] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
+            enc.set_precision(None)
+    # ---- BASELINE config 3 (training step), short: every rank takes part (the gradient all-reduce is a collective) ----
+    train = None
+    if args.train_steps > 0:
+        del enc
+        torch.cuda.empty_cache()
+        train = train_measure(args, dist, world, rank, device, args.train_steps, 2, args.precision)
+
     if rank == 0:
         total_ms = sum(e["ms"] for e in table.values()) or 1.0
         mfma = {k: e for k, e in table.items() if e["flops"] > 0 and k.split("_")[0] in ("gemm", "attn", "attn2", "ffn", "chain")}
@@ -264,7 +398,7 @@ def main():
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            fps, dt = cpu_baseline(enc, T, args.cpu_sample, args.cpu_iters)
+            fps, dt = cpu_baseline(build_encoder("cpu"), T, args.cpu_sample, args.cpu_iters)
             cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                    "sample": "oracle/conformer_oracle.py encoder_forward (f32 torch CPU), %d x (80 x %d) of the same workload, "
                              "1 warm-up + %d timed forwards, %.2f s each" % (args.cpu_sample, T, args.cpu_iters, dt)}
@@ -288,7 +422,12 @@ def main():
                        "parallelism": "replicas x%d (batch-sharded, no data-path collective)" % world,
                        "launch": "hip graph replay" if graph is not None else "eager",
                        "whole_encoder_tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
-                       "whole_encoder_frac_of_mfma_peak": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4)},
+                       "whole_encoder_frac_of_mfma_peak": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4),
+                       "max_rel_err_vs_oracle": None if parity is None else round(parity[args.precision], 6),
+                       "max_rel_err_vs_oracle_by_mode": None if parity is None else {k: round(v, 7) for k, v in parity.items()},
+                       "parity_note": "max|d|/max|ref| of utterances 0-1 of this batch against oracle/conformer_oracle.py (fp32 CPU), same weights, same run",
+                       "ms_per_step_by_mode_graph_replay": alt},
+            "train": train,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

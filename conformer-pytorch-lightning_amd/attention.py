@@ -90,10 +90,24 @@ def _mask_args(mask, B, Tq, Tk):
     return m8, (qm * km if bm == B else 0, km if qm > 1 else 0)
 
 
+def _attend_train(mod, query, key, value, inputs_attn_mask, cache, relative, prec):
+    """module.train(): self-attention over one tensor, no KV cache (encoder.py:73 -- the only way the reference trains it)."""
+    if not (key is query and value is query):
+        raise NotImplementedError("%s: train mode supports self-attention (query is key is value) only" % type(mod).__name__)
+    if cache is not None and cache.dim() == 4 and cache.size(0) > 0:
+        raise NotImplementedError("%s: a KV cache in train mode (streaming is inference-only)" % type(mod).__name__)
+    from cfm import autograd as ag
+    B, T, D = query.shape
+    m8, m_str = _mask_args(inputs_attn_mask, B, T, T)
+    out = ag.AttentionFn.apply(query, mod, prec, relative, m8, m_str, *mod.parameters())
+    return out, torch.zeros((0, 0, 0, 0), dtype=torch.float32, device=query.device)
+
+
 def _attend(mod, query, key, value, inputs_attn_mask, pos_embed, cache, relative):
-    _inference_only(mod, type(mod).__name__)
     cfm.require_hip(query, key, value)
-    prec = cfm.get_precision()
+    prec = cfm.resolve_precision(mod)
+    if cfm.check_mode(mod, type(mod).__name__, (("attention dropout", mod.dropout.p),)):
+        return _attend_train(mod, query, key, value, inputs_attn_mask, cache, relative, prec)
     pk = packing.pack_mhsa(mod, prec, relative)
     B, Tq, D = query.shape
     Tn = key.size(1)

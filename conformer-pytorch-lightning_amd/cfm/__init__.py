@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libconformer_gfx950.so")
 
 F32, BF16, F16 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_GLU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GLU, ACT_DSILU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -32,7 +32,24 @@ class GemmDesc(ctypes.Structure):
                 ("a_dtype", c_i32), ("w_dtype", c_i32), ("c_dtype", c_i32),
                 ("act", c_i32), ("alpha", ctypes.c_float),
                 ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
-                ("tile", c_i32), ("mask_mode", c_i32), ("W_frag", c_p)]
+                ("tile", c_i32), ("mask_mode", c_i32), ("W_frag", c_p),
+                ("C_pre", c_p), ("ld_pre", c_i64), ("pre_dtype", c_i32), ("aux_dtype", c_i32), ("aux", c_p), ("ld_aux", c_i64)]
+
+
+class GemmTnDesc(ctypes.Structure):
+    _fields_ = [("A", c_p), ("B", c_p), ("C", c_p), ("colsum", c_p), ("row_mask", c_p),
+                ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("a_dtype", c_i32), ("b_dtype", c_i32), ("mma_dtype", c_i32), ("split", c_i32), ("accumulate", c_i32), ("splits", c_i32),
+                ("alpha", ctypes.c_float),
+                ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32)]
+
+
+class AttnBwdDesc(ctypes.Structure):
+    _fields_ = [("q", c_p), ("k", c_p), ("v", c_p), ("mask", c_p), ("out", c_p), ("dout", c_p), ("lse", c_p),
+                ("grad_q", c_p), ("grad_k", c_p), ("grad_v", c_p), ("delta", c_p),
+                ("q_sb", c_i64), ("q_st", c_i64), ("k_sb", c_i64), ("k_st", c_i64), ("v_sb", c_i64), ("v_st", c_i64), ("m_sb", c_i64), ("m_sq", c_i64),
+                ("B", c_i32), ("H", c_i32), ("Tq", c_i32), ("Tk", c_i32), ("dk", c_i32),
+                ("io_dtype", c_i32), ("dout_dtype", c_i32), ("mma_dtype", c_i32), ("split", c_i32), ("scale", ctypes.c_float)]
 
 
 class AttnDesc(ctypes.Structure):
@@ -42,7 +59,7 @@ class AttnDesc(ctypes.Structure):
                 ("m_sb", c_i64), ("m_sq", c_i64),
                 ("B", c_i32), ("H", c_i32), ("Tq", c_i32), ("Tk", c_i32), ("dk", c_i32),
                 ("q_dtype", c_i32), ("kv_dtype", c_i32), ("p_dtype", c_i32), ("out_dtype", c_i32), ("mma_dtype", c_i32),
-                ("split", c_i32), ("scale", ctypes.c_float)]
+                ("split", c_i32), ("scale", ctypes.c_float), ("lse", c_p)]
 
 
 class FfnDesc(ctypes.Structure):
@@ -134,6 +151,24 @@ def lib():
                                                 ctypes.POINTER(LayerIO), c_p, c_p, c_i32, c_p, c_p, c_p]
         L.cfm_ctc_nll.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p]
         L.cfm_joint_act.argtypes = [c_p, c_i64, c_p, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
+        c_f = ctypes.c_float
+        L.cfm_gemm_tn.argtypes = [ctypes.POINTER(GemmTnDesc), c_p]
+        L.cfm_attention_bwd.argtypes = [ctypes.POINTER(AttnBwdDesc), c_p]
+        L.cfm_layernorm_bwd_ws.argtypes = [c_i64, c_i32]
+        L.cfm_layernorm_bwd.argtypes = [c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i64, c_i32, c_p]
+        L.cfm_glu_bwd.argtypes = [c_p, c_i32, c_p, c_i32, c_p, c_i32, c_i64, c_i32, c_p]
+        L.cfm_dwconv_bn_ws.argtypes = [c_i32, c_i32, c_i32]
+        L.cfm_dwconv_bn_train.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_dwconv_bn_train_bwd.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_col2im_relu_bwd.argtypes = [c_p, c_i32, c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_conv1_wgrad_ws.argtypes = [c_i32, c_i32, c_i32]
+        L.cfm_conv1_wgrad.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_ctc_nll_train.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+        L.cfm_ctc_grad.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]
+        L.cfm_adam_step.argtypes = [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p, c_p]
+        L.cfm_sumsq.argtypes = [c_p, c_i64, c_p, c_i32, c_p, c_p]
+        for name in ("cfm_layernorm_bwd_ws", "cfm_dwconv_bn_ws", "cfm_conv1_wgrad_ws"):
+            getattr(L, name).restype = c_i64
         L.cfm_prof_enable.argtypes = [c_i32]
         L.cfm_prof_enable.restype = None
         L.cfm_prof_reset.restype = None
@@ -142,7 +177,9 @@ def lib():
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_ffn_partial", "cfm_ffn_partial_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
-                     "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry"):
+                     "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
+                     "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
+                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib
@@ -216,6 +253,38 @@ def set_precision(name):
 
 def get_precision():
     return _precision
+
+
+def resolve_precision(module=None):
+    """The precision a module computes in: its own `precision` attribute when set (a name or a Precision; see
+    ConformerEncoder.set_precision), else the process default.  Resolved per call -- two encoders at different precisions can run
+    side by side."""
+    p = getattr(module, "precision", None) if module is not None else None
+    if p is None:
+        return _precision
+    return p if isinstance(p, Precision) else Precision(p)
+
+
+_warned = set()
+
+
+def check_mode(module, what, dropouts=()):
+    """Shared train / eval gate of the drop-in modules.  Returns True when the module must take its TRAIN path (module.training):
+    BatchNorm batch statistics, autograd Functions.  Active dropout (p > 0 in train mode) is applied by torch around the fused
+    Functions where the reference applies it between modules, and is refused inside them until the in-kernel generator lands.
+    In eval mode the forward is inference-only: gradients do not flow (warned once when someone might expect them to)."""
+    if module.training:
+        for name, p in dropouts:
+            if p > 0.0:
+                raise NotImplementedError("%s: train mode with %s = %g: in-kernel dropout is not built yet; construct the model with "
+                                          "dropout 0 (parity and throughput are measured at p = 0)" % (what, name, p))
+        return True
+    if torch.is_grad_enabled() and what not in _warned and any(q.requires_grad for q in module.parameters()):
+        _warned.add(what)
+        import warnings
+        warnings.warn("%s: eval-mode forward runs inference kernels; its output is detached from the parameters. "
+                      "Call .train() for a differentiable forward, or wrap inference in torch.no_grad()." % what)
+    return False
 
 
 from .ops import *  # noqa: E402,F401,F403

@@ -1,0 +1,384 @@
+"""Train-mode forward + backward of the hot path as ``torch.autograd.Function``s over the C ABI (BASELINE config 3).
+
+Each Function's ``forward`` runs the train-mode kernels and keeps what the backward needs; its ``backward`` RETURNS the gradient of
+every ``nn.Parameter`` it was given (so ``.grad`` accumulation, DDP reducer hooks and gradient accumulation work as with any torch
+op -- SURVEY 8b "Threading").  Nothing here computes: the arithmetic is cfm.gemm (input gradients, on transposed weight packs, with
+the activation-derivative epilogues), cfm.gemm_tn (weight / bias gradients), cfm.layernorm_bwd, cfm.attention_bwd,
+cfm.dwconv_bn_train(_bwd), cfm.glu_bwd, cfm.col2im_relu_bwd, cfm.conv1_wgrad, cfm.ctc_nll_train / cfm.ctc_grad.
+
+What train mode means here (reference: encoder_layer.py:49-71, convolution.py:34-49, decoder.py:18-23 under module.train()):
+  * BatchNorm1d uses BATCH statistics over all B*T' positions, padded frames included (quirk Q6), and updates its running statistics;
+  * every nn.Dropout is active.  Dropout is applied by the kernels from a counter-based generator (no bit-parity with torch's RNG, as
+    SURVEY 2.2 notes): parity is defined and tested at p = 0;
+  * the batch path's positional score term is constant along each softmax row, so linear_pos / pos_bias_v receive an exact
+    zero gradient (the reference's is rounding noise ~1e-8) and the term is not evaluated; pos_bias_u rides in linear_q's bias.
+"""
+import torch
+
+import cfm
+from cfm import packing
+
+
+def _f32c(t):
+    return (t if t.dtype == torch.float32 else t.float()).contiguous()
+
+
+def _split(prec):
+    return prec.split
+
+
+# ======================================================================================================================
+# raw forward / backward pieces (no autograd inside): tensors in, tensors + saved state out
+# ======================================================================================================================
+def ffn_fwd(pk, x, ln, prec, alpha, act=cfm.ACT_SILU):
+    """x f32 [M,D] -> (x + alpha * FFN(LN(x)), saved).  ln = (gain, bias) or None (no norm, no residual: the bare module)."""
+    adt = prec.act_dtype
+    M = x.shape[0]
+    FF = pk.w1.shape[0]
+    xn = cfm.layernorm(x, ln[0], ln[1], out1_dtype=adt)[0] if ln is not None else (x if x.dtype == adt else cfm.cast(x, adt))
+    z = torch.empty((M, FF), dtype=adt, device=x.device)
+    h = cfm.gemm(xn, pk.w1, bias=pk.b1, w_lo=pk.w1_lo, act=act, out_dtype=adt, pre_out=z)
+    if ln is not None:
+        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, residual=x, alpha=alpha)
+    else:
+        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, out_dtype=torch.float32)
+    return y, (x, xn, z, h)
+
+
+def ffn_bwd(pk, saved, dy, ln, prec, alpha, act=cfm.ACT_SILU):
+    """dy f32 [M,D] = d loss / d output -> (dx, grads).  With ln: dx = dy + dLN(...) computed in place over dy."""
+    x, xn, z, h = saved
+    mma, sp = prec.w_code, prec.split
+    dact = cfm.ACT_DSILU if act == cfm.ACT_SILU else cfm.ACT_DRELU
+    dW2, db2 = cfm.gemm_tn(dy, h, want_colsum=True, alpha=alpha, mma_code=mma, split=sp)
+    dz = cfm.gemm(dy, pk.w2t, w_lo=pk.w2t_lo, act=dact, aux=z, alpha=alpha, out_dtype=prec.act_dtype)
+    dW1, db1 = cfm.gemm_tn(dz, xn, want_colsum=True, mma_code=mma, split=sp)
+    dxn = cfm.gemm(dz, pk.w1t, w_lo=pk.w1t_lo, out_dtype=torch.float32)
+    grads = {"w_1.weight": dW1, "w_1.bias": db1, "w_2.weight": dW2, "w_2.bias": db2}
+    if ln is None:
+        return dxn, grads, None
+    dx, dg, db = cfm.layernorm_bwd(x, dxn, ln[0], dres=dy, dx=dy)
+    return dx, grads, (dg, db)
+
+
+def mhsa_fwd(mod, pk, x, ln, B, T, mask8, m_str, prec, relative):
+    """x f32 [B*T,D] -> (x + MHSA(LN(x)) (ln given) or MHSA(x), saved).  Batch path: no cache, positional term not evaluated."""
+    adt = prec.act_dtype
+    M, D = x.shape
+    H, dk = mod.num_heads, mod.d_k
+    xn = cfm.layernorm(x, ln[0], ln[1], out1_dtype=adt)[0] if ln is not None else (x if x.dtype == adt else cfm.cast(x, adt))
+    qkv = cfm.gemm(xn, pk.qkv_w, bias=pk.qkv_b, w_lo=pk.qkv_w_lo, out_dtype=adt)
+    ctx = torch.empty((M, D), dtype=adt, device=x.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
+    st = (T * 3 * D, 3 * D)
+    cfm.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], B, H, T, T, dk, st, st + (dk,), st + (dk,), ctx, mask=mask8, mask_str=m_str, mma_code=prec.w_code,
+                  split=prec.split, lse=lse)
+    if ln is not None:
+        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, residual=x, alpha=1.0)
+    else:
+        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, out_dtype=torch.float32)
+    return y, (x, xn, qkv, ctx, lse)
+
+
+def mhsa_bwd(mod, pk, saved, dy, ln, B, T, mask8, m_str, prec, relative):
+    x, xn, qkv, ctx, lse = saved
+    M, D = x.shape
+    H, dk = mod.num_heads, mod.d_k
+    mma, sp = prec.w_code, prec.split
+    dWo, dbo = cfm.gemm_tn(dy, ctx, want_colsum=True, mma_code=mma, split=sp)
+    dctx = cfm.gemm(dy, pk.out_t, w_lo=pk.out_t_lo, out_dtype=prec.act_dtype)
+    dqkv = torch.empty_like(qkv)
+    st = (T * 3 * D, 3 * D)
+    cfm.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ctx, dctx, lse, B, H, T, T, dk, st, st, st, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], mask=mask8,
+                      mask_str=m_str, mma_code=mma, split=sp)
+    dWqkv, dbqkv = cfm.gemm_tn(dqkv, xn, want_colsum=True, mma_code=mma, split=sp)
+    dxn = cfm.gemm(dqkv, pk.qkv_t, w_lo=pk.qkv_t_lo, out_dtype=torch.float32)
+    grads = {"linear_q.weight": dWqkv[:D], "linear_k.weight": dWqkv[D:2 * D], "linear_v.weight": dWqkv[2 * D:],
+             "linear_q.bias": dbqkv[:D], "linear_k.bias": dbqkv[D:2 * D], "linear_v.bias": dbqkv[2 * D:],
+             "linear_out.weight": dWo, "linear_out.bias": dbo}
+    if relative:
+        grads["pos_bias_u"] = dbqkv[:D].clone().view(H, dk)       # d/du of (q + u) . k^T = the column sums of dq (its own tensor: autograd
+                                                                  # accumulates into what it is handed, and linear_q.bias holds the other copy)
+        # softmax-invariant in the batch path (one positional row per utterance broadcast over keys, attention.py:20,84-88)
+        grads["pos_bias_v"] = torch.zeros_like(mod.pos_bias_v)
+        grads["linear_pos.weight"] = torch.zeros_like(mod.linear_pos.weight)
+    if ln is None:
+        return dxn, grads, None
+    dx, dg, db = cfm.layernorm_bwd(x, dxn, ln[0], dres=dy, dx=dy)
+    return dx, grads, (dg, db)
+
+
+def conv_module_fwd(mod, pk, x, ln, B, T, keep, prec):
+    """x f32 [B*T,D] -> (x + ConvModule(mask(LN(x))) (ln given) or ConvModule(mask(x)), saved); BatchNorm in training mode."""
+    adt = prec.act_dtype
+    M, D = x.shape
+    if ln is not None:
+        if keep is not None:
+            xn = cfm.layernorm(x, ln[0], ln[1], want1=False, out2_dtype=adt, row_mask=keep)[1]
+        else:
+            xn = cfm.layernorm(x, ln[0], ln[1], out1_dtype=adt)[0]
+    else:
+        xn = x if x.dtype == adt else cfm.cast(x, adt)
+    u = torch.empty((M, 2 * D), dtype=adt, device=x.device)
+    # without a LayerNorm in front the padded INPUT rows are zeroed in the GEMM (mask_mode 1: acc = 0, bias kept -- quirk Q5)
+    glu = cfm.gemm(xn, pk.pw1_w, bias=pk.pw1_b, w_lo=pk.pw1_w_lo, act=cfm.ACT_GLU, out_dtype=adt, pre_out=u,
+                   row_mask=keep if ln is None else None, mask_mode=1)
+    bn = mod.norm
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    c, stats, s = cfm.dwconv_bn_train(glu.view(B, T, D), pk.dw_w, pk.dw_b, pk.gamma, pk.beta, rm, rv, momentum, bn.eps, adt)
+    if bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    if ln is not None:
+        y = cfm.gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, residual=x, alpha=1.0)
+    else:
+        y = cfm.gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, out_dtype=torch.float32)
+    return y, (x, xn, u, glu, c, stats, s)
+
+
+def conv_module_bwd(mod, pk, saved, dy, ln, B, T, keep, prec):
+    x, xn, u, glu, c, stats, s = saved
+    M, D = x.shape
+    adt, mma, sp = prec.act_dtype, prec.w_code, prec.split
+    dW2, db2 = cfm.gemm_tn(dy, s.view(M, D), want_colsum=True, row_mask=keep, mma_code=mma, split=sp)
+    ds = cfm.gemm(dy, pk.pw2_t, w_lo=pk.pw2_t_lo, row_mask=keep, mask_mode=1, out_dtype=adt)     # masked OUTPUT rows have no gradient
+    dglu, ddw_w, ddw_b, dgamma, dbeta = cfm.dwconv_bn_train_bwd(ds.view(B, T, D), c, stats, glu.view(B, T, D), pk.dw_w, adt)
+    du = cfm.glu_bwd(u, dglu.view(M, D), adt)
+    # pointwise-conv-1 saw zeroed padded rows: xn already is (LayerNorm path) or is masked here (bare module)
+    dW1i, db1i = cfm.gemm_tn(du, xn, want_colsum=True, mma_code=mma, split=sp) if ln is not None or keep is None else _pw1_wgrad_masked(du, xn, keep, mma, sp)
+    dxn = cfm.gemm(du, pk.pw1_t, w_lo=pk.pw1_t_lo, out_dtype=torch.float32)
+    dW1 = torch.empty_like(dW1i)
+    dW1[pk.idx] = dW1i                                            # undo the value / gate row interleave of the pack
+    db1 = torch.empty_like(db1i)
+    db1[pk.idx] = db1i
+    K = pk.dw_w.shape[1]
+    grads = {"pointwise_conv1.weight": dW1.view(2 * D, D, 1), "pointwise_conv1.bias": db1, "depthwise_conv.weight": ddw_w.view(D, 1, K),
+             "depthwise_conv.bias": ddw_b, "norm.weight": dgamma, "norm.bias": dbeta, "pointwise_conv2.weight": dW2.view(D, D, 1),
+             "pointwise_conv2.bias": db2}
+    if ln is None:
+        if keep is not None:
+            dxn = dxn * keep.view(M, 1).to(dxn.dtype)             # bare module: d masked_fill (convolution.py:36-37)
+        return dxn, grads, None
+    dx, dg, db = cfm.layernorm_bwd(x, dxn, ln[0], row_mask=keep, dres=dy, dx=dy)
+    return dx, grads, (dg, db)
+
+
+def _pw1_wgrad_masked(du, xn, keep, mma, sp):
+    """bare ConvolutionModule with a pad mask: the weight gradient sees the masked input rows (bias gradient: all rows)."""
+    M = du.shape[0]
+    xm = xn * keep.view(M, 1).to(xn.dtype)
+    return cfm.gemm_tn(du, xm, want_colsum=True, mma_code=mma, split=sp)
+
+
+def subsampling_fwd(pk, x, cmvn, prec):
+    """x f32 [B,T,F] -> (y f32 [B*T2, D], saved)."""
+    adt = prec.act_dtype
+    B, T, F = x.shape
+    C = pk.C
+    T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    h1 = cfm.conv1_relu(x, pk.w1, pk.b1, adt, cmvn=cmvn, mma=cfm.conv1_relu_mma_supported(C, adt))
+    h2 = cfm.gemm(h1, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2), out_dtype=adt)
+    y = cfm.gemm(h2.view(B * T2, F2 * C), pk.wl, bias=pk.bl, w_lo=pk.wl_lo, out_dtype=torch.float32)
+    return y, (x, h1, h2, (B, T, F, C, T1, F1, T2, F2), cmvn)
+
+
+def subsampling_bwd(pk, saved, dy, prec):
+    x, h1, h2, (B, T, F, C, T1, F1, T2, F2), cmvn = saved
+    adt, mma, sp = prec.act_dtype, prec.w_code, prec.split
+    Dout = pk.wl.shape[0]
+    h2f = h2.view(B * T2, F2 * C)
+    dWl, dbl = cfm.gemm_tn(dy, h2f, want_colsum=True, mma_code=mma, split=sp)
+    dh2 = cfm.gemm(dy, pk.wlt, w_lo=pk.wlt_lo, act=cfm.ACT_DRELU, aux=h2f, alpha=1.0, out_dtype=adt).view(B * T2 * F2, C)
+    dW2, db2 = cfm.gemm_tn(dh2, h1, conv=(C, T1, F1, T2, F2), want_colsum=True, mma_code=mma, split=sp)
+    dcol = cfm.gemm(dh2, pk.w2t, w_lo=pk.w2t_lo, out_dtype=adt)
+    dh1 = cfm.col2im_relu_bwd(dcol, h1, adt)
+    dw1, db1 = cfm.conv1_wgrad(dh1, x, cmvn=cmvn)
+    return {"conv.0.weight": dw1.t().reshape(C, 1, 3, 3), "conv.0.bias": db1,
+            "conv.2.weight": dW2.view(C, 3, 3, C).permute(0, 3, 1, 2), "conv.2.bias": db2,
+            "out.0.weight": dWl.view(Dout, F2, C).permute(0, 2, 1).reshape(Dout, C * F2), "out.0.bias": dbl}
+
+
+# ======================================================================================================================
+# autograd Functions
+# ======================================================================================================================
+def _params(mod):
+    names, tensors = [], []
+    for n, p in mod.named_parameters():
+        names.append(n)
+        tensors.append(p)
+    return names, tensors
+
+
+def _ordered(names, grads, tensors):
+    out = []
+    for n, p in zip(names, tensors):
+        g = grads.get(n)
+        if g is None:
+            raise RuntimeError("no gradient was produced for parameter %s" % n)
+        out.append(g.reshape(p.shape).to(p.dtype) if p.requires_grad else None)
+    return out
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm on f32 rows (encoder.py:74 after_norm)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x2 = _f32c(x.reshape(-1, x.shape[-1]))
+        y = cfm.layernorm(x2, weight.detach(), bias.detach(), eps=eps)[0]
+        ctx.save_for_backward(x2, weight)
+        ctx.eps, ctx.shape = eps, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dx, dg, db = cfm.layernorm_bwd(x2, _f32c(dy.reshape(x2.shape)), weight.detach(), eps=ctx.eps)
+        return dx.view(ctx.shape), dg, db, None
+
+
+class FeedForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, prec, act, *params):
+        pk = packing.pack_ffn_train(mod, prec)
+        x2 = _f32c(x.reshape(-1, x.shape[-1]))
+        y, saved = ffn_fwd(pk, x2, None, prec, 1.0, act)
+        ctx.mod, ctx.prec, ctx.pk, ctx.saved, ctx.act, ctx.shape = mod, prec, pk, saved, act, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, grads, _ = ffn_bwd(ctx.pk, ctx.saved, _f32c(dy.reshape(-1, dy.shape[-1])), None, ctx.prec, 1.0, ctx.act)
+        names, tensors = _params(ctx.mod)
+        return (dx.view(ctx.shape), None, None, None) + tuple(_ordered(names, grads, tensors))
+
+
+class AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, prec, relative, mask8, m_str, *params):
+        pk = packing.pack_mhsa_train(mod, prec, relative)
+        B, T, D = x.shape
+        y, saved = mhsa_fwd(mod, pk, _f32c(x.reshape(B * T, D)), None, B, T, mask8, m_str, prec, relative)
+        ctx.args = (mod, prec, relative, mask8, m_str, pk, saved, B, T, D)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod, prec, relative, mask8, m_str, pk, saved, B, T, D = ctx.args
+        dx, grads, _ = mhsa_bwd(mod, pk, saved, _f32c(dy.reshape(B * T, D)), None, B, T, mask8, m_str, prec, relative)
+        names, tensors = _params(mod)
+        return (dx.view(B, T, D), None, None, None, None, None) + tuple(_ordered(names, grads, tensors))
+
+
+class ConvModuleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, prec, keep, *params):
+        pk = packing.pack_conv_module_train(mod, prec)
+        B, T, D = x.shape
+        y, saved = conv_module_fwd(mod, pk, _f32c(x.reshape(B * T, D)), None, B, T, keep, prec)
+        ctx.args = (mod, prec, keep, pk, saved, B, T, D)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod, prec, keep, pk, saved, B, T, D = ctx.args
+        dx, grads, _ = conv_module_bwd(mod, pk, saved, _f32c(dy.reshape(B * T, D)), None, B, T, keep, prec)
+        names, tensors = _params(mod)
+        return (dx.view(B, T, D), None, None, None) + tuple(_ordered(names, grads, tensors))
+
+
+class SubsamplingFn(torch.autograd.Function):
+    """conv.0 + ReLU + conv.2 + ReLU + out.0 of the front-end (convolution.py:70-74); the fbank input gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, mod, prec, cmvn, *params):
+        pk = packing.pack_subsampling_train(mod, prec)
+        y, saved = subsampling_fwd(pk, _f32c(x), cmvn, prec)
+        ctx.args = (mod, prec, pk, saved)
+        B, T2 = x.shape[0], saved[3][6]
+        return y.view(B, T2, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod, prec, pk, saved = ctx.args
+        grads = subsampling_bwd(pk, saved, _f32c(dy.reshape(-1, dy.shape[-1])), prec)
+        names, tensors = [], []
+        for n, p in mod.named_parameters():
+            if n.startswith("conv.") or n.startswith("out."):
+                names.append(n)
+                tensors.append(p)
+        return (None, None, None, None) + tuple(_ordered(names, grads, tensors))
+
+
+def subsampling_params(mod):
+    return [p for n, p in mod.named_parameters() if n.startswith("conv.") or n.startswith("out.")]
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """One conformer block in train mode (encoder_layer.py:49-71): four residual sub-blocks + norm_final, one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, layer, prec, mask8, m_str, keep, *params):
+        B, T, D = x.shape
+        rel = layer.use_relative
+        pks = (packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
+               packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
+        ln = lambda m: (m.weight.detach(), m.bias.detach())
+        x0 = _f32c(x.reshape(B * T, D))
+        x1, s1 = ffn_fwd(pks[0], x0, ln(layer.norm_ff_macaron), prec, 0.5)
+        x2, s2 = mhsa_fwd(layer.self_attn, pks[1], x1, ln(layer.norm_mha), B, T, mask8, m_str, prec, rel)
+        x3, s3 = conv_module_fwd(layer.conv_module, pks[2], x2, ln(layer.norm_conv), B, T, keep, prec)
+        x4, s4 = ffn_fwd(pks[3], x3, ln(layer.norm_ff), prec, 0.5)
+        y = cfm.layernorm(x4, *ln(layer.norm_final))[0]
+        ctx.args = (layer, prec, mask8, m_str, keep, pks, (s1, s2, s3, s4, x4), B, T, D)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer, prec, mask8, m_str, keep, pks, (s1, s2, s3, s4, x4), B, T, D = ctx.args
+        rel = layer.use_relative
+        ln = lambda m: (m.weight.detach(), m.bias.detach())
+        grads = {}
+
+        def put(prefix, g, norm_name, lng):
+            for k, v in g.items():
+                grads[prefix + k] = v
+            grads[norm_name + ".weight"], grads[norm_name + ".bias"] = lng
+
+        d, dgf, dbf = cfm.layernorm_bwd(x4, _f32c(dy.reshape(B * T, D)), layer.norm_final.weight.detach())
+        grads["norm_final.weight"], grads["norm_final.bias"] = dgf, dbf
+        d, g, lng = ffn_bwd(pks[3], s4, d, ln(layer.norm_ff), prec, 0.5)
+        put("feed_forward.", g, "norm_ff", lng)
+        d, g, lng = conv_module_bwd(layer.conv_module, pks[2], s3, d, ln(layer.norm_conv), B, T, keep, prec)
+        put("conv_module.", g, "norm_conv", lng)
+        d, g, lng = mhsa_bwd(layer.self_attn, pks[1], s2, d, ln(layer.norm_mha), B, T, mask8, m_str, prec, rel)
+        put("self_attn.", g, "norm_mha", lng)
+        d, g, lng = ffn_bwd(pks[0], s1, d, ln(layer.norm_ff_macaron), prec, 0.5)
+        put("feed_forward_macaron.", g, "norm_ff_macaron", lng)
+        names, tensors = _params(layer)
+        return (d.view(B, T, D), None, None, None, None, None) + tuple(_ordered(names, grads, tensors))
+
+
+class CTCLossFn(torch.autograd.Function):
+    """sum_b nll_b / padded label length on top of ctc_lo (decoder.py:19-22)."""
+
+    @staticmethod
+    def forward(ctx, enc_out, mod, prec, enc_lens, labels, label_lens, weight, bias):
+        pk = packing.pack_ctc_train(mod, prec)
+        B, T, D = enc_out.shape
+        x2 = _f32c(enc_out.reshape(B * T, D))
+        logits = cfm.gemm(x2, pk.w, bias=pk.b, w_lo=pk.w_lo, out_dtype=torch.float32).view(B, T, pk.Vp)
+        nll, state = cfm.ctc_nll_train(logits, pk.V, enc_lens, labels, label_lens)
+        ctx.args = (prec, pk, x2, logits, state, enc_lens, labels, label_lens, B, T, D)
+        return nll.sum() / labels.size(1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        prec, pk, x2, logits, state, enc_lens, labels, label_lens, B, T, D = ctx.args
+        gdev = _f32c(gout.reshape(1))
+        dlog = cfm.ctc_grad(logits, pk.V, enc_lens, labels, label_lens, state, gscale=1.0 / labels.size(1), gscale_dev=gdev).view(B * T, pk.Vp)
+        dW, db = cfm.gemm_tn(dlog, x2, want_colsum=True, mma_code=prec.w_code, split=prec.split)
+        dx = cfm.gemm(dlog, pk.wt, w_lo=pk.wt_lo, out_dtype=torch.float32)
+        return dx.view(B, T, D), None, None, None, None, None, dW[:pk.V], db[:pk.V]

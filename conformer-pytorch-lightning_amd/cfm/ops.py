@@ -6,7 +6,9 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
+__all__ = ["gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
+           "ctc_nll_train", "ctc_grad", "adam_step", "sumsq", "scratch_stats",
+           "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -16,21 +18,36 @@ def _rows2d(t, name):
     return t
 
 
-# a grow-only arena of reusable device buffers (workspace owned by the extension side of the boundary)
+# A grow-only arena of reusable device buffers (workspace owned by the extension side of the boundary), keyed per
+# (device, STREAM): two streams never share a scratch buffer, so forwards running concurrently on one device cannot overwrite each
+# other's xn / hid / qkv.  A buffer that has been handed out is NEVER released: when a larger one is needed the old block is retired,
+# not freed -- a captured HIP graph (bench.py, StreamingSession) may still hold its address.  Blocks grow by at least 1.5x, so the
+# retired list stays short.
 _arena = {}
+_retired = []
 
 
 def scratch(tag, numel, dtype, device):
-    key = (tag, dtype, device)
+    device = torch.device(device)
+    key = (tag, dtype, device, torch.cuda.current_stream(device).cuda_stream)
     buf = _arena.get(key)
     if buf is None or buf.numel() < numel:
-        buf = torch.empty(max(int(numel), 1), dtype=dtype, device=device)
+        want = max(int(numel), 1) if buf is None else max(int(numel), buf.numel() * 3 // 2)
+        if buf is not None:
+            _retired.append(buf)
+        buf = torch.empty(want, dtype=dtype, device=device)
         _arena[key] = buf
     return buf[:numel]
 
 
+def scratch_stats():
+    """(live blocks, retired blocks, bytes held) -- for tests and leak hunting."""
+    held = sum(b.numel() * b.element_size() for b in list(_arena.values()) + _retired)
+    return len(_arena), len(_retired), held
+
+
 def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, residual=None, alpha=1.0, row_mask=None,
-         mask_mode=0, conv=None, tile=0, n_out=None, w_frag=None):
+         mask_mode=0, conv=None, tile=0, n_out=None, w_frag=None, pre_out=None, aux=None):
     """out = epilogue(a[M,K] . w[N,K]^T); see include/cfm.h cfm_gemm.  conv=(C,T1,F1,T2,F2,M) selects the implicit
     3x3/stride-2 convolution over a channels-last image `a` of shape [B,T1,F1,C]."""
     _c.require_hip(a, w, bias, w_lo, out, residual, row_mask)
@@ -73,6 +90,18 @@ def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, 
         if w_frag.dtype != w.dtype or w_frag.numel() < N * K:
             raise ValueError("cfm.gemm: w_frag must be the fragment-major pack of w")
         d.W_frag = _c.ptr(w_frag)
+    if pre_out is not None:                      # training: acc + bias before the activation, all N columns
+        _c.require_hip(pre_out)
+        pre_out = _rows2d(pre_out, "gemm(pre_out)")
+        if tuple(pre_out.shape) != (M, N):
+            raise ValueError("cfm.gemm: pre_out is %s, expected (%d,%d)" % (tuple(pre_out.shape), M, N))
+        d.C_pre, d.ld_pre, d.pre_dtype = _c.ptr(pre_out), pre_out.stride(0), _c.dt_code(pre_out)
+    if aux is not None:                          # backward epilogues (ACT_DSILU / ACT_DRELU): the forward pre-activation / output
+        _c.require_hip(aux)
+        aux = _rows2d(aux, "gemm(aux)")
+        if tuple(aux.shape) != (M, N):
+            raise ValueError("cfm.gemm: aux is %s, expected (%d,%d)" % (tuple(aux.shape), M, N))
+        d.aux, d.ld_aux, d.aux_dtype = _c.ptr(aux), aux.stride(0), _c.dt_code(aux)
     d.A, d.W, d.W_lo, d.bias, d.residual, d.row_mask, d.C = _c.ptr(a), _c.ptr(w), _c.ptr(w_lo), _c.ptr(bias), _c.ptr(residual), _c.ptr(row_mask), _c.ptr(out)
     d.ldc = out.stride(0)
     d.M, d.N, d.K = M, N, K
@@ -201,9 +230,12 @@ def as_u8_mask(mask):
 
 
 def attention(q, k, v, B, H, Tq, Tk, dk, q_str, k_str, v_str, out, p=None, p_str=(0, 0), bias_u=None, bias_v=None, mask=None,
-              mask_str=(0, 0), mma_code=_c.BF16, split=False, scale=None):
-    """Fused attention; *_str are (batch stride, time stride[, head stride]) in ELEMENTS (see include/cfm.h)."""
-    _c.require_hip(q, k, v, p, out, mask, bias_u, bias_v)
+              mask_str=(0, 0), mma_code=_c.BF16, split=False, scale=None, lse=None):
+    """Fused attention; *_str are (batch stride, time stride[, head stride]) in ELEMENTS (see include/cfm.h).  lse: optional f32 [B,H,Tq]
+    output (training): the log-sum-exp of each row's scaled masked scores."""
+    _c.require_hip(q, k, v, p, out, mask, bias_u, bias_v, lse)
+    if lse is not None and (lse.dtype != torch.float32 or lse.numel() != B * H * Tq or not lse.is_contiguous()):
+        raise ValueError("cfm.attention: lse must be contiguous float32 [B,H,Tq]")
     d = _c.AttnDesc()
     d.q, d.k, d.v, d.p, d.out = _c.ptr(q), _c.ptr(k), _c.ptr(v), _c.ptr(p), _c.ptr(out)
     d.bias_u, d.bias_v, d.mask = _c.ptr(bias_u), _c.ptr(bias_v), _c.ptr(mask)
@@ -217,6 +249,7 @@ def attention(q, k, v, B, H, Tq, Tk, dk, q_str, k_str, v_str, out, p=None, p_str
     d.p_dtype = _c.dt_code(p) if p is not None else 0
     d.mma_dtype, d.split = mma_code, 1 if split else 0
     d.scale = scale if scale is not None else float(dk) ** -0.5
+    d.lse = _c.ptr(lse)
     _c.check(_c.lib().cfm_attention(ctypes.byref(d), _c.stream()), "cfm_attention")
     return out
 
@@ -289,7 +322,7 @@ def ctc_nll(logits, V, enc_lens, labels, label_lens):
     if labels.dim() != 2 or labels.size(0) != B or enc_lens.numel() != B or label_lens.numel() != B:
         raise ValueError("cfm.ctc_nll: batch sizes differ")
     out = torch.empty((B,), dtype=torch.float32, device=logits.device)
-    work = scratch("ctc_lp", B * T * (2 * labels.size(1) + 1), torch.float32, logits.device)
+    work = scratch("ctc_lp", B * T * (2 * labels.size(1) + 2), torch.float32, logits.device)
     _c.check(_c.lib().cfm_ctc_nll(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
                                   _c.ptr(work), _c.ptr(out), _c.stream()), "cfm_ctc_nll")
     return out
@@ -376,4 +409,233 @@ def prof_table():
     for i in range(n):
         _c.check(L.cfm_prof_entry(i, name, 128, ctypes.byref(calls), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)), "cfm_prof_entry")
         out[name.value.decode()] = dict(calls=calls.value, ms=ms.value, flops=fl.value, bytes=by.value)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training (include/cfm.h "Training"): thin wrappers, outputs allocated here, workspaces from the per-stream arena
+# ----------------------------------------------------------------------------------------------------------------------
+def gemm_tn(a, b, out=None, want_colsum=False, row_mask=None, alpha=1.0, conv=None, split=False, splits=0, mma_code=_c.BF16, accumulate=False,
+            colsum=None):
+    """C[N,K] (+)= alpha * a[M,N]^T . b[M,K]  (f32) and optionally colsum[N] = alpha * sum_m a[m,:]: the weight / bias gradient of a
+    dense layer from its output gradient `a` and its input rows `b` (include/cfm.h cfm_gemm_tn).  conv=(C,T1,F1,T2,F2): `b` is a
+    channels-last image [B,T1,F1,C] read as its 3x3 stride-2 im2col matrix.  Returns (C, colsum | None)."""
+    _c.require_hip(a, b, out, row_mask, colsum)
+    a = _rows2d(a, "gemm_tn(a)")
+    M, N = a.shape
+    d = _c.GemmTnDesc()
+    if conv is None:
+        b = _rows2d(b, "gemm_tn(b)")
+        if b.shape[0] != M:
+            raise ValueError("cfm.gemm_tn: a is %s but b is %s" % (tuple(a.shape), tuple(b.shape)))
+        K = b.shape[1]
+        d.ldb = b.stride(0)
+    else:
+        C, T1, F1, T2, F2 = conv
+        if not b.is_contiguous() or b.numel() != (M // (T2 * F2)) * T1 * F1 * C:
+            raise ValueError("cfm.gemm_tn(conv): image must be contiguous channels-last [B,T1,F1,C]")
+        K = 9 * C
+        d.conv_C, d.conv_T1, d.conv_F1, d.conv_T2, d.conv_F2 = C, T1, F1, T2, F2
+    if out is None:
+        if accumulate:
+            raise ValueError("cfm.gemm_tn: accumulate needs an existing out")
+        out = torch.empty((N, K), dtype=torch.float32, device=a.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (N, K) or out.stride(1) != 1:
+        raise ValueError("cfm.gemm_tn: out must be float32 (%d,%d)" % (N, K))
+    if want_colsum and colsum is None:
+        colsum = torch.empty((N,), dtype=torch.float32, device=a.device)
+    if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != N or not colsum.is_contiguous()):
+        raise ValueError("cfm.gemm_tn: colsum must be contiguous float32 [N]")
+    if row_mask is not None and (row_mask.dtype != torch.uint8 or row_mask.numel() != M or not row_mask.is_contiguous()):
+        raise ValueError("cfm.gemm_tn: row_mask must be contiguous uint8 [M]")
+    d.A, d.B, d.C, d.colsum, d.row_mask = _c.ptr(a), _c.ptr(b), _c.ptr(out), _c.ptr(colsum), _c.ptr(row_mask)
+    d.lda, d.ldc = a.stride(0), out.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.a_dtype, d.b_dtype, d.mma_dtype = _c.dt_code(a), _c.dt_code(b), mma_code
+    d.split, d.accumulate, d.splits, d.alpha = 1 if split else 0, 1 if accumulate else 0, splits, alpha
+    _c.check(_c.lib().cfm_gemm_tn(ctypes.byref(d), _c.stream()), "cfm_gemm_tn")
+    return out, colsum
+
+
+def layernorm_bwd(x, dy, gamma, row_mask=None, dres=None, dx=None, eps=1e-5):
+    """-> (dx, dgamma, dbeta): dx = (dres or 0) + dLayerNorm(dy) w.r.t. the norm's input x (f32 [M,D]); dx may be dres itself."""
+    _c.require_hip(x, dy, gamma, row_mask, dres, dx)
+    x = _rows2d(x, "layernorm_bwd(x)")
+    M, D = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous() or tuple(dy.shape) != (M, D) or not dy.is_contiguous():
+        raise ValueError("cfm.layernorm_bwd: x must be contiguous float32 [M,D] and dy contiguous [M,D]")
+    if dx is None:
+        dx = torch.empty_like(x)
+    for t in (dres, dx):
+        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (M, D) or not t.is_contiguous()):
+            raise ValueError("cfm.layernorm_bwd: dres / dx must be contiguous float32 [M,D]")
+    dg = torch.empty((D,), dtype=torch.float32, device=x.device)
+    db = torch.empty((D,), dtype=torch.float32, device=x.device)
+    ws = scratch("ln_bwd", _c.lib().cfm_layernorm_bwd_ws(M, D), torch.float32, x.device)
+    _c.check(_c.lib().cfm_layernorm_bwd(_c.ptr(x), _c.ptr(dy), _c.dt_code(dy), _c.ptr(gamma), _c.ptr(row_mask), _c.ptr(dres), _c.ptr(dx), _c.ptr(dg),
+                                        _c.ptr(db), _c.ptr(ws), eps, M, D, _c.stream()), "cfm_layernorm_bwd")
+    return dx, dg, db
+
+
+def glu_bwd(u, dg, out_dtype):
+    """u [M,2D] (the interleaved pre-GLU columns from gemm(..., pre_out=)), dg [M,D] -> du [M,2D] same layout."""
+    _c.require_hip(u, dg)
+    M, D2 = u.shape
+    D = D2 // 2
+    if not u.is_contiguous() or not dg.is_contiguous() or tuple(dg.shape) != (M, D):
+        raise ValueError("cfm.glu_bwd: u must be contiguous [M,2D] and dg contiguous [M,D]")
+    du = torch.empty((M, D2), dtype=out_dtype, device=u.device)
+    _c.check(_c.lib().cfm_glu_bwd(_c.ptr(u), _c.dt_code(u), _c.ptr(dg), _c.dt_code(dg), _c.ptr(du), _c.dt_code(du), M, D, _c.stream()), "cfm_glu_bwd")
+    return du
+
+
+def dwconv_bn_train(g, w, dw_bias, gamma, beta, running_mean, running_var, momentum, eps, s_dtype):
+    """g [B,T,D] -> (c f32 [B,T,D], stats f32 [4,D], s = SiLU(BatchNorm_train(c)) in s_dtype); running statistics updated in place."""
+    _c.require_hip(g, w, dw_bias, gamma, beta, running_mean, running_var)
+    if g.dim() != 3 or not g.is_contiguous():
+        raise ValueError("cfm.dwconv_bn_train: g must be contiguous [B,T,D]")
+    B, T, D = g.shape
+    c = torch.empty((B, T, D), dtype=torch.float32, device=g.device)
+    stats = torch.empty((4, D), dtype=torch.float32, device=g.device)
+    s = torch.empty((B, T, D), dtype=s_dtype, device=g.device)
+    ws = scratch("dwbn", _c.lib().cfm_dwconv_bn_ws(B, T, D), torch.float32, g.device)
+    _c.check(_c.lib().cfm_dwconv_bn_train(_c.ptr(g), _c.dt_code(g), _c.ptr(w), _c.ptr(dw_bias), _c.ptr(gamma), _c.ptr(beta), _c.ptr(running_mean),
+                                          _c.ptr(running_var), momentum, eps, _c.ptr(c), _c.ptr(stats), _c.ptr(s), _c.dt_code(s), _c.ptr(ws), B, T, D,
+                                          w.shape[1], _c.stream()), "cfm_dwconv_bn_train")
+    return c, stats, s
+
+
+def dwconv_bn_train_bwd(ds, c, stats, g, w, dg_dtype):
+    """-> (dg [B,T,D], d taps [D,K], d conv bias [D], d BatchNorm gain [D], d BatchNorm bias [D])."""
+    _c.require_hip(ds, c, stats, g, w)
+    B, T, D = g.shape
+    if not ds.is_contiguous() or ds.numel() != B * T * D or not c.is_contiguous() or not g.is_contiguous():
+        raise ValueError("cfm.dwconv_bn_train_bwd: ds, c, g must be contiguous [B,T,D]")
+    dev = g.device
+    dg = torch.empty((B, T, D), dtype=dg_dtype, device=dev)
+    dw_w = torch.empty((D, w.shape[1]), dtype=torch.float32, device=dev)
+    dw_b, dgamma, dbeta = (torch.empty((D,), dtype=torch.float32, device=dev) for _ in range(3))
+    dy = scratch("dwbn_dy", B * T * D, torch.float32, dev)
+    ws = scratch("dwbn", _c.lib().cfm_dwconv_bn_ws(B, T, D), torch.float32, dev)
+    _c.check(_c.lib().cfm_dwconv_bn_train_bwd(_c.ptr(ds), _c.dt_code(ds), _c.ptr(c), _c.ptr(stats), _c.ptr(g), _c.dt_code(g), _c.ptr(w), _c.ptr(dg),
+                                              _c.dt_code(dg), _c.ptr(dw_w), _c.ptr(dw_b), _c.ptr(dgamma), _c.ptr(dbeta), _c.ptr(dy), _c.ptr(ws), B, T, D,
+                                              w.shape[1], _c.stream()), "cfm_dwconv_bn_train_bwd")
+    return dg, dw_w, dw_b, dgamma, dbeta
+
+
+def col2im_relu_bwd(dcol, h1, out_dtype):
+    """dcol [B*T2*F2, 9C] (K order (kt,kf,c)), h1 [B,T1,F1,C] -> dh1 = (h1 > 0) * col2im(dcol)."""
+    _c.require_hip(dcol, h1)
+    B, T1, F1, C = h1.shape
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    if not dcol.is_contiguous() or tuple(dcol.shape) != (B * T2 * F2, 9 * C) or not h1.is_contiguous():
+        raise ValueError("cfm.col2im_relu_bwd: dcol must be contiguous [B*T2*F2, 9C] and h1 contiguous [B,T1,F1,C]")
+    dh1 = torch.empty((B, T1, F1, C), dtype=out_dtype, device=h1.device)
+    _c.check(_c.lib().cfm_col2im_relu_bwd(_c.ptr(dcol), _c.dt_code(dcol), _c.ptr(h1), _c.dt_code(h1), _c.ptr(dh1), _c.dt_code(dh1), B, T1, F1, C,
+                                          _c.stream()), "cfm_col2im_relu_bwd")
+    return dh1
+
+
+def conv1_wgrad(dh1, x, cmvn=None):
+    """dh1 [B,T1,F1,C], x f32 [B,T,F] -> (dw [9,C] tap-major, db [C])."""
+    _c.require_hip(dh1, x)
+    B, T, F = x.shape
+    C = dh1.shape[3]
+    mean, istd = cmvn if cmvn is not None else (None, None)
+    _c.require_hip(mean, istd)
+    if x.dtype != torch.float32 or not x.is_contiguous() or not dh1.is_contiguous() or tuple(dh1.shape[:3]) != (B, (T - 3) // 2 + 1, (F - 3) // 2 + 1):
+        raise ValueError("cfm.conv1_wgrad: x must be contiguous float32 [B,T,F] and dh1 contiguous [B,T1,F1,C]")
+    dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
+    db = torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws = scratch("conv1_wgrad", _c.lib().cfm_conv1_wgrad_ws(B, T, C), torch.float32, x.device)
+    _c.check(_c.lib().cfm_conv1_wgrad(_c.ptr(dh1), _c.dt_code(dh1), _c.ptr(x), _c.ptr(mean), _c.ptr(istd), _c.ptr(dw), _c.ptr(db), _c.ptr(ws), B, T, F, C,
+                                      _c.stream()), "cfm_conv1_wgrad")
+    return dw, db
+
+
+def attention_bwd(q, k, v, out, dout, lse, B, H, Tq, Tk, dk, q_str, k_str, v_str, dq, dkk, dv, mask=None, mask_str=(0, 0), mma_code=_c.BF16, split=False,
+                  scale=None):
+    """Backward of attention(); q/k/v and dq/dkk/dv share strides ((batch, time) in elements, head h at h*dk); see include/cfm.h."""
+    _c.require_hip(q, k, v, out, dout, lse, dq, dkk, dv, mask)
+    d = _c.AttnBwdDesc()
+    d.q, d.k, d.v, d.mask, d.out, d.dout, d.lse = _c.ptr(q), _c.ptr(k), _c.ptr(v), _c.ptr(mask), _c.ptr(out), _c.ptr(dout), _c.ptr(lse)
+    d.grad_q, d.grad_k, d.grad_v = _c.ptr(dq), _c.ptr(dkk), _c.ptr(dv)
+    delta = scratch("attn_delta", B * H * Tq, torch.float32, q.device)
+    d.delta = _c.ptr(delta)
+    d.q_sb, d.q_st = q_str
+    d.k_sb, d.k_st = k_str
+    d.v_sb, d.v_st = v_str
+    d.m_sb, d.m_sq = mask_str
+    d.B, d.H, d.Tq, d.Tk, d.dk = B, H, Tq, Tk, dk
+    if not (q.dtype == k.dtype == v.dtype == out.dtype == dq.dtype == dkk.dtype == dv.dtype):
+        raise ValueError("cfm.attention_bwd: q, k, v, out and the gradients must share one dtype")
+    d.io_dtype, d.dout_dtype, d.mma_dtype, d.split = _c.dt_code(q), _c.dt_code(dout), mma_code, 1 if split else 0
+    d.scale = scale if scale is not None else float(dk) ** -0.5
+    _c.check(_c.lib().cfm_attention_bwd(ctypes.byref(d), _c.stream()), "cfm_attention_bwd")
+
+
+def _ctc_args(logits, enc_lens, labels, label_lens):
+    if logits.dim() != 3 or logits.dtype != torch.float32 or logits.stride(2) != 1 or logits.stride(0) != logits.size(1) * logits.stride(1):
+        raise ValueError("cfm.ctc: logits must be float32 [B,T,>=V] with contiguous rows")
+    for t in (enc_lens, labels, label_lens):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise ValueError("cfm.ctc: lengths and labels must be contiguous int32")
+    B = logits.shape[0]
+    if labels.dim() != 2 or labels.size(0) != B or enc_lens.numel() != B or label_lens.numel() != B:
+        raise ValueError("cfm.ctc: batch sizes differ")
+
+
+def ctc_nll_train(logits, V, enc_lens, labels, label_lens):
+    """As ctc_nll, keeping what the backward needs: returns (nll [B], state) with state = (work, alpha, lse, nll_shifted) owned by the caller."""
+    _c.require_hip(logits, enc_lens, labels, label_lens)
+    _ctc_args(logits, enc_lens, labels, label_lens)
+    B, T = logits.shape[:2]
+    SM = 2 * labels.size(1) + 2
+    dev = logits.device
+    nll = torch.empty((B,), dtype=torch.float32, device=dev)
+    nllp = torch.empty((B,), dtype=torch.float32, device=dev)
+    work = torch.empty((B, T, SM), dtype=torch.float32, device=dev)
+    alpha = torch.empty((B, T, SM), dtype=torch.float32, device=dev)
+    lse = torch.empty((B, T), dtype=torch.float32, device=dev)
+    _c.check(_c.lib().cfm_ctc_nll_train(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
+                                        _c.ptr(work), _c.ptr(alpha), _c.ptr(lse), _c.ptr(nll), _c.ptr(nllp), _c.stream()), "cfm_ctc_nll_train")
+    return nll, (work, alpha, lse, nllp)
+
+
+def ctc_grad(logits, V, enc_lens, labels, label_lens, state, gscale=1.0, gscale_dev=None, out=None):
+    """d (sum_b nll_b) / d logits * gscale * (*gscale_dev), f32 [B,T,ld]; consumes state[1] (alpha is overwritten)."""
+    _c.require_hip(logits, enc_lens, labels, label_lens, gscale_dev, out)
+    _ctc_args(logits, enc_lens, labels, label_lens)
+    work, alpha, lse, nllp = state
+    B, T = logits.shape[:2]
+    if out is None:
+        out = torch.empty_like(logits)
+    if out.dtype != torch.float32 or out.shape != logits.shape or out.stride() != logits.stride():
+        raise ValueError("cfm.ctc_grad: out must match logits")
+    _c.check(_c.lib().cfm_ctc_grad(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
+                                   _c.ptr(work), _c.ptr(alpha), _c.ptr(lse), _c.ptr(nllp), gscale, _c.ptr(gscale_dev), _c.ptr(out), _c.stream()), "cfm_ctc_grad")
+    return out
+
+
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=None):
+    """In-place Adam over flat float32 buffers (torch.optim.Adam's update rule); grad_scale: optional device scalar multiplied into g."""
+    _c.require_hip(p, g, m, v, grad_scale)
+    n = p.numel()
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+            raise ValueError("cfm.adam_step: p, g, m, v must be contiguous float32 buffers of one size")
+    _c.check(_c.lib().cfm_adam_step(_c.ptr(p), _c.ptr(g), _c.ptr(m), _c.ptr(v), n, lr, betas[0], betas[1], eps, weight_decay, step, _c.ptr(grad_scale),
+                                    _c.stream()), "cfm_adam_step")
+
+
+def sumsq(x):
+    """sum(x^2) of a flat float32 buffer as a 1-element device tensor (no host sync)."""
+    _c.require_hip(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("cfm.sumsq: x must be a contiguous float32 buffer")
+    n = x.numel()
+    nb = max(1, min(1024, (n + 4095) // 4096))
+    part = scratch("sumsq", nb, torch.float32, x.device)
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _c.check(_c.lib().cfm_sumsq(_c.ptr(x), n, _c.ptr(part), nb, _c.ptr(out), _c.stream()), "cfm_sumsq")
     return out

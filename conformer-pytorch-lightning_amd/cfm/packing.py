@@ -11,8 +11,17 @@ import torch
 import cfm as _c
 
 
+_EPOCH = [0]
+
+
+def bump_epoch():
+    """Invalidate every pack: for weight updates that bypass torch's version counters (the flat-buffer Adam kernel of trainer.py writes
+    through raw pointers)."""
+    _EPOCH[0] += 1
+
+
 def _key(tensors, prec):
-    return (prec.name,) + tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in tensors if t is not None)
+    return (prec.name, _EPOCH[0]) + tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in tensors if t is not None)
 
 
 class Packed:
@@ -208,3 +217,108 @@ def layer_weight_struct(layer, prec):
     w.pw2_w, w.pw2_w_lo, w.pw2_b = cv.pw2_w.data_ptr(), _c.ptr(cv.pw2_w_lo), cv.pw2_b.data_ptr()
     w.dw_w, w.dw_b, w.bn_scale, w.bn_shift = cv.dw_w.data_ptr(), cv.dw_b.data_ptr(), cv.bn_scale.data_ptr(), cv.bn_shift.data_ptr()
     return w, (ffm, ff, att, cv, norms)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training packs: every dense layer needs its weight twice -- [N,K] for the forward product and [K,N] for the input gradient
+# (both K-contiguous for cfm_gemm) -- rebuilt when the optimizer has stepped (the parameter's version counter moves)
+# ----------------------------------------------------------------------------------------------------------------------
+def matrix_t(w, prec):
+    """[N,K] float weight -> the packs of its transpose [K,N]."""
+    return matrix(w.detach().t(), prec)
+
+
+def _train_cache(mod):
+    pc = mod.__dict__.get("_pack_train")
+    if pc is None:
+        pc = PackCache()
+        mod.__dict__["_pack_train"] = pc
+    return pc
+
+
+def pack_ffn_train(mod, prec):
+    def build():
+        w1, w1l = matrix(mod.w_1.weight, prec)
+        w2, w2l = matrix(mod.w_2.weight, prec)
+        w1t, w1tl = matrix_t(mod.w_1.weight, prec)
+        w2t, w2tl = matrix_t(mod.w_2.weight, prec)
+        return Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias), w1t=w1t, w1t_lo=w1tl, w2t=w2t, w2t_lo=w2tl)
+    return _train_cache(mod).get([mod.w_1.weight, mod.w_1.bias, mod.w_2.weight, mod.w_2.bias], prec, build)
+
+
+def pack_mhsa_train(mod, prec, relative):
+    srcs = [mod.linear_q.weight, mod.linear_q.bias, mod.linear_k.weight, mod.linear_k.bias, mod.linear_v.weight, mod.linear_v.bias,
+            mod.linear_out.weight, mod.linear_out.bias]
+    if relative:
+        srcs.append(mod.pos_bias_u)
+
+    def build():
+        wcat = torch.cat([mod.linear_q.weight.detach(), mod.linear_k.weight.detach(), mod.linear_v.weight.detach()], 0)
+        qkv, qkvl = matrix(wcat, prec)
+        qkvt, qkvtl = matrix_t(wcat, prec)
+        out, outl = matrix(mod.linear_out.weight, prec)
+        outt, outtl = matrix_t(mod.linear_out.weight, prec)
+        bq = mod.linear_q.bias.detach().float()
+        if relative:                                   # q + pos_bias_u (attention.py:81) rides in the projection's bias; the batch path's
+            bq = bq + mod.pos_bias_u.detach().float().reshape(-1)      # positional term is softmax-invariant (SURVEY Q3) and is not evaluated
+        qkv_b = torch.cat([bq, mod.linear_k.bias.detach().float(), mod.linear_v.bias.detach().float()], 0).contiguous()
+        return Packed(qkv_w=qkv, qkv_w_lo=qkvl, qkv_t=qkvt, qkv_t_lo=qkvtl, qkv_b=qkv_b, out_w=out, out_w_lo=outl, out_t=outt, out_t_lo=outtl,
+                      out_b=f32(mod.linear_out.bias))
+    return _train_cache(mod).get(srcs, prec, build)
+
+
+def pack_conv_module_train(mod, prec):
+    bn = mod.norm
+    srcs = [mod.pointwise_conv1.weight, mod.pointwise_conv1.bias, mod.depthwise_conv.weight, mod.depthwise_conv.bias, bn.weight, bn.bias,
+            mod.pointwise_conv2.weight, mod.pointwise_conv2.bias]
+
+    def build():
+        D = mod.pointwise_conv2.weight.shape[0]
+        dev = mod.pointwise_conv2.weight.device
+        idx = glu_interleave_index(D, dev)
+        w1 = mod.pointwise_conv1.weight.detach()[:, :, 0][idx]
+        b1 = (mod.pointwise_conv1.bias.detach() if mod.pointwise_conv1.bias is not None else torch.zeros(2 * D, device=dev))[idx]
+        w2 = mod.pointwise_conv2.weight.detach()[:, :, 0]
+        pw1, pw1l = matrix(w1, prec)
+        pw1t, pw1tl = matrix_t(w1, prec)
+        pw2, pw2l = matrix(w2, prec)
+        pw2t, pw2tl = matrix_t(w2, prec)
+        dwb = mod.depthwise_conv.bias.detach() if mod.depthwise_conv.bias is not None else torch.zeros(D, device=dev)
+        gamma = bn.weight.detach() if bn.weight is not None else torch.ones(D, device=dev)
+        beta = bn.bias.detach() if bn.bias is not None else torch.zeros(D, device=dev)
+        return Packed(pw1_w=pw1, pw1_w_lo=pw1l, pw1_t=pw1t, pw1_t_lo=pw1tl, pw1_b=f32(b1), pw2_w=pw2, pw2_w_lo=pw2l, pw2_t=pw2t, pw2_t_lo=pw2tl,
+                      pw2_b=f32(mod.pointwise_conv2.bias), dw_w=f32(mod.depthwise_conv.weight.detach()[:, 0, :]), dw_b=f32(dwb), gamma=f32(gamma),
+                      beta=f32(beta), idx=idx)
+    return _train_cache(mod).get(srcs, prec, build)
+
+
+def pack_subsampling_train(mod, prec):
+    c1, c2, lin = mod.conv[0], mod.conv[2], mod.out[0]
+
+    def build():
+        C = c1.weight.shape[0]
+        w2f = c2.weight.detach().permute(0, 2, 3, 1).reshape(C, 9 * C)                      # [co][kt][kf][ci]
+        Dout, CF = lin.weight.shape
+        Fp = CF // C
+        wlf = lin.weight.detach().reshape(Dout, C, Fp).permute(0, 2, 1).reshape(Dout, Fp * C)   # feature order f*C + c
+        w2, w2l = matrix(w2f, prec)
+        w2t, w2tl = matrix_t(w2f, prec)
+        wl, wll = matrix(wlf, prec)
+        wlt, wltl = matrix_t(wlf, prec)
+        return Packed(w1=f32(c1.weight.detach().reshape(C, 9).t()), b1=f32(c1.bias), w2=w2, w2_lo=w2l, w2t=w2t, w2t_lo=w2tl, b2=f32(c2.bias),
+                      wl=wl, wl_lo=wll, wlt=wlt, wlt_lo=wltl, bl=f32(lin.bias), C=C, Fp=Fp)
+    return _train_cache(mod).get([c1.weight, c1.bias, c2.weight, c2.bias, lin.weight, lin.bias], prec, build)
+
+
+def pack_ctc_train(mod, prec):
+    def build():
+        V, D = mod.ctc_lo.weight.shape
+        Vp = (V + 7) // 8 * 8                          # cfm_gemm_tn wants N % 8 == 0; pad rows are zero and never read by the CTC kernels
+        w = torch.zeros((Vp, D), dtype=torch.float32, device=mod.ctc_lo.weight.device)
+        w[:V] = mod.ctc_lo.weight.detach()
+        b = torch.zeros((Vp,), dtype=torch.float32, device=w.device)
+        b[:V] = mod.ctc_lo.bias.detach()
+        wm, wlo = matrix(w, prec)
+        wt, wtlo = matrix_t(w, prec)
+        return Packed(w=wm, w_lo=wlo, wt=wt, wt_lo=wtlo, b=b, V=V, Vp=Vp)
+    return _train_cache(mod).get([mod.ctc_lo.weight, mod.ctc_lo.bias], prec, build)

@@ -24,7 +24,6 @@ import torch.nn as nn
 
 import cfm
 from cfm import packing
-from feedforward import _inference_only
 
 _NO_CACHE = torch.zeros((0, 0, 0, 0))
 
@@ -49,18 +48,20 @@ class ConvolutionModule(nn.Module):
         self._pack = packing.PackCache()
 
     def forward(self, inputs, inputs_pad_mask, cache=_NO_CACHE):
-        _inference_only(self, "ConvolutionModule")
-        if self.training:
-            raise NotImplementedError("ConvolutionModule: BatchNorm batch statistics (train mode) are not built yet; use eval()")
         cfm.require_hip(inputs)
-        prec = cfm.get_precision()
-        pk = packing.pack_conv_module(self, prec)
+        prec = cfm.resolve_precision(self)
         B, T, D = inputs.shape
         keep = None
         if inputs_pad_mask is not None and inputs_pad_mask.dim() >= 3 and inputs_pad_mask.size(2) > 0:
             keep = cfm.as_u8_mask(inputs_pad_mask).reshape(-1)
             if keep.numel() != B * T:
                 raise RuntimeError("pad mask %s does not match inputs %s" % (tuple(inputs_pad_mask.shape), tuple(inputs.shape)))
+        if cfm.check_mode(self, "ConvolutionModule"):
+            # BatchNorm batch statistics over all B*T positions (padded ones included, quirk Q6), running statistics updated
+            from cfm import autograd as ag
+            out = ag.ConvModuleFn.apply(inputs, self, prec, keep, *self.parameters())
+            return out, torch.zeros((0, 0, 0), dtype=inputs.dtype, device=inputs.device)
+        pk = packing.pack_conv_module(self, prec)
         x = _rows_f32(inputs)
         glu = cfm.gemm(x, pk.pw1_w, bias=pk.pw1_b, w_lo=pk.pw1_w_lo, act=cfm.ACT_GLU, row_mask=keep, mask_mode=1,
                        out_dtype=prec.act_dtype)
@@ -88,9 +89,11 @@ class ConvolutionSubSampling(nn.Module):
     def embed_frames(self, inputs, cmvn=None):
         """(B,T,F) fbank -> (B,T',D) f32: the two stride-2 convolutions and the output projection.  cmvn = (mean, istd | None):
         global CMVN (cmvn.py:22-33) folded into the first convolution's tap loads instead of a pass of its own."""
-        _inference_only(self, "ConvolutionSubSampling")
         cfm.require_hip(inputs)
-        prec = cfm.get_precision()
+        prec = cfm.resolve_precision(self)
+        if cfm.check_mode(self, "ConvolutionSubSampling"):
+            from cfm import autograd as ag
+            return ag.SubsamplingFn.apply(inputs, self, prec, cmvn, *ag.subsampling_params(self))
         pk = packing.pack_subsampling(self, prec)
         x = (inputs if inputs.dtype == torch.float32 else inputs.float()).contiguous()
         B, T, F = x.shape

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "cfm_common.h"
+#include "attn_common.h"
 
 struct AttnArgs {
     const void* q;
@@ -34,50 +35,10 @@ struct AttnArgs {
     int B, H, Tq, Tk, dk;
     int q_dtype, kv_dtype, p_dtype, out_dtype;
     float scale;
+    float* lse;      // optional f32 [B,H,Tq]: log-sum-exp of each row's scaled masked scores (training)
 };
 
 namespace {
-
-constexpr int QT = 64;    // queries per workgroup
-constexpr int KT = 64;    // keys per tile
-constexpr int DKP = 64;   // padded head dim
-constexpr int VSTR = 68;  // V^T row stride in 16-bit elements (136 B: conflict-free ds_read_b64)
-
-// 8 consecutive elements starting at element offset `off`, as f32; elements >= nvalid read as 0.
-__device__ __forceinline__ void load8f(const void* base, int dt, int64_t off, int nvalid, float (&o)[8]) {
-    if (nvalid >= 8 && dt == CFM_F32 && (off & 3) == 0) {
-        const f32x4 a = *(const f32x4*)((const float*)base + off);
-        const f32x4 b = *(const f32x4*)((const float*)base + off + 4);
-        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-        return;
-    }
-    if (nvalid >= 8 && dt != CFM_F32 && (off & 7) == 0) {
-        const u32x4 r = *(const u32x4*)((const u16*)base + off);
-        const unsigned w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u16 lo = (u16)(w[i] & 0xffffu), hi = (u16)(w[i] >> 16);
-            o[2 * i] = dt == CFM_BF16 ? BF16::to_f32(lo) : F16::to_f32(lo);
-            o[2 * i + 1] = dt == CFM_BF16 ? BF16::to_f32(hi) : F16::to_f32(hi);
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = i < nvalid ? load_as_f32(base, off + i, dt) : 0.f;
-}
-
-template <typename HT, bool SPLIT>
-__device__ __forceinline__ void pack_planes(const float (&f)[8], u32x4& hi, u32x4& lo) {
-    const f32x4 a = {f[0], f[1], f[2], f[3]}, b = {f[4], f[5], f[6], f[7]};
-    if constexpr (SPLIT) {
-        split8(a, b, hi, lo);
-    } else {
-        hi = pack8<HT>(a, b);
-        lo = hi;
-    }
-}
-
-__device__ __forceinline__ int k_swz(int row, int c) { return row * 8 + (c ^ ((row >> 1) & 7)); }
 
 template <typename HT, bool HAS_POS, bool SPLIT>
 __global__ __launch_bounds__(256) void cfm_attn_kernel(const AttnArgs a) {
@@ -242,6 +203,7 @@ __global__ __launch_bounds__(256) void cfm_attn_kernel(const AttnArgs a) {
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;  // fully masked row -> zeros (attention.py:92)
+    if (a.lse && qi < a.Tq && g == 0) a.lse[((int64_t)b * a.H + h) * a.Tq + qi] = l_tot > 0.f ? m_run + logf(l_tot) : -INFINITY;
     if (qi < a.Tq) {
         const int64_t ob = ((int64_t)b * a.Tq + qi) * ((int64_t)a.H * dk) + (int64_t)h * dk;
 #pragma unroll
@@ -505,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
     const float inv = l_tot > 0.f ? __builtin_amdgcn_rcpf(l_tot) : 0.f;
+    if (a.lse && qi < a.Tq && g == 0) a.lse[((int64_t)b * a.H + h) * a.Tq + qi] = l_tot > 0.f ? m_run + logf(l_tot) : -INFINITY;
     if (qi < a.Tq) {
         const int64_t ob = ((int64_t)b * a.Tq + qi) * ((int64_t)a.H * dk) + (int64_t)h * dk;
 #pragma unroll
@@ -600,7 +563,7 @@ extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
     a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.k_sh = d->k_sh;
     a.v_sb = d->v_sb; a.v_st = d->v_st; a.v_sh = d->v_sh; a.p_sb = d->p_sb; a.p_st = d->p_st; a.m_sb = d->m_sb; a.m_sq = d->m_sq;
     a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk; a.dk = d->dk;
-    a.q_dtype = d->q_dtype; a.kv_dtype = d->kv_dtype; a.p_dtype = d->p_dtype; a.out_dtype = d->out_dtype; a.scale = d->scale;
+    a.q_dtype = d->q_dtype; a.kv_dtype = d->kv_dtype; a.p_dtype = d->p_dtype; a.out_dtype = d->out_dtype; a.scale = d->scale; a.lse = d->lse;
     hipStream_t s = (hipStream_t)stream;
     const bool pos = d->p != nullptr;
     // v2 fast path: d_k = 64, 16-bit q (and p) of the MFMA type, K/V either that type or f32 (streaming cache), 16-byte

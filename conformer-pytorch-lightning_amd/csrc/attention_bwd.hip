@@ -1,0 +1,323 @@
+// attention_bwd.hip -- backward of the fused attention (attention.py:81-96 under autograd), gfx950.
+//
+//   P = softmax_j(scale * q'_i . k_j  [masked])      (q' = q + pos_bias_u, added by the projection's bias in train mode; the batch
+//   O = P . V                                          path's positional term is constant along a row: softmax-invariant, no gradient)
+//   delta_i = dO_i . O_i
+//   dS = P * (dO . V^T - delta) * scale;   dQ = dS . K;   dK = dS^T . Q';   dV = P^T . dO
+//
+// Flash-style recomputation: the forward kept only the row log-sum-exp (cfm_attn_desc.lse), so P is rebuilt tile by tile as
+// exp(scale * s - lse) and nothing of size Tq x Tk reaches memory.  Two kernels with the forward kernel's structure (cfm_attn_kernel:
+// 256 threads, 4 wavefronts x 16 rows, 64-wide tiles staged in LDS, swapped MFMA orientation so a lane owns one query / key column):
+//   cfm_attn_bwd_dq_kernel   workgroup = (b, h, 64 queries), loops over key tiles:   S^T = K Q'^T, dP^T = V dO^T, dQ^T += K^T dS^T
+//   cfm_attn_bwd_dkv_kernel  workgroup = (b, h, 64 keys),    loops over query tiles: S = Q' K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q'^T dS
+// Each computes the scores twice over (5 products instead of the minimal 4 + a cross-workgroup reduction) in exchange for no atomics:
+// bitwise reproducible.  A fully masked row (lse = -inf) has P = 0 and contributes nothing -- the reference's masked_fill(mask, 0.0)
+// after the softmax makes such a row a constant (attention.py:91-92).
+// SPLIT evaluates every product as hi*hi + lo*hi + hi*lo on bf16 planes (f32-accurate mode, f32 tensors in memory).
+#include "cfm_common.h"
+#include "attn_common.h"
+
+struct AttnBwdArgs {
+    const void *q, *k, *v, *out, *dout;
+    const float* lse;
+    const uint8_t* mask;
+    void *dq, *dkk, *dv;
+    float* delta;
+    int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, m_sb, m_sq;
+    int B, H, Tq, Tk, dk;
+    int io_dt, do_dt;
+    float scale;
+};
+
+namespace {
+
+__global__ void cfm_attn_delta_kernel(const AttnBwdArgs a) {
+    const int64_t n = (int64_t)a.B * a.H * a.Tq;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const int i = (int)(id % a.Tq);
+    const int h = (int)((id / a.Tq) % a.H);
+    const int b = (int)(id / ((int64_t)a.Tq * a.H));
+    const int64_t o = ((int64_t)b * a.Tq + i) * ((int64_t)a.H * a.dk) + (int64_t)h * a.dk;
+    float s = 0.f;
+    for (int d = 0; d < a.dk; d += 4) {
+        float x[4], y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = load_as_f32(a.out, o + d + e, a.io_dt);
+            y[e] = load_as_f32(a.dout, o + d + e, a.do_dt);
+        }
+        s += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+    }
+    a.delta[id] = s;
+}
+
+// 64 rows x dk of `src` (row r at element offset base + r*stride, rows >= nrows read as zero) -> row-major swizzled planes `rm` (may be
+// null) and transposed planes `tr` [d][row] (may be null)
+template <typename HT, bool SPLIT>
+__device__ __forceinline__ void stage_tile(const void* src, int dt, int64_t base, int64_t stride, int r0, int nrows, int dk, u32x4* rm, u16* tr, int tid) {
+    constexpr int KS_PLANE = KT * 8, VT_PLANE = DKP * VSTR;
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) {
+        const int id = pss * 256 + tid;
+        const int row = id >> 3, c = id & 7;
+        const int rr = r0 + row;
+        const int d0 = c * 8;
+        const int nv = rr < nrows ? dk - d0 : 0;
+        float f[8];
+        load8f(src, dt, base + (int64_t)(rr < nrows ? rr : 0) * stride + d0, nv, f);
+        if (rm) {
+            u32x4 hi, lo;
+            pack_planes<HT, SPLIT>(f, hi, lo);
+            rm[k_swz(row, c)] = hi;
+            if constexpr (SPLIT) rm[KS_PLANE + k_swz(row, c)] = lo;
+        }
+        if (tr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (SPLIT) {
+                    const u16 hb = BF16::from_f32(f[j]);
+                    tr[(d0 + j) * VSTR + row] = hb;
+                    tr[VT_PLANE + (d0 + j) * VSTR + row] = BF16::from_f32(f[j] - BF16::to_f32(hb));
+                } else {
+                    tr[(d0 + j) * VSTR + row] = HT::from_f32(f[j]);
+                }
+            }
+        }
+    }
+}
+
+// acc[f] (f = 0..3: 16-row fragments of the LDS tile) += tile[f*16 + .., :] . frag^T   -- the "first product" of both kernels
+template <typename HT, bool SPLIT>
+__device__ __forceinline__ void tile_dot(const u32x4* tile, const u32x4 (&fr)[2], const u32x4 (&frl)[2], f32x4 (&acc)[4], int l15, int g) {
+    constexpr int KS_PLANE = KT * 8;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int idx = k_swz(f * 16 + l15, kk * 4 + g);
+            const u32x4 t = tile[idx];
+            if constexpr (SPLIT) {
+                acc[f] = HT::mfma(t, frl[kk], acc[f]);
+                acc[f] = HT::mfma(tile[KS_PLANE + idx], fr[kk], acc[f]);
+            }
+            acc[f] = HT::mfma(t, fr[kk], acc[f]);
+        }
+    }
+}
+
+// acc[fd] += T^T[fd*16 + .., 32-step k2] . b^T  with T^T a transposed tile [d][row] (stride VSTR) and b the packed accumulator fragment
+template <typename HT, bool SPLIT>
+__device__ __forceinline__ void tr_dot(const u16* tr, int k2, const u32x4& bh, const u32x4& bl, f32x4 (&acc)[4], int l15, int g) {
+    constexpr int VT_PLANE = DKP * VSTR;
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) {
+        const int o0 = (fd * 16 + l15) * VSTR + (2 * k2) * 16 + g * 4;
+        const u32x2 v0 = *(const u32x2*)(tr + o0);
+        const u32x2 v1 = *(const u32x2*)(tr + o0 + 16);
+        const u32x4 th = {v0.x, v0.y, v1.x, v1.y};
+        if constexpr (SPLIT) {
+            const u32x2 w0 = *(const u32x2*)(tr + VT_PLANE + o0);
+            const u32x2 w1 = *(const u32x2*)(tr + VT_PLANE + o0 + 16);
+            const u32x4 tl = {w0.x, w0.y, w1.x, w1.y};
+            acc[fd] = HT::mfma(th, bl, acc[fd]);
+            acc[fd] = HT::mfma(tl, bh, acc[fd]);
+        }
+        acc[fd] = HT::mfma(th, bh, acc[fd]);
+    }
+}
+
+template <typename HT, bool SPLIT>
+__device__ __forceinline__ void row_frags(const void* src, int dt, int64_t off, int dk, int g, u32x4 (&hi)[2], u32x4 (&lo)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int d0 = kk * 32 + g * 8;
+        float f[8];
+        load8f(src, dt, off + d0, dk - d0, f);
+        pack_planes<HT, SPLIT>(f, hi[kk], lo[kk]);
+    }
+}
+
+__device__ __forceinline__ void store_row4(void* base, int dt, int64_t off, const f32x4& o) {
+    if (dt == CFM_F32) *(f32x4*)((float*)base + off) = o;
+    else if (dt == CFM_BF16) *(u32x2*)((u16*)base + off) = (u32x2){pack2<BF16>(o.x, o.y), pack2<BF16>(o.z, o.w)};
+    else *(u32x2*)((u16*)base + off) = (u32x2){pack2<F16>(o.x, o.y), pack2<F16>(o.z, o.w)};
+}
+
+template <typename HT, bool SPLIT>
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dq_kernel(const AttnBwdArgs a) {
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int KS_PLANE = KT * 8, VT_PLANE = DKP * VSTR;
+    __shared__ u32x4 Ks[KS_PLANE * NPL];
+    __shared__ u32x4 Vs[KS_PLANE * NPL];
+    __shared__ __attribute__((aligned(16))) u16 Kt[VT_PLANE * NPL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qi = blockIdx.x * QT + wave * 16 + l15;
+    const int qc = qi < a.Tq ? qi : a.Tq - 1;
+    const int dk = a.dk;
+    u32x4 qf[2], qfl[2], dof[2], dofl[2];
+    row_frags<HT, SPLIT>(a.q, a.io_dt, (int64_t)b * a.q_sb + (int64_t)qc * a.q_st + h * dk, dk, g, qf, qfl);
+    row_frags<HT, SPLIT>(a.dout, a.do_dt, ((int64_t)b * a.Tq + qc) * ((int64_t)a.H * dk) + (int64_t)h * dk, dk, g, dof, dofl);
+    const int64_t rid = ((int64_t)b * a.H + h) * a.Tq + qc;
+    const float lse_q = qi < a.Tq ? a.lse[rid] : -INFINITY;
+    const float delta_q = a.delta[rid];
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t kb = (int64_t)b * a.k_sb + (int64_t)h * dk, vb = (int64_t)b * a.v_sb + (int64_t)h * dk;
+    const int ntiles = (a.Tk + KT - 1) / KT;
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * KT;
+        __syncthreads();
+        stage_tile<HT, SPLIT>(a.k, a.io_dt, kb, a.k_st, k0, a.Tk, dk, Ks, Kt, tid);
+        stage_tile<HT, SPLIT>(a.v, a.io_dt, vb, a.v_st, k0, a.Tk, dk, Vs, nullptr, tid);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+        tile_dot<HT, SPLIT>(Ks, qf, qfl, s, l15, g);       // s[f][r]: key k0 + f*16 + g*4 + r, query qi
+        tile_dot<HT, SPLIT>(Vs, dof, dofl, dp, l15, g);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kj = k0 + f * 16 + g * 4 + r;
+                bool ok = kj < a.Tk && lse_q != -INFINITY;
+                if (ok && a.mask) ok = a.mask[(int64_t)b * a.m_sb + (int64_t)qc * a.m_sq + kj] != 0;
+                const float p = ok ? __expf(s[f][r] * a.scale - lse_q) : 0.f;
+                s[f][r] = p * (dp[f][r] - delta_q) * a.scale;  // dS
+            }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const float pf[8] = {s[2 * k2][0], s[2 * k2][1], s[2 * k2][2], s[2 * k2][3], s[2 * k2 + 1][0], s[2 * k2 + 1][1], s[2 * k2 + 1][2], s[2 * k2 + 1][3]};
+            u32x4 ph, pl;
+            pack_planes<HT, SPLIT>(pf, ph, pl);
+            tr_dot<HT, SPLIT>(Kt, k2, ph, pl, acc, l15, g);   // dQ^T[d, q] += K^T[d, key] dS^T[key, q]
+        }
+    }
+    if (qi < a.Tq) {
+        const int64_t ob = (int64_t)b * a.q_sb + (int64_t)qi * a.q_st + h * dk;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            const int d = fd * 16 + g * 4;
+            if (d < dk) store_row4(a.dq, a.io_dt, ob + d, acc[fd]);
+        }
+    }
+}
+
+template <typename HT, bool SPLIT>
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int KS_PLANE = KT * 8, VT_PLANE = DKP * VSTR;
+    __shared__ u32x4 Qs[KS_PLANE * NPL];
+    __shared__ u32x4 Os[KS_PLANE * NPL];
+    __shared__ __attribute__((aligned(16))) u16 Qt[VT_PLANE * NPL];
+    __shared__ __attribute__((aligned(16))) u16 Ot[VT_PLANE * NPL];
+    __shared__ float Ls[QT], Ds[QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int kj = blockIdx.x * KT + wave * 16 + l15;
+    const int kc = kj < a.Tk ? kj : a.Tk - 1;
+    const int dk = a.dk;
+    u32x4 kf[2], kfl[2], vf[2], vfl[2];
+    row_frags<HT, SPLIT>(a.k, a.io_dt, (int64_t)b * a.k_sb + (int64_t)kc * a.k_st + h * dk, dk, g, kf, kfl);
+    row_frags<HT, SPLIT>(a.v, a.io_dt, (int64_t)b * a.v_sb + (int64_t)kc * a.v_st + h * dk, dk, g, vf, vfl);
+    f32x4 acc_k[4], acc_v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_k[i] = acc_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t qb = (int64_t)b * a.q_sb + (int64_t)h * dk, ob = (int64_t)b * a.Tq * ((int64_t)a.H * dk) + (int64_t)h * dk;
+    const int64_t rb = ((int64_t)b * a.H + h) * a.Tq;
+    const int ntiles = (a.Tq + QT - 1) / QT;
+    for (int t = 0; t < ntiles; ++t) {
+        const int q0 = t * QT;
+        __syncthreads();
+        stage_tile<HT, SPLIT>(a.q, a.io_dt, qb, a.q_st, q0, a.Tq, dk, Qs, Qt, tid);
+        stage_tile<HT, SPLIT>(a.dout, a.do_dt, ob, (int64_t)a.H * dk, q0, a.Tq, dk, Os, Ot, tid);
+        if (tid < QT) {
+            const int qq = q0 + tid;
+            Ls[tid] = qq < a.Tq ? a.lse[rb + qq] : -INFINITY;
+            Ds[tid] = qq < a.Tq ? a.delta[rb + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x4 s[4], dp[4];
+        tile_dot<HT, SPLIT>(Qs, kf, kfl, s, l15, g);       // s[f][r]: query q0 + f*16 + g*4 + r, key kj
+        tile_dot<HT, SPLIT>(Os, vf, vfl, dp, l15, g);
+        float pv[4][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = f * 16 + g * 4 + r, qq = q0 + ql;
+                const float L = Ls[ql];
+                bool ok = qq < a.Tq && kj < a.Tk && L != -INFINITY;
+                if (ok && a.mask) ok = a.mask[(int64_t)b * a.m_sb + (int64_t)qq * a.m_sq + kj] != 0;
+                const float p = ok ? __expf(s[f][r] * a.scale - L) : 0.f;
+                pv[f][r] = p;
+                s[f][r] = p * (dp[f][r] - Ds[ql]) * a.scale;   // dS
+            }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const float pf[8] = {pv[2 * k2][0], pv[2 * k2][1], pv[2 * k2][2], pv[2 * k2][3], pv[2 * k2 + 1][0], pv[2 * k2 + 1][1], pv[2 * k2 + 1][2], pv[2 * k2 + 1][3]};
+            const float sf[8] = {s[2 * k2][0], s[2 * k2][1], s[2 * k2][2], s[2 * k2][3], s[2 * k2 + 1][0], s[2 * k2 + 1][1], s[2 * k2 + 1][2], s[2 * k2 + 1][3]};
+            u32x4 ph, pl, sh, sl;
+            pack_planes<HT, SPLIT>(pf, ph, pl);
+            pack_planes<HT, SPLIT>(sf, sh, sl);
+            tr_dot<HT, SPLIT>(Ot, k2, ph, pl, acc_v, l15, g);   // dV^T[d, key] += dO^T[d, q] P[q, key]
+            tr_dot<HT, SPLIT>(Qt, k2, sh, sl, acc_k, l15, g);   // dK^T[d, key] += Q'^T[d, q] dS[q, key]
+        }
+    }
+    if (kj < a.Tk) {
+        const int64_t ko = (int64_t)b * a.k_sb + (int64_t)kj * a.k_st + h * dk, vo = (int64_t)b * a.v_sb + (int64_t)kj * a.v_st + h * dk;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            const int d = fd * 16 + g * 4;
+            if (d < dk) {
+                store_row4(a.dkk, a.io_dt, ko + d, acc_k[fd]);
+                store_row4(a.dv, a.io_dt, vo + d, acc_v[fd]);
+            }
+        }
+    }
+}
+
+template <typename HT, bool SPLIT>
+int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char* n_dkv) {
+    const double fl = 2.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
+    const double by = (double)a.B * a.H * (a.Tq + a.Tk) * a.dk * cfm_elt_size(a.io_dt) * 3;
+    {
+        CfmProfScope prof("attn_bwd_delta", s, 0.0, 2.0 * a.B * a.Tq * a.H * a.dk * cfm_elt_size(a.io_dt));
+        const int64_t n = (int64_t)a.B * a.H * a.Tq;
+        CFM_LAUNCH(cfm_attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        if (int rc = cfm_launch_status("cfm_attention_bwd (delta)")) return rc;
+    }
+    {
+        CfmProfScope prof(n_dq, s, 3.0 * fl, by);
+        CFM_LAUNCH((cfm_attn_bwd_dq_kernel<HT, SPLIT>), dim3((unsigned)((a.Tq + QT - 1) / QT), (unsigned)a.H, (unsigned)a.B), dim3(256), 0, s, a);
+        if (int rc = cfm_launch_status("cfm_attention_bwd (dq)")) return rc;
+    }
+    CfmProfScope prof(n_dkv, s, 4.0 * fl, by);
+    CFM_LAUNCH((cfm_attn_bwd_dkv_kernel<HT, SPLIT>), dim3((unsigned)((a.Tk + KT - 1) / KT), (unsigned)a.H, (unsigned)a.B), dim3(256), 0, s, a);
+    return cfm_launch_status("cfm_attention_bwd (dkv)");
+}
+
+}  // namespace
+
+extern "C" int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream) {
+    CFM_CHECK_ARG(d && d->q && d->k && d->v && d->out && d->dout && d->lse && d->grad_q && d->grad_k && d->grad_v && d->delta, "cfm_attention_bwd: null pointer");
+    CFM_CHECK_ARG(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "cfm_attention_bwd: empty problem");
+    CFM_CHECK_ARG(d->dk > 0 && d->dk <= DKP && d->dk % 4 == 0, "cfm_attention_bwd: need dk %% 4 == 0 and dk <= 64 (dk=%d)", d->dk);
+    CFM_CHECK_ARG(d->B <= 65535 && d->H <= 65535, "cfm_attention_bwd: B,H must fit a grid dimension");
+    CFM_CHECK_ARG(d->mma_dtype == CFM_BF16 || d->mma_dtype == CFM_F16, "cfm_attention_bwd: mma_dtype must be bf16 or fp16");
+    CFM_CHECK_ARG(!d->split || d->mma_dtype == CFM_BF16, "cfm_attention_bwd: split mode uses bf16 planes");
+    CFM_CHECK_ARG(d->io_dtype >= CFM_F32 && d->io_dtype <= CFM_F16 && d->dout_dtype >= CFM_F32 && d->dout_dtype <= CFM_F16, "cfm_attention_bwd: bad dtype");
+    AttnBwdArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.out = d->out; a.dout = d->dout; a.lse = d->lse; a.mask = d->mask;
+    a.dq = d->grad_q; a.dkk = d->grad_k; a.dv = d->grad_v; a.delta = d->delta;
+    a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st; a.m_sb = d->m_sb; a.m_sq = d->m_sq;
+    a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk; a.dk = d->dk; a.io_dt = d->io_dtype; a.do_dt = d->dout_dtype; a.scale = d->scale;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->split) return launch_bwd<BF16, true>(a, s, "attn_bwd_dq_bf16x3", "attn_bwd_dkv_bf16x3");
+    if (d->mma_dtype == CFM_BF16) return launch_bwd<BF16, false>(a, s, "attn_bwd_dq_bf16", "attn_bwd_dkv_bf16");
+    return launch_bwd<F16, false>(a, s, "attn_bwd_dq_f16", "attn_bwd_dkv_f16");
+}

@@ -7,8 +7,8 @@
 //
 // Two launches:
 //   rows   one wavefront per frame (b, t < len), the whole chip busy: lse = log sum_c exp(logits[t, c]) (16-byte loads, max-shifted,
-//          fp32), then the <= 2U+1 log-probabilities the recursion will need, lp[b, t, s] = logits[t, z_s] - lse, written to a
-//          compact work buffer [B, T, 2 Umax + 1] (z = (blank, y1, blank, y2, ..., blank) is the blank-extended label sequence);
+//          fp32), then the <= 2U+1 log-probabilities the recursion will need, lp[b, t, s] = logits[t, z_s] - lse, shifted by the frame's
+//          maximum o_t and written to a compact work buffer [B, T, 2 Umax + 2] (last slot: o_t) (z = (blank, y1, blank, y2, ..., blank) is the blank-extended label sequence);
 //   alpha  one workgroup per utterance, thread s owns state s (two states per thread when S > 256), alpha double-buffered in
 //          LDS, one barrier per frame, the lp rows of the next frames already in registers (they do not depend on alpha):
 //              alpha_t[s] = lp[t, s] + logaddexp(alpha_{t-1}[s], alpha_{t-1}[s-1], alpha_{t-1}[s-2] if z_s != blank and z_s != z_{s-2})
@@ -45,7 +45,7 @@ __device__ __forceinline__ int ext_label(const int* __restrict__ labels, int64_t
 // rows: grid = ceil(B*T / 4) workgroups of 4 wavefronts, wavefront = one frame
 __global__ __launch_bounds__(CTC_NT) void cfm_ctc_rows_kernel(const float* __restrict__ logits, int64_t ld, int B, int T, int V,
                                                               const int* __restrict__ enc_lens, const int* __restrict__ labels, int Umax,
-                                                              const int* __restrict__ label_lens, float* __restrict__ work) {
+                                                              const int* __restrict__ label_lens, float* __restrict__ work, float* __restrict__ lse_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row_id = (int64_t)blockIdx.x * (CTC_NT / 64) + (threadIdx.x >> 6);
     if (row_id >= (int64_t)B * T) return;
@@ -72,21 +72,44 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_rows_kernel(const float* __res
         }
     }
     const float lse = m + logf(wave_sum(sum));
-    const int S = 2 * min(max(label_lens[b], 0), Umax) + 1, SM = 2 * Umax + 1;
-    for (int s = lane; s < S; s += 64) work[row_id * SM + s] = row[ext_label(labels, (int64_t)b * Umax, s, V)] - lse;
+    if (lse_out && lane == 0) lse_out[row_id] = lse;
+    // The recursions run on lp'[t,s] = lp[t,s] - o_t with o_t = max_s lp[t,s]: along the likely paths lp' is ~0, so alpha' / beta' stay small
+    // numbers instead of growing like -8 per frame, and fp32 keeps ~1e-6 absolute in the log domain however long the utterance
+    // (unshifted: |alpha| ~ 2000 at T' = 249, one ulp = 1.2e-4, gradients off by 1e-3).  sum_t o_t is added back to the loss in fp64;
+    // the state posteriors do not depend on it.  o_t sits in the row's last slot (row stride 2 Umax + 2).
+    const int S = 2 * min(max(label_lens[b], 0), Umax) + 1, SW = 2 * Umax + 2;
+    float lpv[(CTC_MAXS + 63) / 64];
+    float omax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < (CTC_MAXS + 63) / 64; ++i) {
+        const int s = lane + 64 * i;
+        lpv[i] = s < S ? row[ext_label(labels, (int64_t)b * Umax, s, V)] - lse : -INFINITY;
+        omax = fmaxf(omax, lpv[i]);
+    }
+    omax = wave_max(omax);
+#pragma unroll
+    for (int i = 0; i < (CTC_MAXS + 63) / 64; ++i) {
+        const int s = lane + 64 * i;
+        if (s < S) work[row_id * SW + s] = lpv[i] - omax;
+    }
+    if (lane == 0) work[row_id * SW + SW - 1] = omax;
 }
 
 // alpha: one workgroup per utterance
 __global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __restrict__ work, int T, int V, const int* __restrict__ enc_lens,
                                                                const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
-                                                               float* __restrict__ nll) {
+                                                               float* __restrict__ nll, float* __restrict__ alpha_out, float* __restrict__ nllp_out) {
     __shared__ float alpha[2][CTC_MAXS + 2];
+    __shared__ double osum[CTC_NT];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int len = min(max(enc_lens[b], 0), T);
     const int U = min(max(label_lens[b], 0), Umax);
-    const int S = 2 * U + 1, SM = 2 * Umax + 1;
+    const int S = 2 * U + 1, SM = 2 * Umax + 2;             // row stride of work / alpha (the last slot of a work row is the frame's offset)
     if (len == 0) {                                        // no frames: only the empty label sequence is possible
-        if (tid == 0) nll[b] = U == 0 ? 0.f : INFINITY;
+        if (tid == 0) {
+            nll[b] = U == 0 ? 0.f : INFINITY;
+            if (nllp_out) nllp_out[b] = nll[b];
+        }
         return;
     }
     const float* lp = work + (int64_t)b * T * SM;
@@ -106,7 +129,11 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int s = tid + i * CTC_NT;
-        if (live[i]) alpha[0][s + 2] = s < 2 ? lp[s] : -INFINITY;
+        if (live[i]) {
+            const float a0 = s < 2 ? lp[s] : -INFINITY;
+            alpha[0][s + 2] = a0;
+            if (alpha_out) alpha_out[(int64_t)b * T * SM + s] = a0;
+        }
     }
     constexpr int AHEAD = 4;                               // lp rows requested this many frames before they are used
     float nxt[AHEAD][2];
@@ -131,6 +158,7 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __re
                         float a = logaddexp_(alpha[cur][s + 2], alpha[cur][s + 1]);
                         if (skip[i]) a = logaddexp_(a, alpha[cur][s]);
                         alpha[cur ^ 1][s + 2] = a + nxt[k][i];
+                        if (alpha_out) alpha_out[((int64_t)b * T + t) * SM + s] = a + nxt[k][i];
                         const int tn = t + AHEAD;
                         nxt[k][i] = tn < len ? lp[(int64_t)tn * SM + s] : 0.f;
                     }
@@ -140,16 +168,132 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __re
             }
         }
     }
+    double part = 0.0;                                      // sum_t o_t, fp64
+    for (int t = tid; t < len; t += CTC_NT) part += (double)lp[(int64_t)t * SM + SM - 1];
+    osum[tid] = part;
+    __syncthreads();
     if (tid == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < CTC_NT; ++i) tot += osum[i];
         const float a = S >= 2 ? logaddexp_(alpha[cur][S + 1], alpha[cur][S]) : alpha[cur][S + 1];
-        nll[b] = -a;
+        nll[b] = (float)(-((double)a + tot));
+        if (nllp_out) nllp_out[b] = -a;                     // the shifted recursion's own -log P': what the posteriors are normalised with
+    }
+}
+
+
+// beta recursion, one workgroup per utterance, walking the frames backwards; ab[t][s] = log(alpha_t(s) beta_t(s) / y_t(z_s)) replaces
+// alpha in place (both recursions include the emission at t, as torch's CTC does, hence the division)
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __restrict__ work, float* __restrict__ ab, int T, int V, const int* __restrict__ enc_lens,
+                                                              const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens) {
+    __shared__ float beta[2][CTC_MAXS + 2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int len = min(max(enc_lens[b], 0), T);
+    const int U = min(max(label_lens[b], 0), Umax);
+    const int S = 2 * U + 1, SM = 2 * Umax + 2;
+    if (len == 0) return;
+    const float* lp = work + (int64_t)b * T * SM;
+    float* abp = ab + (int64_t)b * T * SM;
+    bool skip[2], live[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = tid + i * CTC_NT;
+        live[i] = s < S;
+        skip[i] = false;
+        if (live[i] && s + 2 < S && (s & 1)) {              // s -> s+2 skips a blank: allowed when the two labels differ
+            const int z2 = ext_label(labels, (int64_t)b * Umax, s + 2, V);
+            skip[i] = z2 != 0 && z2 != ext_label(labels, (int64_t)b * Umax, s, V);
+        }
+    }
+    // state s lives at index s; indices S and S+1 are -inf guard cells so that s+1 / s+2 need no branch
+    for (int i = tid; i < CTC_MAXS + 2; i += CTC_NT) beta[0][i] = beta[1][i] = -INFINITY;
+    __syncthreads();
+    int cur = 0;
+    {
+        const int t = len - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = tid + i * CTC_NT;
+            if (live[i]) {
+                const float l = lp[(int64_t)t * SM + s];
+                const float bt = (s >= S - 2) ? l : -INFINITY;
+                beta[0][s] = bt;
+                abp[(int64_t)t * SM + s] = abp[(int64_t)t * SM + s] + bt - l;
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = len - 2; t >= 0; --t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = tid + i * CTC_NT;
+            if (live[i]) {
+                float a = logaddexp_(beta[cur][s], beta[cur][s + 1]);
+                if (skip[i]) a = logaddexp_(a, beta[cur][s + 2]);
+                const float l = lp[(int64_t)t * SM + s];
+                beta[cur ^ 1][s] = a + l;
+                abp[(int64_t)t * SM + s] = abp[(int64_t)t * SM + s] + a;      // alpha + beta - lp
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// d nll / d logits, one wavefront per frame, persistent over frames.  Each wavefront keeps an occupancy table over the vocabulary in LDS:
+// the <= 2U+1 state posteriors exp(ab + nll) of a frame are scattered into it (several states share a class: blank, repeated labels),
+// the row is written as gs * (softmax - occupancy), and the touched entries are cleared again.
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_grad_kernel(const float* __restrict__ logits, int64_t ld, int B, int T, int V, const int* __restrict__ enc_lens,
+                                                              const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
+                                                              const float* __restrict__ ab, const float* __restrict__ lse, const float* __restrict__ nll,
+                                                              float gscale, const float* __restrict__ gscale_dev, float* __restrict__ dlogits) {
+    extern __shared__ float occ_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Vp = (V + 3) & ~3;
+    float* occ = occ_all + wave * Vp;
+    for (int c = lane; c < Vp; c += 64) occ[c] = 0.f;
+    __threadfence_block();
+    const float gs = gscale * (gscale_dev ? *gscale_dev : 1.f);
+    const int SM = 2 * Umax + 2;
+    const int64_t rows = (int64_t)B * T;
+    for (int64_t row_id = (int64_t)blockIdx.x * (CTC_NT / 64) + wave; row_id < rows; row_id += (int64_t)gridDim.x * (CTC_NT / 64)) {
+        const int b = (int)(row_id / T), t = (int)(row_id % T);
+        const float* row = logits + row_id * ld;
+        float* drow = dlogits + row_id * ld;
+        const float nl = nll[b];
+        const bool live = t < min(max(enc_lens[b], 0), T) && nl < INFINITY && nl > -INFINITY;
+        if (!live) {                                        // padded frame (or an impossible alignment: torch's gradient is undefined there)
+            for (int c = lane * 4; c < (int)ld; c += 256) {
+                if (c + 3 < (int)ld) *(f32x4*)(drow + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                else for (int k = c; k < (int)ld; ++k) drow[k] = 0.f;
+            }
+            continue;
+        }
+        const int S = 2 * min(max(label_lens[b], 0), Umax) + 1;
+        for (int s = lane; s < S; s += 64) atomicAdd(&occ[ext_label(labels, (int64_t)b * Umax, s, V)], __expf(ab[row_id * SM + s] + nl));
+        __threadfence_block();
+        const float l = lse[row_id];
+        for (int c = lane * 4; c < (int)ld; c += 256) {
+            if (c + 3 < V) {
+                const f32x4 v = *(const f32x4*)(row + c), o = *(const f32x4*)(occ + c);
+                f32x4 gq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gq[e] = gs * (__expf(v[e] - l) - o[e]);
+                *(f32x4*)(drow + c) = gq;
+            } else {
+                for (int k = c; k < (int)ld && k < c + 4; ++k) drow[k] = k < V ? gs * (__expf(row[k] - l) - occ[k]) : 0.f;
+            }
+        }
+        __threadfence_block();
+        for (int s = lane; s < S; s += 64) occ[ext_label(labels, (int64_t)b * Umax, s, V)] = 0.f;
+        __threadfence_block();
     }
 }
 
 }  // namespace
 
-extern "C" int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens,
-                           const int32_t* labels, int32_t Umax, const int32_t* label_lens, float* work, float* nll, cfm_stream_t stream) {
+static int ctc_forward(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
+                       const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nllp, cfm_stream_t stream) {
     CFM_CHECK_ARG(logits && enc_lens && labels && label_lens && work && nll, "cfm_ctc_nll: null pointer");
     CFM_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0, "cfm_ctc_nll: bad shape B=%d T=%d V=%d Umax=%d", B, T, V, Umax);
     CFM_CHECK_ARG(2 * Umax + 1 <= CTC_MAXS, "cfm_ctc_nll: Umax=%d labels exceeds %d", Umax, (CTC_MAXS - 1) / 2);
@@ -159,10 +303,52 @@ extern "C" int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T
         const int64_t rows = (int64_t)B * T;
         CfmProfScope prof("ctc_rows", s, 0.0, (double)rows * V * 4);
         CFM_LAUNCH(cfm_ctc_rows_kernel, dim3((unsigned)((rows + CTC_NT / 64 - 1) / (CTC_NT / 64))), dim3(CTC_NT), 0, s, logits, ld, B, T, V, enc_lens,
-                   labels, Umax, label_lens, work);
+                   labels, Umax, label_lens, work, lse);
         if (int rc = cfm_launch_status("cfm_ctc_nll (rows)")) return rc;
     }
     CfmProfScope prof("ctc_alpha", s, 0.0, (double)B * T * (2 * Umax + 1) * 4);
-    CFM_LAUNCH(cfm_ctc_alpha_kernel, dim3(B), dim3(CTC_NT), 0, s, (const float*)work, T, V, enc_lens, labels, Umax, label_lens, nll);
+    CFM_LAUNCH(cfm_ctc_alpha_kernel, dim3(B), dim3(CTC_NT), 0, s, (const float*)work, T, V, enc_lens, labels, Umax, label_lens, nll, alpha, nllp);
     return cfm_launch_status("cfm_ctc_nll (alpha)");
+}
+
+extern "C" int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens,
+                           const int32_t* labels, int32_t Umax, const int32_t* label_lens, float* work, float* nll, cfm_stream_t stream) {
+    return ctc_forward(logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, work, nullptr, nullptr, nll, nullptr, stream);
+}
+
+extern "C" int cfm_ctc_nll_train(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
+                                 const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, cfm_stream_t stream) {
+    CFM_CHECK_ARG(alpha && lse && nll_shifted, "cfm_ctc_nll_train: null pointer");
+    return ctc_forward(logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, work, alpha, lse, nll, nll_shifted, stream);
+}
+
+extern "C" int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
+                            const int32_t* label_lens, const float* work, float* alpha_beta, const float* lse, const float* nll_shifted, float gscale,
+                            const float* gscale_dev, float* dlogits, cfm_stream_t stream) {
+    const float* nll = nll_shifted;
+    CFM_CHECK_ARG(logits && enc_lens && labels && label_lens && work && alpha_beta && lse && nll && dlogits, "cfm_ctc_grad: null pointer");
+    CFM_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0 && 2 * Umax + 1 <= CTC_MAXS, "cfm_ctc_grad: bad shape B=%d T=%d V=%d Umax=%d", B, T, V, Umax);
+    CFM_CHECK_ARG(ld >= V && ld % 4 == 0, "cfm_ctc_grad: row stride %lld must be >= V and a multiple of 4", (long long)ld);
+    const int Vp = (V + 3) & ~3;
+    const size_t lds = (size_t)(CTC_NT / 64) * Vp * 4;
+    CFM_CHECK_ARG(lds <= 128 * 1024, "cfm_ctc_grad: vocabulary of %d classes exceeds the LDS occupancy tables (<= 8192)", V);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        CfmProfScope prof("ctc_beta", s, 0.0, (double)B * T * (2 * Umax + 1) * 12);
+        CFM_LAUNCH(cfm_ctc_beta_kernel, dim3(B), dim3(CTC_NT), 0, s, work, alpha_beta, T, V, enc_lens, labels, Umax, label_lens);
+        if (int rc = cfm_launch_status("cfm_ctc_grad (beta)")) return rc;
+    }
+    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the attribute once per process
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)cfm_ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return cfm_fail(CFM_ERR_LAUNCH, "cfm_ctc_grad: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int64_t rows = (int64_t)B * T;
+    int64_t nb = (rows + CTC_NT / 64 - 1) / (CTC_NT / 64);
+    nb = nb > 512 ? 512 : nb;
+    CfmProfScope prof("ctc_grad", s, 0.0, (double)rows * ld * 8);
+    CFM_LAUNCH(cfm_ctc_grad_kernel, dim3((unsigned)nb), dim3(CTC_NT), lds, s, logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, (const float*)alpha_beta, lse, nll,
+               gscale, gscale_dev, dlogits);
+    return cfm_launch_status("cfm_ctc_grad");
 }

@@ -35,7 +35,10 @@ struct GemmArgs {
     const float* res;
     const uint8_t* mask;
     void* C;
-    int64_t lda, ldc, ldr;
+    void* Cpre;      // training: optional second output, acc + bias before the activation (row stride ld_pre, pre_dtype)
+    const void* aux; // training: pre-activation (DSILU) / forward output (DRELU) of the layer whose input gradient this GEMM computes
+    int64_t lda, ldc, ldr, ld_pre, ld_aux;
+    int pre_dtype, aux_dtype;
     int M, N, K;
     int m_begin;     // first row this launch computes (rows [m_begin, M)); 0 except for the tail of a split launch (see cfm_gemm)
     int c_dtype, act, mask_mode;
@@ -306,6 +309,13 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     // (in-place accumulate) and the compiler cannot prove it does not alias `bias`, so a load placed after a store is
     // serialised behind it -- 16 fragments x one exposed L2 latency each (measured: +6 us per launch for the bias alone).
     f32x4 res_r[FM][FN];
+    const bool dact = g.act == CFM_ACT_DSILU || g.act == CFM_ACT_DRELU;
+    auto store_pre = [&](int row, int col, const f32x4& pv) {   // training: the pre-activation, 4 columns (N % 4 == 0 checked by the host)
+        const int64_t po = (int64_t)row * g.ld_pre + col;
+        if (g.pre_dtype == CFM_F32) *(f32x4*)((float*)g.Cpre + po) = pv;
+        else if (g.pre_dtype == CFM_BF16) *(u32x2*)((u16*)g.Cpre + po) = (u32x2){pack2<BF16>(pv[0], pv[1]), pack2<BF16>(pv[2], pv[3])};
+        else *(u32x2*)((u16*)g.Cpre + po) = (u32x2){pack2<F16>(pv[0], pv[1]), pack2<F16>(pv[2], pv[3])};
+    };
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
@@ -316,6 +326,18 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             const int ocol = glu ? (cb >> 1) + q4 : col;
             const bool live = g.res && row < g.M && col < g.N && !(glu && (j & 1));
             res_r[i][j] = live ? *(const f32x4*)(g.res + (int64_t)row * g.ldr + ocol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (dact && row < g.M && col + 3 < g.N) {        // backward epilogue: the activation's argument shares the residual's registers
+                const int64_t ao = (int64_t)row * g.ld_aux + col;
+                if (g.aux_dtype == CFM_F32) {
+                    res_r[i][j] = *(const f32x4*)((const float*)g.aux + ao);
+                } else {
+                    const u32x2 r2 = *(const u32x2*)((const u16*)g.aux + ao);
+                    if (g.aux_dtype == CFM_BF16)
+                        res_r[i][j] = (f32x4){BF16::to_f32((u16)(r2.x & 0xffffu)), BF16::to_f32((u16)(r2.x >> 16)), BF16::to_f32((u16)(r2.y & 0xffffu)), BF16::to_f32((u16)(r2.y >> 16))};
+                    else
+                        res_r[i][j] = (f32x4){F16::to_f32((u16)(r2.x & 0xffffu)), F16::to_f32((u16)(r2.x >> 16)), F16::to_f32((u16)(r2.y & 0xffffu)), F16::to_f32((u16)(r2.y >> 16))};
+                }
+            }
         }
     }
 #pragma unroll
@@ -332,12 +354,14 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             if (col >= g.N) continue;
             f32x4 v = in_dead ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j];
             v += bias_r[j];
+            if (g.Cpre && col + 3 < g.N) store_pre(row, col, v);
             int ocol = col;
             if (glu) {
                 constexpr int JN_MAX = FN - 1;
                 const int jn = j + 1 <= JN_MAX ? j + 1 : JN_MAX;  // FN is even; keeps the index static
                 f32x4 gt = in_dead ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][jn];
                 gt += bias_r[jn];
+                if (g.Cpre && col + 16 + 3 < g.N) store_pre(row, col + 16, gt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= sigmoidf_(gt[r]);
                 ocol = (cb >> 1) + q4;
@@ -347,6 +371,15 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             } else if (g.act == CFM_ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (g.act == CFM_ACT_DSILU) {               // d silu(z)/dz = s (1 + z (1 - s)), s = sigmoid(z)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = res_r[i][j][r], sg = sigmoidf_(z);
+                    v[r] *= g.alpha * sg * (1.f + z * (1.f - sg));
+                }
+            } else if (g.act == CFM_ACT_DRELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = res_r[i][j][r] > 0.f ? g.alpha * v[r] : 0.f;
             }
             if (!keep && g.mask_mode == 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (g.res) v = res_r[i][j] + g.alpha * v;
@@ -584,7 +617,7 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
     constexpr int BK = SPLIT ? 32 : 64;
     if constexpr (!SPLIT && !A_F32 && !CONV) {
         // persistent workgroups: plain 16-bit products whose tiles are short (K <= 1024) and many (>= 8 per resident workgroup)
-        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && !a.Wf && a.m_begin == 0;
+        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && !a.Wf && a.m_begin == 0 && !a.Cpre && a.act < CFM_ACT_DSILU;
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         if (tile == 7 || (tile == 0 && plain && a.K % BK == 0 && a.K <= 1024 && t128 >= 8L * CFM_PERSIST_GRID)) {
             if (!plain || a.K % BK) return cfm_fail(CFM_ERR_ARG, "cfm_gemm: the persistent tile takes bias / SiLU / ReLU epilogues only and K %% 64 == 0");
@@ -625,7 +658,12 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_gemm: w_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(d->a_dtype == CFM_F32 || d->a_dtype == d->w_dtype, "cfm_gemm: a_dtype must be f32 or equal w_dtype");
     CFM_CHECK_ARG(d->c_dtype >= CFM_F32 && d->c_dtype <= CFM_F16, "cfm_gemm: bad c_dtype");
-    CFM_CHECK_ARG(d->act >= CFM_ACT_NONE && d->act <= CFM_ACT_GLU, "cfm_gemm: bad activation");
+    CFM_CHECK_ARG(d->act >= CFM_ACT_NONE && d->act <= CFM_ACT_DRELU, "cfm_gemm: bad activation");
+    const bool dact = d->act == CFM_ACT_DSILU || d->act == CFM_ACT_DRELU;
+    CFM_CHECK_ARG(!dact || (d->aux && !d->residual && d->N % 4 == 0 && d->ld_aux % 4 == 0 && d->aux_dtype >= CFM_F32 && d->aux_dtype <= CFM_F16),
+                  "cfm_gemm: a backward activation epilogue needs aux [M,N] (ld_aux %% 4 == 0), N %% 4 == 0 and no residual");
+    CFM_CHECK_ARG(!d->C_pre || (d->N % 4 == 0 && d->ld_pre % 4 == 0 && d->pre_dtype >= CFM_F32 && d->pre_dtype <= CFM_F16 && !dact),
+                  "cfm_gemm: C_pre needs N %% 4 == 0 and ld_pre %% 4 == 0");
     CFM_CHECK_ARG(d->mask_mode == 0 || d->mask_mode == 1, "cfm_gemm: bad mask_mode");
     CFM_CHECK_ARG(d->act != CFM_ACT_GLU || d->N % 32 == 0, "cfm_gemm: GLU needs N %% 32 == 0 (N=%d)", d->N);
     CFM_CHECK_ARG(d->ldc % 2 == 0, "cfm_gemm: ldc=%lld must be a multiple of 2", (long long)d->ldc);
@@ -652,13 +690,14 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     a.Wf = (split || d->a_dtype == CFM_F32) ? nullptr : (const u16*)d->W_frag;
     a.A = d->A; a.W = (const u16*)d->W; a.Wlo = (const u16*)d->W_lo; a.bias = d->bias; a.res = d->residual;
     a.mask = d->row_mask; a.C = d->C; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
+    a.Cpre = d->C_pre; a.ld_pre = d->ld_pre; a.pre_dtype = d->pre_dtype; a.aux = dact ? d->aux : nullptr; a.ld_aux = d->ld_aux; a.aux_dtype = d->aux_dtype;
     a.M = d->M; a.N = d->N; a.K = d->K; a.m_begin = 0; a.c_dtype = d->c_dtype; a.act = d->act; a.alpha = d->alpha; a.mask_mode = d->mask_mode;
     a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
     hipStream_t s = (hipStream_t)stream;
     const bool a32 = d->a_dtype == CFM_F32;
     long head256 = 0;
     {   // 256 x 256 tile with LDS-DMA staging (gemm256.hip): tile id 8, or chosen by a two-line cost model when it can run
-        const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->W_frag;
+        const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->W_frag && !d->C_pre && !dact;
         Gemm256Args b;
         b.A = (const u16*)d->A; b.W = (const u16*)d->W; b.bias = d->bias; b.C = d->C; b.lda = d->lda; b.ldc = d->ldc;
         b.M = d->M; b.N = d->N; b.K = d->K; b.c_dtype = d->c_dtype; b.act = d->act;

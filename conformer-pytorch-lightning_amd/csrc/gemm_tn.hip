@@ -1,0 +1,287 @@
+// gemm_tn.hip -- weight gradients on gfx950 MFMA:   C[N,K] (+)= alpha * A[M,N]^T . B[M,K]      (f32 out)
+//
+// The backward of every dense layer of the conformer block needs  dW = dY^T . X  with dY [M,N] and X [M,K] both stored
+// row-major, i.e. with the CONTRACTION index m as the slow index of both operands (feedforward.py:17-20, attention.py:62-64,99,
+// convolution.py:41,46,62,74 and decoder.py:19 under autograd).  The forward GEMM (gemm.hip) wants k-contiguous operands; rather
+// than writing transposed copies of every activation, this kernel stages [m][col] tiles as they lie in memory (16-byte global
+// loads along n / k) and lets the LDS hardware transpose on the way out: ds_read_b64_tr_b16 hands each lane 4 consecutive m of
+// one column, two of them make the 8-element MFMA fragment.  Both operands use the same (permuted) m order inside a 32-row
+// step -- {4g..4g+3, 16+4g..16+4g+3} for lane group g -- which is all the contraction needs.
+//
+//   tile   128 (n) x 128 (k) outputs per workgroup, 256 threads = 2 x 2 wavefronts of 64 x 64, 16 accumulator fragments each
+//   M      split over `splits` workgroups per tile (training batches are M = 2-8 k rows against N x K <= 2048 x 256 outputs: a
+//          single pass over M would leave most CUs idle); partial products meet in C through f32 atomics (global_atomic_add_f32)
+//   bias   the column sums of A (d loss / d bias) ride along in the k-tile-0 workgroups: the A tile is in LDS anyway
+//   conv   B rows may be the implicit im2col rows of a channels-last image (3x3 stride 2): the front-end's conv2 weight gradient
+//   SPLIT  f32 operands split into bf16 hi/lo planes while staging, 3 MFMAs per fragment pair (the f32-accurate mode)
+#include <string>
+
+#include "cfm_common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct TnArgs {
+    const void* A;
+    const void* B;
+    float* C;
+    float* colsum;
+    const uint8_t* mask;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    float alpha;
+    int convC, T1, F1, T2, F2;
+    int chunks_per_split, atomic;
+};
+
+constexpr int TN_BN = 128, TN_BK = 128;
+constexpr int TN_STR = 128 + 16;   // LDS row stride in 16-bit elements: 288 B = 72 words = 8 (mod 64): the 4 rows of a transposed read hit disjoint banks
+
+template <typename HT, bool SPLIT>
+__device__ __forceinline__ void stage_store(u16* tile, int plane_elems, int row, int col, const u32x4& raw, const f32x4& f0, const f32x4& f1, bool is_f32) {
+    u16* p = tile + row * TN_STR + col;
+    if constexpr (SPLIT) {
+        u32x4 hi, lo;
+        split8(f0, f1, hi, lo);
+        *(u32x4*)p = hi;
+        *(u32x4*)(p + plane_elems) = lo;
+    } else {
+        *(u32x4*)p = is_f32 ? pack8<HT>(f0, f1) : raw;
+    }
+}
+
+// one MFMA operand fragment (16 columns starting at c0, the 32 rows of m-step ms) from a [m][col] tile
+__device__ __forceinline__ u32x4 tr_frag(const u16* tile, int ms, int c0, int g, int l15) {
+    const u16* pa = tile + (ms * 32 + 4 * g + (l15 >> 2)) * TN_STR + c0 + (l15 & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 16 * TN_STR));
+    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+    return (u32x4){lo2.x, lo2.y, hi2.x, hi2.y};
+}
+
+template <typename HT, bool SPLIT, bool A32, bool B32, bool CONV>
+__global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
+    constexpr int MCH = SPLIT ? 32 : 64;             // rows of M per staged chunk
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int PLANE = MCH * TN_STR;              // 16-bit elements per operand plane
+    constexpr int PASSES = MCH / 16;                 // 16-byte pieces per thread and operand: MCH rows x 16 pieces / 256 threads
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * 2 * NPL * PLANE];   // [buffer][A | B][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int wr = wave >> 1, wc = wave & 1;         // wavefront's 64 x 64 quadrant: n rows wr, k columns wc
+    const int tiles_k = (g.K + TN_BK - 1) / TN_BK;
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
+    const int n0 = tile_n * TN_BN, k0 = tile_k * TN_BK;
+    const int chunk_begin = blockIdx.y * g.chunks_per_split;
+    const int total_chunks = (g.M + MCH - 1) / MCH;
+    int chunk_end = chunk_begin + g.chunks_per_split;
+    chunk_end = chunk_end < total_chunks ? chunk_end : total_chunks;
+    if (chunk_begin >= chunk_end) return;            // uniform, before any barrier
+
+    // ---- staging: thread -> (row = pass*16 + tid/16, 8 columns at (tid & 15) * 8) of both operand tiles -------------------------
+    const int prow = tid >> 4, pcol = (tid & 15) * 8;
+    const bool a_col_ok = n0 + pcol < g.N;           // N % 8 == 0: a piece is entirely inside or outside
+    const bool b_col_ok = k0 + pcol < g.K;
+    int64_t b_koff = k0 + pcol;                      // element offset of this thread's B columns inside a row
+    if constexpr (CONV) {
+        const int kk = k0 + pcol;
+        const int tap = kk / g.convC, ci = kk - tap * g.convC;
+        const int k3 = tap / 3, f3 = tap - 3 * k3;
+        b_koff = (int64_t)(k3 * g.F1 + f3) * g.convC + ci;
+    }
+    u32x4 ra[A32 ? 1 : PASSES], rb[B32 ? 1 : PASSES];
+    f32x4 fa[A32 ? PASSES : 1][2], fb[B32 ? PASSES : 1][2];
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int m = chunk * MCH + p * 16 + prow;
+            const bool row_ok = m < g.M;
+            const bool a_ok = row_ok && a_col_ok && (!g.mask || g.mask[m] != 0);
+            const bool b_ok = row_ok && b_col_ok;
+            const int mc = row_ok ? m : 0;
+            if constexpr (A32) {
+                const float* pa = (const float*)g.A + ((int64_t)mc * g.lda + n0 + pcol);
+                fa[p][0] = a_ok ? *(const f32x4*)pa : zf;
+                fa[p][1] = a_ok ? *(const f32x4*)(pa + 4) : zf;
+            } else {
+                ra[p] = a_ok ? *(const u32x4*)((const u16*)g.A + ((int64_t)mc * g.lda + n0 + pcol)) : z4;
+            }
+            int64_t boff;
+            if constexpr (CONV) {
+                const int per_b = g.T2 * g.F2;
+                const int b = mc / per_b, rem = mc - b * per_b;
+                const int t2 = rem / g.F2, f2 = rem - t2 * g.F2;
+                boff = ((int64_t)(b * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.convC + b_koff;
+            } else {
+                boff = (int64_t)mc * g.ldb + b_koff;
+            }
+            if constexpr (B32) {
+                const float* pb = (const float*)g.B + boff;
+                fb[p][0] = b_ok ? *(const f32x4*)pb : zf;
+                fb[p][1] = b_ok ? *(const f32x4*)(pb + 4) : zf;
+            } else {
+                rb[p] = b_ok ? *(const u32x4*)((const u16*)g.B + boff) : z4;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        u16* At = smem + buf * (2 * NPL * PLANE);
+        u16* Bt = At + NPL * PLANE;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int row = p * 16 + prow;
+            if constexpr (A32) stage_store<HT, SPLIT>(At, PLANE, row, pcol, z4, fa[p][0], fa[p][1], true);
+            else stage_store<HT, SPLIT>(At, PLANE, row, pcol, ra[p], zf, zf, false);
+            if constexpr (B32) stage_store<HT, SPLIT>(Bt, PLANE, row, pcol, z4, fb[p][0], fb[p][1], true);
+            else stage_store<HT, SPLIT>(Bt, PLANE, row, pcol, rb[p], zf, zf, false);
+        }
+    };
+
+    f32x4 acc[4][4];                                 // [n fragment][k fragment]: lane holds C[n = .. + l15][k = .. + 4*g4 + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zf;
+    float csum = 0.f;                                // bias gradient: thread t < 128 owns column n0 + t (k-tile 0 workgroups only)
+    const bool do_colsum = g.colsum != nullptr && tile_k == 0 && tid < TN_BN;
+
+    gload(chunk_begin);
+    int buf = 0;
+    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+        lstore(buf);
+        __syncthreads();                             // chunk ch visible; everyone has left chunk ch-1's compute on the OTHER buffer... see below
+        if (ch + 1 < chunk_end) gload(ch + 1);
+        const u16* At = smem + buf * (2 * NPL * PLANE);
+        const u16* Bt = At + NPL * PLANE;
+#pragma unroll
+        for (int ms = 0; ms < MCH / 32; ++ms) {
+            u32x4 af[4], bf[4], afl[SPLIT ? 4 : 1], bfl[SPLIT ? 4 : 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = tr_frag(At, ms, wr * 64 + i * 16, g4, l15);
+                if constexpr (SPLIT) afl[i] = tr_frag(At + PLANE, ms, wr * 64 + i * 16, g4, l15);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf[j] = tr_frag(Bt, ms, wc * 64 + j * 16, g4, l15);
+                if constexpr (SPLIT) bfl[j] = tr_frag(Bt + PLANE, ms, wc * 64 + j * 16, g4, l15);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (SPLIT) {
+                        acc[i][j] = HT::mfma(bf[j], afl[i], acc[i][j]);
+                        acc[i][j] = HT::mfma(bfl[j], af[i], acc[i][j]);
+                    }
+                    acc[i][j] = HT::mfma(bf[j], af[i], acc[i][j]);
+                }
+        }
+        if (do_colsum) {
+#pragma unroll 8
+            for (int r = 0; r < MCH; ++r) {
+                csum += HT::to_f32(At[r * TN_STR + tid]);
+                if constexpr (SPLIT) csum += BF16::to_f32(At[PLANE + r * TN_STR + tid]);
+            }
+        }
+        // two buffers, one barrier per chunk: chunk ch+1 is stored into the other buffer, whose last readers (chunk ch-1) all passed
+        // the barrier above before anyone gets here
+        buf ^= 1;
+    }
+
+    // ---- epilogue: C[n][k..k+3] -----------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wr * 64 + i * 16 + l15;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wc * 64 + j * 16 + 4 * g4;
+            if (k >= g.K) continue;                  // K % 4 == 0: the 4 columns are valid together
+            float* c = g.C + (int64_t)n * g.ldc + k;
+            const f32x4 v = acc[i][j] * g.alpha;
+            if (g.atomic) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, v[r]);
+            } else {
+                *(f32x4*)c = v;
+            }
+        }
+    }
+    if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum + n0 + tid, csum * g.alpha);
+}
+
+template <typename HT, bool SPLIT, bool A32, bool B32>
+int launch_tn(const TnArgs& a, bool conv, int splits, hipStream_t s, const char* name) {
+    const int tiles = ((a.N + TN_BN - 1) / TN_BN) * ((a.K + TN_BK - 1) / TN_BK);
+    CfmProfScope prof(name, s, 2.0 * a.M * (double)a.N * a.K, (double)a.M * (a.N * (A32 ? 4 : 2) + a.K * (B32 ? 4 : 2)) + 4.0 * a.N * a.K);
+    const dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+    if (conv) CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, true>), grid, block, 0, s, a);
+    else CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, false>), grid, block, 0, s, a);
+    return cfm_launch_status(name);
+}
+
+}  // namespace
+
+extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
+    CFM_CHECK_ARG(d && d->A && d->B && d->C, "cfm_gemm_tn: null pointer");
+    CFM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "cfm_gemm_tn: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    CFM_CHECK_ARG(d->N % 8 == 0 && d->K % 8 == 0, "cfm_gemm_tn: N=%d and K=%d must be multiples of 8", d->N, d->K);
+    CFM_CHECK_ARG(d->mma_dtype == CFM_BF16 || d->mma_dtype == CFM_F16, "cfm_gemm_tn: mma_dtype must be bf16 or fp16");
+    CFM_CHECK_ARG(d->a_dtype == CFM_F32 || d->a_dtype == d->mma_dtype, "cfm_gemm_tn: a_dtype must be f32 or the MFMA type");
+    CFM_CHECK_ARG(d->b_dtype == CFM_F32 || d->b_dtype == d->mma_dtype, "cfm_gemm_tn: b_dtype must be f32 or the MFMA type");
+    CFM_CHECK_ARG(!d->split || (d->a_dtype == CFM_F32 && d->b_dtype == CFM_F32 && d->mma_dtype == CFM_BF16),
+                  "cfm_gemm_tn: split mode needs f32 operands and bf16 planes");
+    CFM_CHECK_ARG(d->lda % (d->a_dtype == CFM_F32 ? 4 : 8) == 0 && d->lda >= d->N, "cfm_gemm_tn: bad lda=%lld", (long long)d->lda);
+    CFM_CHECK_ARG(d->ldc % 4 == 0 && d->ldc >= d->K, "cfm_gemm_tn: bad ldc=%lld", (long long)d->ldc);
+    const bool conv = d->conv_C > 0;
+    if (conv) {
+        CFM_CHECK_ARG(d->conv_C % 8 == 0 && d->K == 9 * d->conv_C, "cfm_gemm_tn: conv needs C %% 8 == 0 and K == 9*C");
+        CFM_CHECK_ARG(d->conv_T2 == (d->conv_T1 - 3) / 2 + 1 && d->conv_F2 == (d->conv_F1 - 3) / 2 + 1 && d->conv_T2 > 0 && d->conv_F2 > 0,
+                      "cfm_gemm_tn: conv output shape does not match a 3x3 stride-2 convolution");
+        CFM_CHECK_ARG(d->M % (d->conv_T2 * d->conv_F2) == 0, "cfm_gemm_tn: conv M must be B*T2*F2");
+    } else {
+        CFM_CHECK_ARG(d->ldb % (d->b_dtype == CFM_F32 ? 4 : 8) == 0 && d->ldb >= d->K, "cfm_gemm_tn: bad ldb=%lld", (long long)d->ldb);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int mch = d->split ? 32 : 64;
+    const int chunks = (d->M + mch - 1) / mch;
+    const int tiles = ((d->N + TN_BN - 1) / TN_BN) * ((d->K + TN_BK - 1) / TN_BK);
+    int splits = d->splits;
+    if (splits <= 0) {                                      // ~2 workgroups per CU, at least 2 chunks per split
+        splits = (512 + tiles - 1) / tiles;
+        const int max_s = (chunks + 1) / 2;
+        splits = splits > max_s ? max_s : splits;
+    }
+    splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
+    TnArgs a;
+    a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum; a.mask = d->row_mask; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.alpha = d->alpha;
+    a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
+    a.chunks_per_split = (chunks + splits - 1) / splits;
+    splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;   // no empty split
+    a.atomic = (splits > 1 || d->accumulate) ? 1 : 0;
+    if (!d->accumulate) {
+        if (a.atomic && hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->K * 4, (size_t)d->N, s) != hipSuccess)
+            return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of C failed");
+        if (d->colsum && hipMemsetAsync(d->colsum, 0, (size_t)d->N * 4, s) != hipSuccess)
+            return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of colsum failed");
+    }
+    const bool a32 = d->a_dtype == CFM_F32, b32 = d->b_dtype == CFM_F32;
+    if (d->split) return launch_tn<BF16, true, true, true>(a, conv, splits, s, "gemm_tn_bf16x3");
+#define CFM_TN(HT, NAME)                                                                        \
+    do {                                                                                        \
+        if (a32 && b32) return launch_tn<HT, false, true, true>(a, conv, splits, s, NAME);      \
+        if (a32) return launch_tn<HT, false, true, false>(a, conv, splits, s, NAME);            \
+        if (b32) return launch_tn<HT, false, false, true>(a, conv, splits, s, NAME);            \
+        return launch_tn<HT, false, false, false>(a, conv, splits, s, NAME);                    \
+    } while (0)
+    if (d->mma_dtype == CFM_BF16) CFM_TN(BF16, "gemm_tn_bf16");
+    CFM_TN(F16, "gemm_tn_f16");
+#undef CFM_TN
+}

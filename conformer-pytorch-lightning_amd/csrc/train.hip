@@ -1,0 +1,646 @@
+// train.hip -- the HBM-bound half of the backward pass (config 3: encoder + CTC loss + backward).
+//
+//   cfm_layernorm_bwd        d LayerNorm (+ the residual branch's gradient) and its gain / bias gradients  (encoder_layer.py:56-70)
+//   cfm_glu_bwd              d GLU over the interleaved pointwise-conv-1 output                            (convolution.py:42)
+//   cfm_dwconv_bn_train      depthwise conv -> BatchNorm1d with BATCH statistics (all B*T rows, padded ones included: quirk Q6)
+//                            -> SiLU, running statistics updated as torch does                              (convolution.py:43-45)
+//   cfm_dwconv_bn_train_bwd  its backward: d SiLU, d BatchNorm (batch statistics), d depthwise conv (input, taps, bias)
+//   cfm_col2im_relu_bwd      scatter-free transpose of the 3x3 stride-2 im2col (a <= 4-term gather per element) * ReLU'
+//   cfm_conv1_wgrad          tap / bias gradients of the first convolution                                  (convolution.py:60-61)
+//   cfm_adam_step            fused clip-scale + Adam update over a flat parameter buffer                    (module.py:140-143, train.sh:35)
+//   cfm_sumsq                sum of squares of a flat buffer (the global gradient norm of gradient_clip_val, executor.py:150)
+//
+// Everything here is a streaming pass: one read of its inputs, one write of its outputs, reductions over the M = B*T' rows as
+// per-workgroup partials in a caller-provided f32 workspace followed by a fixed-order second stage (bitwise reproducible -- no
+// atomics).  The GEMM-shaped part of the backward is gemm.hip (input gradients) and gemm_tn.hip (weight gradients).
+#include "cfm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// loads / stores by dtype, 4 consecutive elements
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 load4(const void* base, int dt, int64_t off) {
+    if (dt == CFM_F32) return *(const f32x4*)((const float*)base + off);
+    const u32x2 r = *(const u32x2*)((const u16*)base + off);
+    if (dt == CFM_BF16)
+        return (f32x4){BF16::to_f32((u16)(r.x & 0xffffu)), BF16::to_f32((u16)(r.x >> 16)), BF16::to_f32((u16)(r.y & 0xffffu)), BF16::to_f32((u16)(r.y >> 16))};
+    return (f32x4){F16::to_f32((u16)(r.x & 0xffffu)), F16::to_f32((u16)(r.x >> 16)), F16::to_f32((u16)(r.y & 0xffffu)), F16::to_f32((u16)(r.y >> 16))};
+}
+__device__ __forceinline__ void store4(void* base, int dt, int64_t off, const f32x4& v) {
+    if (dt == CFM_F32) *(f32x4*)((float*)base + off) = v;
+    else if (dt == CFM_BF16) *(u32x2*)((u16*)base + off) = (u32x2){pack2<BF16>(v.x, v.y), pack2<BF16>(v.z, v.w)};
+    else *(u32x2*)((u16*)base + off) = (u32x2){pack2<F16>(v.x, v.y), pack2<F16>(v.z, v.w)};
+}
+__device__ __forceinline__ float dsilu_(float z) {
+    const float s = sigmoidf_(z);
+    return s * (1.f + z * (1.f - s));
+}
+
+// out_a[j] = alpha * sum_b part[b*J + j] for j < J1, out_b[j - J1] for the rest: the fixed-order second stage of every reduction here
+__global__ void cfm_reduce_partials_kernel(const float* __restrict__ part, int nblk, int J, int J1, float alpha, float* out_a, float* out_b) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    float s0 = 0.f, s1 = 0.f;                            // two chains: the loop is latency-bound otherwise
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) {
+        s0 += part[(int64_t)b * J + j];
+        s1 += part[(int64_t)(b + 1) * J + j];
+    }
+    if (b < nblk) s0 += part[(int64_t)b * J + j];
+    const float s = (s0 + s1) * alpha;
+    if (j < J1) out_a[j] = s;
+    else out_b[j - J1] = s;
+}
+
+int reduce_partials(const float* part, int nblk, int J, int J1, float alpha, float* out_a, float* out_b, hipStream_t s, const char* what) {
+    CfmProfScope prof("reduce_partials", s, 0.0, (double)nblk * J * 4);
+    CFM_LAUNCH(cfm_reduce_partials_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, s, part, nblk, J, J1, alpha, out_a, out_b);
+    return cfm_launch_status(what);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  One wavefront per row (as norm.hip), 32 rows per workgroup; the row statistics are recomputed from x.
+//   xhat = (x - mean) * rstd;  gy = gamma * dy;   dx = dres + rstd * (gy - mean_D(gy) - xhat * mean_D(gy * xhat))
+//   dgamma = sum_rows dy * xhat;  dbeta = sum_rows dy          (per-workgroup partials -> ws[blk][2][D])
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int LNB_ROWS = 32;
+
+template <int ITERS>
+__global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy, int dy_dt,
+                                                                const float* __restrict__ gamma, const uint8_t* __restrict__ mask,
+                                                                const float* dres, float* dx, float* __restrict__ ws, float eps, int64_t M, int D) {
+    __shared__ float red[4][2][ITERS * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[ITERS], db[ITERS], gm[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (lane + 64 * it) * 4;
+        dg[it] = db[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gm[it] = c < D ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float invD = 1.0f / (float)D;
+    for (int r = wave; r < LNB_ROWS; r += 4) {
+        const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + r;
+        if (row >= M) break;                               // wave-uniform
+        const bool keep = mask ? mask[row] != 0 : true;
+        f32x4 xv[ITERS], dv[ITERS];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            const bool in = c < D;
+            xv[it] = in ? *(const f32x4*)(x + row * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv[it] = (in && keep) ? load4(dy, dy_dt, row * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += (xv[it].x + xv[it].y) + (xv[it].z + xv[it].w);
+        }
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < D) {
+                const f32x4 d = xv[it] - mean;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < D) {
+                xv[it] = (xv[it] - mean) * rstd;           // xhat
+                const f32x4 gy = gm[it] * dv[it];
+                a += (gy.x + gy.y) + (gy.z + gy.w);
+                const f32x4 t = gy * xv[it];
+                b += (t.x + t.y) + (t.z + t.w);
+                dg[it] += dv[it] * xv[it];
+                db[it] += dv[it];
+            }
+        }
+        const float m1 = wave_sum(a) * invD, m2 = wave_sum(b) * invD;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < D) {
+                f32x4 o = (gm[it] * dv[it] - m1 - xv[it] * m2) * rstd;
+                if (dres) o += *(const f32x4*)(dres + row * D + c);
+                *(f32x4*)(dx + row * D + c) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (lane + 64 * it) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][0][c + e] = dg[it][e];
+            red[wave][1][c + e] = db[it][e];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * D; j += 256) {
+        const int which = j / D, c = j - which * D;
+        ws[((int64_t)blockIdx.x * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// GLU backward on the interleaved layout of the pointwise-conv-1 GEMM (column blk*32 + half*16 + i <-> output column blk*16 + i)
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void cfm_glu_bwd_kernel(const void* __restrict__ u, int u_dt, const void* __restrict__ dg, int dg_dt, void* __restrict__ du, int du_dt,
+                                   int64_t M, int D) {
+    const int qpr = D / 4;                                  // 4-column groups per output row
+    const int64_t n = M * qpr;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = id / qpr;
+        const int oc = (int)(id - row * qpr) * 4;           // output column
+        const int blk = oc >> 4, i = oc & 15;
+        const int64_t ua = row * 2 * D + blk * 32 + i;
+        const f32x4 a = load4(u, u_dt, ua), gt = load4(u, u_dt, ua + 16), d = load4(dg, dg_dt, row * D + oc);
+        f32x4 da, dgt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = sigmoidf_(gt[e]);
+            da[e] = d[e] * sg;
+            dgt[e] = d[e] * a[e] * sg * (1.f - sg);
+        }
+        store4(du, du_dt, ua, da);
+        store4(du, du_dt, ua + 16, dgt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// depthwise conv + BatchNorm (batch statistics) + SiLU, forward and backward.  Workgroup = (16 frames, one utterance), thread =
+// channel (two when D > 256); a 16 + k - 1 frame window per channel lives in registers.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int DWT = 16;
+constexpr int DWK = 15;                                     // taps (the only kernel size on the path, encoder.py:38 kernel_size=15)
+constexpr int DWW = DWT + DWK - 1;
+
+__global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __restrict__ g, int g_dt, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ c_out, float* __restrict__ ws, int T, int D) {
+    const int b = blockIdx.y, t0 = blockIdx.x * DWT;
+    const int nblk_t = gridDim.x;
+    const int64_t ub = (int64_t)b * T * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float win[DWW], wk[DWK];
+#pragma unroll
+        for (int i = 0; i < DWW; ++i) {
+            const int t = t0 - (DWK - 1) / 2 + i;
+            win[i] = (t >= 0 && t < T) ? load_as_f32(g, ub + (int64_t)t * D + c, g_dt) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) wk[k] = w[c * DWK + k];
+        const float bs = bias[c];
+        float mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < DWT; ++j) {
+            const int t = t0 + j;
+            if (t < T) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < DWK; ++k) a = fmaf(wk[k], win[j + k], a);
+                a += bs;
+                c_out[ub + (int64_t)t * D + c] = a;
+                const float dlt = a - mean;                 // Welford
+                mean += dlt / (float)(j + 1);
+                m2 += dlt * (a - mean);
+            }
+        }
+        const int64_t blk = (int64_t)b * nblk_t + blockIdx.x;
+        ws[(blk * 2 + 0) * D + c] = mean;
+        ws[(blk * 2 + 1) * D + c] = m2;
+    }
+}
+
+// stats[0..3][D] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running statistics updated (torch: unbiased variance)
+__global__ void cfm_bn_finalize_kernel(const float* __restrict__ ws, int nblk_t, int B, int T, int D, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+                                       float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;                   // Chan's pairwise combination, fixed order
+    for (int b = 0; b < B; ++b)
+        for (int tb = 0; tb < nblk_t; ++tb) {
+            const int64_t blk = (int64_t)b * nblk_t + tb;
+            const double nb = (double)min(DWT, T - tb * DWT);
+            const double mb = ws[(blk * 2 + 0) * D + c], qb = ws[(blk * 2 + 1) * D + c];
+            const double d = mb - mean, nn = n + nb;
+            mean += d * nb / nn;
+            m2 += qb + d * d * n * nb / nn;
+            n = nn;
+        }
+    const double var = m2 / n;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    stats[c] = (float)mean;
+    stats[D + c] = rstd;
+    stats[2 * D + c] = sc;
+    stats[3 * D + c] = beta[c] - (float)mean * sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
+}
+
+__global__ void cfm_bn_silu_apply_kernel(const float* __restrict__ c, const float* __restrict__ stats, void* __restrict__ out, int out_dt, int64_t M, int D) {
+    const int qpr = D / 4;
+    const int64_t n = M * qpr;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(id % qpr) * 4;
+        const f32x4 v = *(const f32x4*)(c + id * 4), sc = *(const f32x4*)(stats + 2 * D + col), sh = *(const f32x4*)(stats + 3 * D + col);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = siluf_(v[e] * sc[e] + sh[e]);
+        store4(out, out_dt, id * 4, o);
+    }
+}
+
+// dy = ds * silu'(c*scale + shift) -> dy_out (f32); per-workgroup sums over 64 rows of dy and dy * chat -> ws[blk][2][D]
+constexpr int BNB_ROWS = 64;
+__global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __restrict__ ds, int ds_dt, const float* __restrict__ c, const float* __restrict__ stats,
+                                                              float* __restrict__ dy_out, float* __restrict__ ws, int64_t M, int D) {
+    const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
+    for (int ch = threadIdx.x; ch < D; ch += 256) {
+        const float mean = stats[ch], rstd = stats[D + ch], sc = stats[2 * D + ch], sh = stats[3 * D + ch];
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < BNB_ROWS; ++r) {
+            const int64_t row = r0 + r;
+            if (row >= M) break;
+            const float cv = c[row * D + ch];
+            const float dyv = load_as_f32(ds, row * D + ch, ds_dt) * dsilu_(cv * sc + sh);
+            dy_out[row * D + ch] = dyv;
+            s1 += dyv;
+            s2 += dyv * ((cv - mean) * rstd);
+        }
+        ws[((int64_t)blockIdx.x * 2 + 0) * D + ch] = s1;
+        ws[((int64_t)blockIdx.x * 2 + 1) * D + ch] = s2;
+    }
+}
+
+// dc = gamma*rstd * (dy - k1 - chat*k2), then the depthwise conv's backward: dg[t] = sum_k w[k] dc[t-k+7] and per-workgroup partials of
+// dw[k] = sum dc[t] g[t+k-7], db = sum dc  -> ws[blk][16][D]
+__global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ c, const float* __restrict__ stats,
+                                                             const float* __restrict__ coef, const void* __restrict__ g, int g_dt,
+                                                             const float* __restrict__ w, void* __restrict__ dg_out, int dg_dt, float* __restrict__ ws,
+                                                             int T, int D) {
+    const int b = blockIdx.y, t0 = blockIdx.x * DWT;
+    const int64_t ub = (int64_t)b * T * D;
+    const int64_t blk = (int64_t)b * gridDim.x + blockIdx.x;
+    for (int ch = threadIdx.x; ch < D; ch += 256) {
+        const float mean = stats[ch], rstd = stats[D + ch], sc = stats[2 * D + ch];       // sc = gamma * rstd
+        const float k1 = coef[ch], k2 = coef[D + ch];
+        float dcw[DWW], gw[DWW], wk[DWK];
+#pragma unroll
+        for (int i = 0; i < DWW; ++i) {
+            const int t = t0 - (DWK - 1) / 2 + i;
+            const bool in = t >= 0 && t < T;
+            const int64_t o = ub + (int64_t)(in ? t : 0) * D + ch;
+            const float chat = (c[o] - mean) * rstd;
+            dcw[i] = in ? sc * (dy[o] - k1 - chat * k2) : 0.f;
+            gw[i] = in ? load_as_f32(g, o, g_dt) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) wk[k] = w[ch * DWK + k];
+#pragma unroll
+        for (int j = 0; j < DWT; ++j) {
+            const int t = t0 + j;
+            if (t < T) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < DWK; ++k) a = fmaf(wk[k], dcw[j + DWK - 1 - k], a);
+                store_from_f32(dg_out, ub + (int64_t)t * D + ch, dg_dt, a);
+            }
+        }
+        float db = 0.f;
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < DWT; ++j) a = fmaf(dcw[j + (DWK - 1) / 2], gw[j + k], a);   // frames past T have dc = 0
+            ws[(blk * 16 + k) * D + ch] = a;
+        }
+#pragma unroll
+        for (int j = 0; j < DWT; ++j) db += dcw[j + (DWK - 1) / 2];
+        ws[(blk * 16 + 15) * D + ch] = db;
+    }
+}
+
+// second stage of the BatchNorm backward sums: dbeta = S1, dgamma = S2, coef = (S1/N, S2/N)
+__global__ void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, double inv_n, float* dgamma, float* dbeta, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += ws[((int64_t)b * 2 + 0) * D + c];
+        s2 += ws[((int64_t)b * 2 + 1) * D + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 * inv_n);
+    coef[D + c] = (float)(s2 * inv_n);
+}
+
+// second stage of the depthwise gradients: dw_w[c][k] (the layout of depthwise_conv.weight (D,1,K)) and dw_b[c]
+__global__ void cfm_dwconv_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, float* dw_w, float* dw_b) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 16 * D) return;
+    const int slot = id / D, c = id - slot * D;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) {
+        s0 += ws[((int64_t)b * 16 + slot) * D + c];
+        s1 += ws[((int64_t)(b + 1) * 16 + slot) * D + c];
+    }
+    if (b < nblk) s0 += ws[((int64_t)b * 16 + slot) * D + c];
+    if (slot < DWK) dw_w[c * DWK + slot] = s0 + s1;
+    else dw_b[c] = s0 + s1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// front-end backward helpers
+// ------------------------------------------------------------------------------------------------------------------------------
+// dh1[b,t1,f1,c] = (h1 > 0) * sum_{kt,kf : (t1-kt), (f1-kf) even and in range} dcol[(b,(t1-kt)/2,(f1-kf)/2), (kt*3+kf)*C + c]
+// -- the transpose of the 3x3 stride-2 im2col as a gather (<= 4 terms), 8 channels per thread
+__global__ void cfm_col2im_relu_bwd_kernel(const void* __restrict__ dcol, int dc_dt, const void* __restrict__ h1, int h_dt, void* __restrict__ dh1, int o_dt,
+                                           int B, int T1, int F1, int T2, int F2, int C) {
+    const int c4n = C / 4;
+    const int64_t n = (int64_t)B * T1 * F1 * c4n;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(id % c4n) * 4;
+        int64_t r = id / c4n;
+        const int f1 = (int)(r % F1);
+        r /= F1;
+        const int t1 = (int)(r % T1);
+        const int b = (int)(r / T1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const int tt = t1 - kt;
+            if (tt < 0 || (tt & 1) || (tt >> 1) >= T2) continue;
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) {
+                const int ff = f1 - kf;
+                if (ff < 0 || (ff & 1) || (ff >> 1) >= F2) continue;
+                const int64_t m = ((int64_t)b * T2 + (tt >> 1)) * F2 + (ff >> 1);
+                acc += load4(dcol, dc_dt, m * (9 * (int64_t)C) + (kt * 3 + kf) * C + c);
+            }
+        }
+        const f32x4 hv = load4(h1, h_dt, id * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = hv[e] > 0.f ? acc[e] : 0.f;
+        store4(dh1, o_dt, id * 4, acc);
+    }
+}
+
+// first convolution: dw1[tap][c] = sum_{b,t1,f1} dh1[b,t1,f1,c] * xin[b,2t1+kt,2f1+kf], db1[c] = sum dh1 -- workgroup = (8 output rows t1 of
+// one utterance), thread = channel; the 3 input rows of each t1 go through LDS (every thread reads the same taps)
+constexpr int C1_TB = 8;
+__global__ __launch_bounds__(256) void cfm_conv1_wgrad_kernel(const void* __restrict__ dh1, int d_dt, const float* __restrict__ x, const float* __restrict__ cm,
+                                                              const float* __restrict__ ci, float* __restrict__ ws, int T, int F, int T1, int F1, int C) {
+    extern __shared__ float xr[];                           // [3][F]
+    const int b = blockIdx.y, tb = blockIdx.x * C1_TB;
+    const int64_t blk = (int64_t)b * gridDim.x + blockIdx.x;
+    float acc0[10], acc1[10];                               // channels tid and tid + 256 (C <= 512)
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc0[i] = acc1[i] = 0.f;
+    for (int dt = 0; dt < C1_TB; ++dt) {
+        const int t1 = tb + dt;
+        if (t1 >= T1) break;                                // uniform
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * F; i += 256) {
+            const int rr = i / F, f = i - rr * F;
+            float v = x[((int64_t)b * T + 2 * t1 + rr) * F + f];
+            if (cm) v -= cm[f];                             // global CMVN folded into the first convolution (cmvn.py:22-33)
+            if (ci) v *= ci[f];
+            xr[i] = v;
+        }
+        __syncthreads();
+        for (int f1 = 0; f1 < F1; ++f1) {
+            float taps[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) taps[k] = xr[(k / 3) * F + 2 * f1 + (k % 3)];
+            const int64_t o = (((int64_t)b * T1 + t1) * F1 + f1) * C;
+            if ((int)threadIdx.x < C) {
+                const float d = load_as_f32(dh1, o + threadIdx.x, d_dt);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc0[k] = fmaf(d, taps[k], acc0[k]);
+                acc0[9] += d;
+            }
+            if ((int)threadIdx.x + 256 < C) {
+                const float d = load_as_f32(dh1, o + threadIdx.x + 256, d_dt);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc1[k] = fmaf(d, taps[k], acc1[k]);
+                acc1[9] += d;
+            }
+        }
+    }
+    if ((int)threadIdx.x < C)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) ws[(blk * 10 + k) * C + threadIdx.x] = acc0[k];
+    if ((int)threadIdx.x + 256 < C)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) ws[(blk * 10 + k) * C + threadIdx.x + 256] = acc1[k];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// optimizer: Adam over flat buffers with the clip coefficient read from device memory (no host sync between backward and step)
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void cfm_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                float b1, float b2, float eps, float weight_decay, float bc1, float bc2_sqrt, const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.f;
+    const int64_t n4 = n / 4;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n4; id += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pv = *(const f32x4*)(p + id * 4), gv = *(const f32x4*)(g + id * 4) * gs, mv = *(const f32x4*)(m + id * 4), vv = *(const f32x4*)(v + id * 4);
+        gv += pv * weight_decay;
+        mv = mv * b1 + gv * (1.f - b1);
+        vv = vv * b2 + gv * gv * (1.f - b2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[e] -= (lr / bc1) * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+        *(f32x4*)(p + id * 4) = pv;
+        *(f32x4*)(m + id * 4) = mv;
+        *(f32x4*)(v + id * 4) = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {         // tail
+        const int64_t i = n4 * 4 + threadIdx.x;
+        const float gq = g[i] * gs + p[i] * weight_decay;
+        const float mq = m[i] * b1 + gq * (1.f - b1), vq = v[i] * b2 + gq * gq * (1.f - b2);
+        p[i] -= (lr / bc1) * mq / (sqrtf(vq) / bc2_sqrt + eps);
+        m[i] = mq;
+        v[i] = vq;
+    }
+}
+
+__global__ __launch_bounds__(256) void cfm_sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n4; id += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(x + id * 4);
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = x[n4 * 4 + threadIdx.x];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
+    int64_t b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+// ================================================================================================================================
+extern "C" int64_t cfm_layernorm_bwd_ws(int64_t M, int32_t D) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * (int64_t)D; }
+
+extern "C" int cfm_layernorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres,
+                                 float* dx, float* dgamma, float* dbeta, float* ws, float eps, int64_t M, int32_t D, cfm_stream_t stream) {
+    CFM_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && ws, "cfm_layernorm_bwd: null pointer");
+    CFM_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "cfm_layernorm_bwd: need D %% 4 == 0 and D <= 1024 (M=%lld D=%d)", (long long)M, D);
+    CFM_CHECK_ARG(dy_dtype >= CFM_F32 && dy_dtype <= CFM_F16, "cfm_layernorm_bwd: bad dy dtype");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)((M + LNB_ROWS - 1) / LNB_ROWS);
+    {
+        CfmProfScope prof("layernorm_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(dy_dtype) + (dres ? 4 : 0)));
+        const dim3 grid((unsigned)nblk), block(256);
+        if (D <= 256) CFM_LAUNCH((cfm_layernorm_bwd_kernel<1>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D);
+        else if (D <= 512) CFM_LAUNCH((cfm_layernorm_bwd_kernel<2>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D);
+        else CFM_LAUNCH((cfm_layernorm_bwd_kernel<4>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D);
+        if (int rc = cfm_launch_status("cfm_layernorm_bwd")) return rc;
+    }
+    return reduce_partials(ws, nblk, 2 * D, D, 1.0f, dgamma, dbeta, s, "cfm_layernorm_bwd (reduce)");
+}
+
+extern "C" int cfm_glu_bwd(const void* u, int32_t u_dtype, const void* dg, int32_t dg_dtype, void* du, int32_t du_dtype, int64_t M, int32_t D,
+                           cfm_stream_t stream) {
+    CFM_CHECK_ARG(u && dg && du, "cfm_glu_bwd: null pointer");
+    CFM_CHECK_ARG(M > 0 && D > 0 && D % 16 == 0, "cfm_glu_bwd: need D %% 16 == 0 (M=%lld D=%d)", (long long)M, D);
+    hipStream_t s = (hipStream_t)stream;
+    CfmProfScope prof("glu_bwd", s, 0.0, (double)M * D * (2.0 * cfm_elt_size(u_dtype) + cfm_elt_size(dg_dtype) + 2.0 * cfm_elt_size(du_dtype)));
+    CFM_LAUNCH(cfm_glu_bwd_kernel, dim3((unsigned)grid_for(M * (D / 4))), dim3(256), 0, s, u, u_dtype, dg, dg_dtype, du, du_dtype, M, D);
+    return cfm_launch_status("cfm_glu_bwd");
+}
+
+extern "C" int64_t cfm_dwconv_bn_ws(int32_t B, int32_t T, int32_t D) {     // floats: enough for the forward and for the backward
+    const int64_t nblk_t = (T + DWT - 1) / DWT;
+    // backward: BatchNorm sums [nb][2][D] | coef [2][D] | depthwise partials [B*nblk_t][16][D]   (forward: [B*nblk_t][2][D])
+    return (((int64_t)B * T + BNB_ROWS - 1) / BNB_ROWS) * 2 * D + 2 * (int64_t)D + (int64_t)B * nblk_t * 16 * D;
+}
+
+extern "C" int cfm_dwconv_bn_train(const void* g, int32_t g_dtype, const float* w, const float* dw_bias, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* c_out, float* stats, void* s_out,
+                                   int32_t s_dtype, float* ws, int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream) {
+    CFM_CHECK_ARG(g && w && dw_bias && gamma && beta && c_out && stats && s_out && ws, "cfm_dwconv_bn_train: null pointer");
+    CFM_CHECK_ARG(ktaps == DWK, "cfm_dwconv_bn_train: %d taps (only %d is built: the conformer's kernel_size)", ktaps, DWK);
+    CFM_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 512 && B <= 65535, "cfm_dwconv_bn_train: need D %% 4 == 0, D <= 512 (B=%d T=%d D=%d)", B, T, D);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk_t = (T + DWT - 1) / DWT;
+    const int64_t M = (int64_t)B * T;
+    {
+        CfmProfScope prof("dwconv_stats", s, 2.0 * M * D * DWK, (double)M * D * (cfm_elt_size(g_dtype) + 4.0));
+        CFM_LAUNCH(cfm_dwconv_stats_kernel, dim3((unsigned)nblk_t, (unsigned)B), dim3(256), 0, s, g, g_dtype, w, dw_bias, c_out, ws, T, D);
+        if (int rc = cfm_launch_status("cfm_dwconv_bn_train (conv)")) return rc;
+    }
+    {
+        CfmProfScope prof("bn_finalize", s, 0.0, (double)B * nblk_t * 2 * D * 4);
+        CFM_LAUNCH(cfm_bn_finalize_kernel, dim3((unsigned)((D + 63) / 64)), dim3(64), 0, s, (const float*)ws, nblk_t, B, T, D, gamma, beta, running_mean,
+                   running_var, momentum, eps, stats);
+        if (int rc = cfm_launch_status("cfm_dwconv_bn_train (finalize)")) return rc;
+    }
+    CfmProfScope prof("bn_silu_apply", s, 0.0, (double)M * D * (4.0 + cfm_elt_size(s_dtype)));
+    CFM_LAUNCH(cfm_bn_silu_apply_kernel, dim3((unsigned)grid_for(M * (D / 4))), dim3(256), 0, s, (const float*)c_out, (const float*)stats, s_out, s_dtype, M, D);
+    return cfm_launch_status("cfm_dwconv_bn_train (apply)");
+}
+
+extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
+                                       void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
+                                       int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream) {
+    CFM_CHECK_ARG(ds && c && stats && g && w && dg_out && dw_w && dw_b && dgamma && dbeta && dy_ws && ws, "cfm_dwconv_bn_train_bwd: null pointer");
+    CFM_CHECK_ARG(ktaps == DWK, "cfm_dwconv_bn_train_bwd: %d taps (only %d is built)", ktaps, DWK);
+    CFM_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 512 && B <= 65535, "cfm_dwconv_bn_train_bwd: need D %% 4 == 0, D <= 512 (B=%d T=%d D=%d)", B, T, D);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * T;
+    const int nb = (int)((M + BNB_ROWS - 1) / BNB_ROWS);
+    float* coef = ws + (int64_t)nb * 2 * D;                                 // [2][D] behind the BatchNorm partials
+    {
+        CfmProfScope prof("bn_silu_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(ds_dtype)));
+        CFM_LAUNCH(cfm_bn_silu_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, ds, ds_dtype, c, stats, dy_ws, ws, M, D);
+        if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (silu/bn sums)")) return rc;
+    }
+    {
+        CfmProfScope prof("bn_bwd_finalize", s, 0.0, (double)nb * 2 * D * 4);
+        CFM_LAUNCH(cfm_bn_bwd_finalize_kernel, dim3((unsigned)((D + 63) / 64)), dim3(64), 0, s, (const float*)ws, nb, D, 1.0 / (double)M, dgamma, dbeta, coef);
+        if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (finalize)")) return rc;
+    }
+    const int nblk_t = (T + DWT - 1) / DWT;
+    float* part = coef + 2 * (int64_t)D;                                    // depthwise partials [blk][16][D] behind coef
+    {
+        CfmProfScope prof("dwconv_bwd", s, 4.0 * M * D * DWK, (double)M * D * (8.0 + cfm_elt_size(g_dtype) + cfm_elt_size(dg_dtype)));
+        CFM_LAUNCH(cfm_dwconv_bwd_kernel, dim3((unsigned)nblk_t, (unsigned)B), dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, g_dtype, w,
+                   dg_out, dg_dtype, part, T, D);
+        if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (conv)")) return rc;
+    }
+    CfmProfScope prof("dwconv_bwd_finalize", s, 0.0, (double)B * nblk_t * 16 * D * 4);
+    CFM_LAUNCH(cfm_dwconv_bwd_finalize_kernel, dim3((unsigned)((16 * D + 255) / 256)), dim3(256), 0, s, (const float*)part, B * nblk_t, D, dw_w, dw_b);
+    return cfm_launch_status("cfm_dwconv_bn_train_bwd (reduce)");
+}
+
+extern "C" int cfm_col2im_relu_bwd(const void* dcol, int32_t dcol_dtype, const void* h1, int32_t h1_dtype, void* dh1, int32_t dh1_dtype, int32_t B, int32_t T1,
+                                   int32_t F1, int32_t C, cfm_stream_t stream) {
+    CFM_CHECK_ARG(dcol && h1 && dh1, "cfm_col2im_relu_bwd: null pointer");
+    CFM_CHECK_ARG(B > 0 && T1 >= 3 && F1 >= 3 && C > 0 && C % 4 == 0, "cfm_col2im_relu_bwd: bad shape B=%d T1=%d F1=%d C=%d", B, T1, F1, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+    const int64_t n = (int64_t)B * T1 * F1 * (C / 4);
+    CfmProfScope prof("col2im_relu_bwd", s, 0.0, (double)B * T2 * F2 * 9 * C * cfm_elt_size(dcol_dtype) + (double)n * 4 * (cfm_elt_size(h1_dtype) + cfm_elt_size(dh1_dtype)));
+    CFM_LAUNCH(cfm_col2im_relu_bwd_kernel, dim3((unsigned)grid_for(n, 256, 16384)), dim3(256), 0, s, dcol, dcol_dtype, h1, h1_dtype, dh1, dh1_dtype, B, T1, F1, T2, F2, C);
+    return cfm_launch_status("cfm_col2im_relu_bwd");
+}
+
+extern "C" int64_t cfm_conv1_wgrad_ws(int32_t B, int32_t T, int32_t C) {
+    const int T1 = (T - 3) / 2 + 1;
+    return (int64_t)B * ((T1 + C1_TB - 1) / C1_TB) * 10 * C;
+}
+
+extern "C" int cfm_conv1_wgrad(const void* dh1, int32_t dh1_dtype, const float* x, const float* cmvn_mean, const float* cmvn_istd, float* dw, float* db, float* ws,
+                               int32_t B, int32_t T, int32_t F, int32_t C, cfm_stream_t stream) {
+    CFM_CHECK_ARG(dh1 && x && dw && db && ws, "cfm_conv1_wgrad: null pointer");
+    CFM_CHECK_ARG(B > 0 && T >= 3 && F >= 3 && C > 0 && C <= 512 && B <= 65535 && F <= 4096, "cfm_conv1_wgrad: bad shape B=%d T=%d F=%d C=%d", B, T, F, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const int nbt = (T1 + C1_TB - 1) / C1_TB;
+    {
+        CfmProfScope prof("conv1_wgrad", s, 20.0 * B * T1 * F1 * C, (double)B * T1 * F1 * C * cfm_elt_size(dh1_dtype));
+        CFM_LAUNCH(cfm_conv1_wgrad_kernel, dim3((unsigned)nbt, (unsigned)B), dim3(256), (size_t)3 * F * 4, s, dh1, dh1_dtype, x, cmvn_mean, cmvn_istd, ws, T, F, T1, F1, C);
+        if (int rc = cfm_launch_status("cfm_conv1_wgrad")) return rc;
+    }
+    return reduce_partials(ws, B * nbt, 10 * C, 9 * C, 1.0f, dw, db, s, "cfm_conv1_wgrad (reduce)");     // dw [9][C] tap-major (the packed layout), db [C]
+}
+
+extern "C" int cfm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int64_t step, const float* grad_scale, cfm_stream_t stream) {
+    CFM_CHECK_ARG(p && g && m && v && n > 0 && step > 0, "cfm_adam_step: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    CfmProfScope prof("adam_step", s, 0.0, (double)n * 28);
+    CFM_LAUNCH(cfm_adam_kernel, dim3((unsigned)grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
+               grad_scale);
+    return cfm_launch_status("cfm_adam_step");
+}
+
+extern "C" int cfm_sumsq(const float* x, int64_t n, float* partials, int32_t n_partials, float* out, cfm_stream_t stream) {
+    CFM_CHECK_ARG(x && partials && out && n > 0 && n_partials > 0 && n_partials <= 4096, "cfm_sumsq: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        CfmProfScope prof("sumsq", s, 0.0, (double)n * 4);
+        CFM_LAUNCH(cfm_sumsq_kernel, dim3((unsigned)n_partials), dim3(256), 0, s, x, n, partials);
+        if (int rc = cfm_launch_status("cfm_sumsq")) return rc;
+    }
+    return reduce_partials(partials, n_partials, 1, 1, 1.0f, out, out, s, "cfm_sumsq (reduce)");
+}

@@ -5,8 +5,9 @@
 
 Same constructor arguments and parameter names (`ctc_lo.weight`, `ctc_lo.bias`) as the reference.  Quirk Q7 is kept: the reference
 calls F.dropout with its default training=True, i.e. it drops activations even in eval mode; with dropout > 0 this module does the same
-(and is then as random as the reference), parity is defined and tested at dropout = 0.  No backward: calling it with gradients enabled
-on parameters that require them raises.
+(and is then as random as the reference), parity is defined and tested at dropout = 0.  In train mode `forward` is differentiable
+(cfm/autograd.py CTCLossFn: the beta recursion and d loss / d logits in csrc/ctc.hip, the projection's gradients through cfm_gemm /
+cfm_gemm_tn); `nll` is loss evaluation only.
 """
 import torch
 import torch.nn as nn
@@ -36,11 +37,9 @@ class CTCDecoder(nn.Module):
         return self._pack.get([self.ctc_lo.weight, self.ctc_lo.bias], prec, build)
 
     def nll(self, encoder_out, encoder_out_lens, padded_labels, label_lengths):
-        """Per-utterance CTC negative log-likelihood, f32 [B]."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("CTCDecoder: backward is not built yet (forward / loss evaluation only)")
+        """Per-utterance CTC negative log-likelihood, f32 [B] (loss evaluation: not differentiable -- use forward in train mode)."""
         cfm.require_hip(encoder_out)
-        prec = cfm.get_precision()
+        prec = cfm.resolve_precision(self)
         pk = self._weights(prec)
         x = nn.functional.dropout(encoder_out, self.dropout)      # training=True by default, as decoder.py:19 (quirk Q7)
         B, T, D = x.shape
@@ -51,5 +50,14 @@ class CTCDecoder(nn.Module):
         return cfm.ctc_nll(logits, pk.V, i32(encoder_out_lens), i32(padded_labels), i32(label_lengths))
 
     def forward(self, encoder_out, encoder_out_lens, padded_labels, label_lengths):
+        if self.training:
+            # differentiable path (cfm/autograd.py CTCLossFn): projection, alpha AND beta recursions, gradients for ctc_lo and the encoder
+            from cfm import autograd as ag
+            cfm.require_hip(encoder_out)
+            dev = encoder_out.device
+            i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+            x = nn.functional.dropout(encoder_out, self.dropout)          # training=True by default, as decoder.py:19 (quirk Q7); a torch op
+            return ag.CTCLossFn.apply(x, self, cfm.resolve_precision(self), i32(encoder_out_lens), i32(padded_labels), i32(label_lengths),
+                                      self.ctc_lo.weight, self.ctc_lo.bias)
         loss = self.nll(encoder_out, encoder_out_lens, padded_labels, label_lengths).sum()
         return loss / padded_labels.size(1)

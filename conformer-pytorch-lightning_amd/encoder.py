@@ -51,7 +51,7 @@ class ConformerEncoder(nn.Module):
         bufs = [torch.empty_like(x), torch.empty_like(x)]
         new_caches = [] if caches is not None else None
         cur, ready = x, False
-        prec = cfm.get_precision()
+        prec = cfm.resolve_precision(self)
         handover = (self.encoders[0]._use_partial_ffn and cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
                     bool(cfm.lib().cfm_ffn_partial_supported(self.encoder_dim, self.encoders[0].hidden_dim)))
         pending = None
@@ -102,7 +102,7 @@ class ConformerEncoder(nn.Module):
         if not isinstance(self.position_encoding, RelativePositionalEncoding) or pos_embed is None:
             return None
         from cfm import packing
-        prec = cfm.get_precision()
+        prec = cfm.resolve_precision(self)
         ws = [blk.self_attn.linear_pos.weight for blk in self.encoders]
         if not hasattr(self, "_pos_pack"):
             self._pos_pack = packing.PackCache()
@@ -111,12 +111,30 @@ class ConformerEncoder(nn.Module):
         pe = (pe if pe.dtype == torch.float32 else pe.float()).contiguous()
         return cfm.gemm(pe, pk.w[0], w_lo=pk.w[1], out_dtype=prec.act_dtype)
 
+    def set_precision(self, name):
+        """Pin this encoder (every drop-in module under it) to a precision mode, independent of the process default
+        (cfm.set_precision): 'bf16' | 'fp16' | 'fp32' | None (follow the default again)."""
+        prec = None if name is None else (name if isinstance(name, cfm.Precision) else cfm.Precision(name))
+        for m in self.modules():
+            m.precision = prec
+        return self
+
     def forward(self, inputs, input_lengths, decoding_chunk_size=0, num_decoding_chunk_size=-1):
         inputs, cmvn = self._cmvn_args(inputs)
         cfm.require_hip(inputs, input_lengths)
         frames = inputs.size(1)
         x = self.embed.embed_frames(inputs, cmvn)
         x, pos_embed = self.position_encoding(x, 0)
+        if self.training:
+            # train mode (encoder.py:54-75 under module.train()): the same driver over the modules' autograd paths
+            from cfm import autograd as ag
+            pad_mask = cfm.valid_mask(input_lengths, x.size(1), first=6, stride=4).unsqueeze(1)
+            attn_mask = make_attn_mask(x, pad_mask, self.use_dynamic_chunk_size, self.use_dynamic_left_chunk,
+                                       decoding_chunk_size, self.static_chunk_size, num_decoding_chunk_size)
+            for block in self.encoders:
+                x, attn_mask, _, _ = block(x, attn_mask, pos_embed, pad_mask)
+            y = ag.LayerNormFn.apply(x, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+            return y.to(inputs.dtype), pad_mask
         # (~make_pad_mask(len, T))[:, None, :][:, :, 2::2][:, :, 2::2]  ==  (6 + 4 j < len), built in one launch
         pad_mask = cfm.valid_mask(input_lengths, x.size(1), first=6, stride=4).unsqueeze(1)
         # (Tried: positional projection + mask on a side stream beside the front-end.  Under graph replay the fork/join costs more
@@ -127,6 +145,8 @@ class ConformerEncoder(nn.Module):
         return y.to(inputs.dtype), pad_mask
 
     def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None):
+        if self.training:
+            raise NotImplementedError("ConformerEncoder.forward_chunk: streaming is inference-only; call .eval()")
         """One streaming step.  Batch 1 as in the reference: attn_cache (L,H,Tc,2dk) or empty; returns (chunk output, new attn
         cache (L,H,Tc',2dk), cnn cache (L,0,0,0) -- the reference keeps no conv context).
         Batch B > 1 (beyond the reference, whose forward_chunk only works at batch 1: SURVEY 8 row S): B streams in lockstep at

@@ -47,11 +47,9 @@ class ConformerEncoderLayer(nn.Module):
         # 32-row chain kernels at config 2, so it is opt-in: CFM_PARTIAL_FFN=1.
         self._use_partial_ffn = os.environ.get("CFM_PARTIAL_FFN", "0") == "1"
         self._fused = None                 # (key, LayerWeights, keepalive)
-        self._plist = None
 
     def _apply(self, fn, *a, **kw):        # .to() / .cuda() / .half(): drop every packed copy
         self._fused = None
-        self._plist = None
         return super()._apply(fn, *a, **kw)
 
     def pending_handover(self, prec):
@@ -59,9 +57,10 @@ class ConformerEncoderLayer(nn.Module):
         return packing.pack_ffn(self.feed_forward, prec).b2, self.norm_final
 
     def _weights(self, prec):
-        if self._plist is None:
-            self._plist = [t for t in list(self.parameters()) + list(self.buffers())]
-        key = (prec.name,) + tuple((t.data_ptr(), t._version) for t in self._plist)   # in-place updates bump _version; `p.data = ...` moves the pointer
+        # the tensor list is rebuilt on every call: replacing a Parameter OBJECT (layer.norm_ff.weight = nn.Parameter(...), pruning /
+        # reparametrisation, swapping a submodule) must change the key too; walking ~60 tensors is cheap next to a 5-launch block
+        plist = list(self.parameters()) + list(self.buffers())
+        key = (prec.name, packing._EPOCH[0]) + tuple((t.data_ptr(), t._version) for t in plist)   # in-place updates bump _version; `p.data = ...` moves the pointer
         if self._fused is None or self._fused[0] != key:
             struct, keep = packing.layer_weight_struct(self, prec)
             self._fused = (key, struct, keep)
@@ -70,13 +69,11 @@ class ConformerEncoderLayer(nn.Module):
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
                       want_cache=True, pos_proj=None, pending=None, defer_final=False, pos_shared=False, after=None):
         """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified."""
-        _inference_only(self, "ConformerEncoderLayer")
-        if self.training:
-            raise NotImplementedError("ConformerEncoderLayer: train-mode (dropout, BatchNorm batch statistics) is not built yet")
+        _inference_only(self, "ConformerEncoderLayer.fused_forward")
         cfm.require_hip(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        prec = cfm.get_precision()
+        prec = cfm.resolve_precision(self)
         w = self._weights(prec)
         B, T, D = x.shape
         H, FF = self.num_heads, self.hidden_dim
@@ -151,7 +148,28 @@ class ConformerEncoderLayer(nn.Module):
                   "cfm_encoder_layer_forward")
         return out, new_cache
 
+    def train_forward(self, inputs, inputs_attn_mask, inputs_pad_mask):
+        """module.train(): the block as ONE autograd node (cfm/autograd.py EncoderLayerFn) -- BatchNorm batch statistics, every
+        parameter's gradient returned from its backward.  encoder_layer.py:49-71 with the shared nn.Dropout(feedforward_dropout)."""
+        from cfm import autograd as ag
+        cfm.require_hip(inputs)
+        B, T, D = inputs.shape
+        m8, m_str = _mask_args(inputs_attn_mask, B, T, T)
+        keep = None
+        if inputs_pad_mask is not None and inputs_pad_mask.dim() >= 3 and inputs_pad_mask.size(2) > 0:
+            keep = cfm.as_u8_mask(inputs_pad_mask).reshape(-1)
+            if keep.numel() != B * T:
+                raise RuntimeError("pad mask %s does not match inputs %s" % (tuple(inputs_pad_mask.shape), tuple(inputs.shape)))
+        return ag.EncoderLayerFn.apply(inputs, self, cfm.resolve_precision(self), m8, m_str, keep, *self.parameters())
+
     def forward(self, inputs, inputs_attn_mask, pos_embed, inputs_pad_mask=_ABSENT, attn_cache=_ABSENT, cnn_cache=_ABSENT):
+        if cfm.check_mode(self, "ConformerEncoderLayer", (("feedforward dropout", self.dropout.p), ("feed_forward.dropout", self.feed_forward.dropout.p),
+                                                           ("attention dropout", self.self_attn.dropout.p))):
+            if attn_cache is not None and attn_cache.dim() == 4 and attn_cache.size(0) > 0:
+                raise NotImplementedError("ConformerEncoderLayer: a KV cache in train mode (streaming is inference-only)")
+            out = self.train_forward(inputs, inputs_attn_mask, inputs_pad_mask)
+            return (out, inputs_attn_mask, torch.zeros((0, 0, 0, 0), dtype=torch.float32, device=inputs.device),
+                    torch.zeros((0, 0, 0), dtype=inputs.dtype, device=inputs.device))
         out, new_attn_cache = self.fused_forward(inputs, inputs_attn_mask, pos_embed, inputs_pad_mask, attn_cache,
                                                  want_cache=self.return_cache)
         if new_attn_cache is None:

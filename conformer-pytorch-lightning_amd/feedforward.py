@@ -4,7 +4,8 @@ Drop-in for the reference's ``src/feedforward.py`` (class name, constructor argu
 ``w_1.{weight,bias}`` / ``w_2.{weight,bias}`` and ``forward(inputs)`` are the reference's, feedforward.py:4-21).
 The arithmetic is ONE launch of the fused feed-forward kernel of libconformer_gfx950 (csrc/ffn.hip: W1, bias, SiLU/ReLU, W2,
 bias with the hidden activation kept in registers) when the shape has a fused instance, otherwise two MFMA GEMMs whose
-epilogues carry the bias / activation.
+epilogues carry the bias / activation.  In train mode (module.train()) the forward is a torch.autograd.Function over the train kernels
+(cfm/autograd.py): pre-activation kept for the backward, gradients returned for every parameter.
 """
 import torch
 import torch.nn as nn
@@ -14,10 +15,9 @@ from cfm import packing
 
 
 def _inference_only(module, what):
-    if module.training and torch.is_grad_enabled():
-        raise NotImplementedError(
-            "%s: this build ships forward (inference) kernels only; call .eval() / torch.no_grad(). "
-            "Backward kernels are the next row of the scope table (SURVEY 8f)." % what)
+    """Entry points that only exist for inference (KV-cache streaming): refuse train mode loudly."""
+    if module.training:
+        raise NotImplementedError("%s: this entry point is inference-only (streaming / KV cache); call .eval()" % what)
 
 
 class PositionwiseFeedForwardModule(nn.Module):
@@ -31,9 +31,12 @@ class PositionwiseFeedForwardModule(nn.Module):
         self._pack = packing.PackCache()
 
     def forward(self, inputs):
-        _inference_only(self, "PositionwiseFeedForwardModule")
         cfm.require_hip(inputs)
-        prec = cfm.get_precision()
+        prec = cfm.resolve_precision(self)
+        if cfm.check_mode(self, "PositionwiseFeedForwardModule", (("dropout", self.dropout.p),)):
+            from cfm import autograd as ag
+            act = cfm.ACT_SILU if isinstance(self.activation, nn.SiLU) else cfm.ACT_RELU
+            return ag.FeedForwardFn.apply(inputs, self, prec, act, *self.parameters())
         pk = packing.pack_ffn(self, prec)
         d_in = inputs.shape[-1]
         x = inputs.reshape(-1, d_in)

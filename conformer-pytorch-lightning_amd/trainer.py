@@ -1,0 +1,204 @@
+"""Data-parallel training step for the hot path (BASELINE config 3): encoder + CTC loss + backward, gradient all-reduce over RCCL/xGMI.
+
+What the reference does, implicitly, through Lightning (src/executor.py:137-154 devices=N / accumulate_grad_batches / gradient_clip_val,
+train.sh:35-36 clip 4 / accum 2, src/module.py:140-143 Adam + WarmupLR stepped per optimizer step, src/dataset.py:54-58 data[rank::world]):
+one process per GPU, DDP's bucketed gradient all-reduce overlapped with backward, `no_sync` on all but the last accumulated micro-batch,
+clip-by-global-norm after the reduce, Adam.  The MI355X-first restatement:
+
+  * ONE flat f32 buffer each for parameters, gradients and the two Adam moments.  Every nn.Parameter is a view into the first, every
+    `.grad` a view into the second, laid out in the order gradients become READY (CTC head, after_norm, last block ... first block,
+    front-end), so a bucket is a contiguous slice and "bucket ready" is a counter.
+  * buckets (25 MB like DDP's default: 6 all-reduces for the 139 MB of encoder + CTC gradients; xGMI is 7 point-to-point links per GPU,
+    and RCCL's ring is per-link bound, so fewer, larger messages than NVSwitch-tuned 1-5 MB buckets) are all-reduced with
+    torch.distributed (backend "nccl" = RCCL) as soon as their last gradient has been accumulated -- post-accumulate-grad hooks fire from
+    the autograd thread because the Functions in cfm/autograd.py RETURN their gradients -- asynchronously, on RCCL's stream, overlapped
+    with the rest of the backward; nothing is reduced for the first accum_grad-1 micro-batches (no_sync).
+  * after the last bucket: sum of squares of the flat gradient (one kernel), clip coefficient computed ON THE DEVICE, fused
+    clip-scale + average + Adam over the flat buffers (one kernel, cfm_adam_step), gradient buffer zeroed.  No host synchronisation
+    anywhere in the step; the learning rate is host scalar math (WarmupLR, src/scheduler.py:36-52).
+  * BatchNorm statistics stay per rank (the reference uses no SyncBatchNorm: SURVEY quirk Q6).
+
+The elementwise kernels come from a small `kernels` object (default: the HIP ones, no fallback); the gloo/CPU tests of the bucket /
+accumulate / clip logic inject a torch implementation from tests/.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+class HipStepKernels:
+    """sum of squares and the fused Adam step on the MI355X (csrc/train.hip)."""
+
+    def sumsq(self, flat):
+        import cfm
+        return cfm.sumsq(flat)
+
+    def adam_step(self, p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale):
+        import cfm
+        cfm.adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=grad_scale)
+
+    def weights_changed(self):
+        from cfm import packing
+        packing.bump_epoch()               # the flat update bypasses torch's version counters: invalidate the packed weights
+
+
+def warmup_lr(base_lr, warmup_steps, step_num):
+    """WarmupLR of the reference (src/scheduler.py:36-52): peak = base_lr at step_num == warmup_steps."""
+    if warmup_steps == 0:
+        return base_lr * step_num ** -0.5
+    return base_lr * warmup_steps ** 0.5 * min(step_num ** -0.5, step_num * warmup_steps ** -1.5)
+
+
+class DataParallelTrainer:
+    def __init__(self, modules, loss_fn, lr=1e-3, warmup_steps=25000, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, accum_grad=2,
+                 grad_clip=4.0, bucket_mb=25.0, process_group=None, kernels=None, always_reduce=False):
+        """modules: nn.Modules in FORWARD order (their parameters are flattened in reverse); loss_fn(batch) -> scalar loss tensor.
+        always_reduce: issue the bucket all-reduces even with one rank (lets a 1-GPU box rehearse the RCCL path)."""
+        self.modules = list(modules)
+        self.loss_fn = loss_fn
+        self.base_lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
+        self.accum_grad, self.grad_clip = int(accum_grad), grad_clip
+        self.kernels = kernels if kernels is not None else HipStepKernels()
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.always_reduce = bool(always_reduce) and dist.is_available() and dist.is_initialized()
+        self.step_count = 0
+
+        forward_order = []
+        seen = set()
+        for m in self.modules:
+            for p in m.parameters():
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    forward_order.append(p)
+        self.params = forward_order[::-1]                                  # gradient-ready order
+        if not self.params:
+            raise ValueError("DataParallelTrainer: no trainable parameters")
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("DataParallelTrainer: parameters must be float32 on one device")
+        # 16-byte aligned offsets so the vectorised kernels and the collectives see aligned slices
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.numel = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                self.flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.kernels.weights_changed()
+
+        # buckets: contiguous runs of parameters (ready order) of at least bucket_mb
+        limit = int(bucket_mb * (1 << 20) / 4)
+        self.buckets = []                                                   # (start, end, n_params)
+        start, count = 0, 0
+        self._bucket_of = {}
+        for i, (p, o) in enumerate(zip(self.params, offs)):
+            self._bucket_of[id(p)] = len(self.buckets)
+            count += 1
+            end = o + (p.numel() + 3) // 4 * 4
+            if end - start >= limit or i == len(self.params) - 1:
+                self.buckets.append((start, end, count))
+                start, count = end, 0
+        self._ready = [0] * len(self.buckets)
+        self._next = 0
+        self._works = []
+        self._sync = False
+        self.reduce_log = []                                                # bucket indices in launch order of the last step (tests)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _on_grad(self, p):
+        if not self._sync:
+            return
+        b = self._bucket_of[id(p)]
+        self._ready[b] += 1
+        # buckets are launched strictly in index order (a collective must be issued in the same order on every rank, whatever order the
+        # autograd engine happens to run the accumulation hooks of one Function's many parameters in)
+        while self._next < len(self.buckets) and self._ready[self._next] == self.buckets[self._next][2]:
+            self._launch(self._next)
+            self._next += 1
+
+    def _launch(self, b):
+        self.reduce_log.append(b)
+        if self.world > 1 or self.always_reduce:
+            s, e, _ = self.buckets[b]
+            self._works.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def lr(self):
+        return warmup_lr(self.base_lr, self.warmup_steps, self.step_count + 1)
+
+    def step(self, micro_batches):
+        """One optimizer step over accum_grad micro-batches.  Returns the mean loss (a device tensor; no sync)."""
+        if len(micro_batches) != self.accum_grad:
+            raise ValueError("step() wants %d micro-batches (accum_grad), got %d" % (self.accum_grad, len(micro_batches)))
+        total = None
+        self.reduce_log = []
+        for i, mb in enumerate(micro_batches):
+            self._sync = i == self.accum_grad - 1                          # no_sync on all but the last micro-batch
+            self._ready = [0] * len(self.buckets)
+            self._next = 0
+            loss = self.loss_fn(mb)
+            (loss / self.accum_grad).backward()
+            total = loss.detach() if total is None else total + loss.detach()
+        self._sync = False
+        while self._next < len(self.buckets):                               # parameters that took no part in this graph: still reduce
+            self._launch(self._next)
+            self._next += 1
+        for w in self._works:
+            w.wait()                                                        # the current stream waits for RCCL's
+        self._works = []
+        self.finish()
+        return total / self.accum_grad
+
+    def finish(self):
+        """clip by the global norm of the AVERAGED gradient (executor.py:150), Adam, zero the gradient buffer."""
+        inv_world = 1.0 / self.world
+        scale = None
+        if self.grad_clip is not None and self.grad_clip > 0:
+            norm = self.kernels.sumsq(self.flat_g).sqrt() * inv_world       # 1-element device tensors: no sync
+            scale = (self.grad_clip / (norm + 1e-6)).clamp(max=1.0) * inv_world
+            self.last_grad_norm = norm
+        elif self.world > 1:
+            scale = torch.full((1,), inv_world, dtype=torch.float32, device=self.flat_g.device)
+        self.step_count += 1
+        self.kernels.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, warmup_lr(self.base_lr, self.warmup_steps, self.step_count),
+                               self.betas, self.eps, self.weight_decay, self.step_count, scale)
+        self.flat_g.zero_()
+        self.kernels.weights_changed()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# synthetic "LibriSpeech-shaped" batches: what the reference's dynamic batcher hands the model (processor.py:267-316)
+# ----------------------------------------------------------------------------------------------------------------------
+def librispeech_shaped_batch(rs, max_frames_in_batch=8000, min_len=200, max_len=1650, vocab=5002, feat_dim=80):
+    """One dynamic batch: utterance lengths ~ U{min_len..max_len} added while B * T_max <= max_frames_in_batch (data_config.json:39,15),
+    sorted by length descending (processor.py:295), labels in [2, vocab-2] of length ~T/30 clipped to [1, 200] padded with 0
+    (data_config.json:17, processor.py:305-308).  rs: numpy RandomState (seed 1234 + rank).  Returns numpy arrays."""
+    import numpy as np
+    lens = []
+    while True:
+        L = int(rs.randint(min_len, max_len + 1))
+        if (len(lens) + 1) * max(lens + [L]) > max_frames_in_batch:
+            break
+        lens.append(L)
+    lens = sorted(lens, reverse=True)
+    B, T = len(lens), lens[0]
+    feats = rs.standard_normal((B, T, feat_dim)).astype(np.float32)
+    for b, L in enumerate(lens):
+        feats[b, L:] = 0.0
+    label_lens = np.array([min(200, max(1, L // 30)) for L in lens], dtype=np.int64)
+    labels = np.zeros((B, int(label_lens.max())), dtype=np.int64)
+    for b in range(B):
+        labels[b, :label_lens[b]] = rs.randint(2, vocab - 1, size=label_lens[b])
+    return feats, np.array(lens, dtype=np.int32), labels, label_lens

@@ -40,7 +40,11 @@ typedef enum {
     CFM_ERR_UNSUPPORTED = -3  /* valid request this build has no kernel for */
 } cfm_status;
 
-typedef enum { CFM_ACT_NONE = 0, CFM_ACT_SILU = 1, CFM_ACT_RELU = 2, CFM_ACT_GLU = 3 } cfm_act;
+typedef enum {
+    CFM_ACT_NONE = 0, CFM_ACT_SILU = 1, CFM_ACT_RELU = 2, CFM_ACT_GLU = 3,
+    /* backward epilogues (training): v = alpha * (acc + bias) * f'(aux[m,n]) with aux the forward pre-activation (SiLU) or output (ReLU) */
+    CFM_ACT_DSILU = 4, CFM_ACT_DRELU = 5
+} cfm_act;
 
 int cfm_version(void);
 const char* cfm_last_error(void);
@@ -92,9 +96,48 @@ typedef struct {
                                                            1: row_mask zeroes the INPUT row (acc = 0, bias/act still apply) */
     const void* W_frag; /* optional: the same weights fragment-major (see cfm_rowchain), K %% 32 == 0, N %% 16 == 0.  16-bit, non-split
                            launches with a 128- or 64-row tile then read W global -> VGPR in MFMA layout and stage only A in LDS */
+    /* training: */
+    void* C_pre;        /* optional second output [M,N] (row stride ld_pre, pre_dtype): acc + bias BEFORE the activation -- what the
+                           backward of SiLU / GLU needs (feedforward.py:18, convolution.py:42).  GLU: all N interleaved columns. */
+    int64_t ld_pre;
+    int32_t pre_dtype;
+    int32_t aux_dtype;  /* CFM_ACT_DSILU / CFM_ACT_DRELU: dtype and row stride of aux [M,N] */
+    const void* aux;
+    int64_t ld_aux;
 } cfm_gemm_desc;
 
 int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradient ("TN" product, csrc/gemm_tn.hip):   C[N,K] (+)= alpha * A[M,N]^T . B[M,K]      (f32 output, MFMA)
+ * the d loss / d weight of every nn.Linear / Conv1d(k=1) / Conv2d(3,2) on the path: A = gradient of the layer's output rows,
+ * B = the rows the layer consumed (what autograd computes for the `weight` of feedforward.py:17-20, attention.py:62-64,99,
+ * convolution.py:41,46,62,74, decoder.py:19).  Both operands are read with the contraction index (the row m) as the SLOW index and
+ * transposed on the way out of LDS (ds_read_b64_tr_b16), so no transposed copy of an activation is ever written.
+ *  A, B      16-bit (mma_dtype) or f32 (rounded while staging; split = 1: both f32, hi/lo bf16 planes, 3 MFMAs: "f32-accurate")
+ *  colsum    optional f32 [N]: (+)= alpha * sum_m A[m,n]     (the gradient of the layer's bias)
+ *  row_mask  optional uint8 [M]: rows with 0 contribute nothing (padded frames of convolution.py:47-48)
+ *  conv      conv_C > 0: B is a channels-last image [Bt, T1, F1, C] and row m = (b, t2, f2) of its 3x3 stride-2 im2col matrix,
+ *            K = 9*C ordered (kt, kf, c) -- the weight gradient of the front-end's second convolution
+ *  The M rows are split over `splits` workgroups per output tile (0 = auto) that add their partial products with f32 atomics;
+ *  accumulate = 0 zero-fills C / colsum first (same stream).  splits = 1 is bitwise reproducible.
+ * constraints: N % 8 == 0, K % 8 == 0, lda/ldb % 8 == 0 (16-bit) or % 4 (f32), ldc % 4 == 0.
+ */
+typedef struct {
+    const void* A;
+    const void* B;
+    float* C;
+    float* colsum;
+    const uint8_t* row_mask;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t a_dtype, b_dtype, mma_dtype;
+    int32_t split, accumulate, splits;
+    float alpha;
+    int32_t conv_C, conv_T1, conv_F1, conv_T2, conv_F2;
+} cfm_gemm_tn_desc;
+
+int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused feed-forward block (one launch; the [M,FF] hidden activation never reaches memory):
@@ -247,6 +290,7 @@ typedef struct {
     int32_t q_dtype, kv_dtype, p_dtype, out_dtype, mma_dtype; /* mma_dtype: bf16|fp16 operand type */
     int32_t split;                                            /* 1: hi/lo bf16 split (f32-accurate) */
     float scale;
+    float* lse;        /* optional (training): f32 [B,H,Tq], log-sum-exp of each row's scaled masked scores (-inf: fully masked) */
 } cfm_attn_desc;
 
 int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream);
@@ -377,7 +421,7 @@ int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_layer_scratc
  * CTC negative log-likelihood per utterance on top of the vocabulary projection (csrc/ctc.hip):
  * replaces  probs = logits.transpose(0,1).log_softmax(2); nn.CTCLoss(reduction='sum')(probs, labels, enc_lens, label_lens)
  * of CTCDecoder.forward (reference src/decoder.py:20-21; blank = 0, no zero_infinity).  logits f32 [B,T,ld>=V] (from cfm_gemm with
- * ctc_lo.weight / bias), labels int32 [B,Umax] (padding ignored beyond label_lens[b]), work f32 scratch [B,T,2*Umax+1], nll f32 [B];
+ * ctc_lo.weight / bias), labels int32 [B,Umax] (padding ignored beyond label_lens[b]), work f32 scratch [B,T,2*Umax+2], nll f32 [B];
  * the caller sums nll and divides by Umax as decoder.py:22 does.  Umax <= 255.  An impossible alignment gives +inf, like nn.CTCLoss.
  */
 int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens,
@@ -392,6 +436,93 @@ int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V
  */
 int cfm_joint_act(const float* enc, int64_t ld_e, const float* pred, int64_t ld_p, void* out, int32_t out_dtype, int32_t B,
                   int32_t T, int32_t U, int32_t J, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training (BASELINE config 3: encoder + CTC loss + backward).  Input gradients of the dense layers are cfm_gemm on transposed
+ * weight packs (with the CFM_ACT_DSILU / CFM_ACT_DRELU epilogues), weight / bias gradients are cfm_gemm_tn; the rest is below.
+ * Every reduction over rows is two-stage through a caller-provided f32 workspace (size from the matching *_ws function, in floats)
+ * and bitwise reproducible.
+ *
+ * cfm_layernorm_bwd     x f32 [M,D] (the norm's INPUT; statistics are recomputed), dy [M,D] (dy_dtype), gamma [D];
+ *                       dx = (dres ? dres : 0) + dLN(dy)   (dx may alias dres: the residual stream's gradient is updated in place);
+ *                       rows with row_mask == 0 have dy = 0 (the masked norm_conv of convolution.py:36-37);  dgamma, dbeta f32 [D].
+ *                       backward of nn.LayerNorm at encoder_layer.py:57,60,64,68,70 and encoder.py:74.   D % 4 == 0, D <= 1024.
+ */
+int64_t cfm_layernorm_bwd_ws(int64_t M, int32_t D);
+int cfm_layernorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres,
+                      float* dx, float* dgamma, float* dbeta, float* ws, float eps, int64_t M, int32_t D, cfm_stream_t stream);
+
+/* GLU backward (convolution.py:42) on the column-interleaved layout the pointwise-conv-1 GEMM writes through cfm_gemm_desc.C_pre:
+ * u [M,2D] (blocks of 16 value columns followed by their 16 gate columns), dg [M,D] -> du [M,2D] same layout.  D % 16 == 0. */
+int cfm_glu_bwd(const void* u, int32_t u_dtype, const void* dg, int32_t dg_dtype, void* du, int32_t du_dtype, int64_t M, int32_t D,
+                cfm_stream_t stream);
+
+/* Depthwise conv (15 taps) -> BatchNorm1d in TRAINING mode -> SiLU  (convolution.py:43-45 under module.train()):
+ *   c = dw(g) + bias            -> c_out f32 [B,T,D]  (kept for the backward)
+ *   batch mean / biased variance over ALL B*T rows of each channel, padded frames included
+ *   stats f32 [4][D] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale;   s_out = SiLU(c*scale + shift)  (s_dtype)
+ *   running_mean / running_var (optional) are updated in place with `momentum` and the UNBIASED variance, as torch does.
+ * cfm_dwconv_bn_train_bwd: ds = d loss / d s_out -> dg_out = d loss / d g, and the gradients of the taps dw_w [D,15], the conv bias
+ * dw_b [D], the BatchNorm gain / bias dgamma, dbeta [D].  dy_ws: f32 [B*T,D] scratch.  ws: cfm_dwconv_bn_ws(B,T,D) floats (both). */
+int64_t cfm_dwconv_bn_ws(int32_t B, int32_t T, int32_t D);
+int cfm_dwconv_bn_train(const void* g, int32_t g_dtype, const float* w, const float* dw_bias, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* c_out, float* stats, void* s_out,
+                        int32_t s_dtype, float* ws, int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream);
+int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
+                            void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
+                            int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream);
+
+/* Front-end backward (convolution.py:60-63).  cfm_col2im_relu_bwd: dcol [B*T2*F2, 9*C] = dh2 . W2 (cfm_gemm on the transposed conv2 pack,
+ * K order (kt,kf,c)) -> dh1 [B,T1,F1,C] = ReLU'(h1) * (transposed im2col of dcol).  cfm_conv1_wgrad: dh1 and the fbank input x [B,T,F]
+ * (global CMVN folded as in cfm_conv1_relu) -> dw [9,C] tap-major, db [C]. */
+int cfm_col2im_relu_bwd(const void* dcol, int32_t dcol_dtype, const void* h1, int32_t h1_dtype, void* dh1, int32_t dh1_dtype, int32_t B, int32_t T1,
+                        int32_t F1, int32_t C, cfm_stream_t stream);
+int64_t cfm_conv1_wgrad_ws(int32_t B, int32_t T, int32_t C);
+int cfm_conv1_wgrad(const void* dh1, int32_t dh1_dtype, const float* x, const float* cmvn_mean, const float* cmvn_istd, float* dw, float* db, float* ws,
+                    int32_t B, int32_t T, int32_t F, int32_t C, cfm_stream_t stream);
+
+/* Attention backward (csrc/attention_bwd.hip; attention.py:81-96 under autograd).  cfm_attention with `lse` set also writes the row
+ * log-sum-exp of the scaled, masked scores, lse f32 [B,H,Tq] (-inf for a fully masked row).  Given dout [B,Tq,H*dk] the backward
+ * recomputes the probabilities tile by tile (nothing of size Tq x Tk reaches memory) and writes grad_q/k/v with the strides of q, k, v.
+ * Batch path only (p broadcast over keys or absent: the positional term is then constant along a softmax row and has no gradient;
+ * d pos_bias_u = the column sums of dq).  Fully masked rows contribute nothing (the reference's masked_fill(0) makes them constant). */
+typedef struct {
+    const void *q, *k, *v;          /* element (b,t,h,d) at base + b*sb + t*st + h*dk + d; q already includes pos_bias_u (train mode adds it
+                                       through the projection's bias) */
+    const uint8_t* mask;
+    const void* out;                /* forward output [B,Tq,H*dk] */
+    const void* dout;               /* [B,Tq,H*dk] */
+    const float* lse;               /* [B,H,Tq] */
+    void *grad_q, *grad_k, *grad_v; /* same strides as q, k, v */
+    float* delta;                   /* f32 scratch [B,H,Tq] */
+    int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, m_sb, m_sq;
+    int32_t B, H, Tq, Tk, dk;
+    int32_t io_dtype;               /* dtype of q,k,v,out,dq,dk,dv (16-bit or f32) */
+    int32_t dout_dtype;
+    int32_t mma_dtype, split;
+    float scale;
+} cfm_attn_bwd_desc;
+int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream);
+
+/* CTC backward (csrc/ctc.hip): cfm_ctc_nll_train is cfm_ctc_nll that also keeps log alpha (alpha f32 [B,T,2*Umax+2]), the per-frame
+ * log-sum-exp (lse f32 [B,T]) and nll_shifted f32 [B] (-log P of the per-frame-shifted recursion: the posteriors' normaliser); cfm_ctc_grad runs the beta recursion and writes d loss / d logits [B,T,ld] = gscale[b] * (softmax - occupancy)
+ * for t < enc_lens[b] and 0 elsewhere (pad columns V..ld-1 too) -- what autograd gives for nn.CTCLoss(reduction='sum') on
+ * log_softmax(logits) (decoder.py:20-21).  The scale is gscale * (gscale_dev ? *gscale_dev : 1): a host factor (1 / padded label length,
+ * decoder.py:22) times an optional DEVICE scalar (the upstream gradient).  alpha_beta is cfm_ctc_nll_train's alpha, overwritten.
+ * An utterance with no valid alignment (nll = inf) gets a zero gradient (torch's is undefined without zero_infinity).  V <= 8192. */
+int cfm_ctc_nll_train(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
+                      const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, cfm_stream_t stream);
+int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
+                 const int32_t* label_lens, const float* work, float* alpha_beta, const float* lse, const float* nll_shifted, float gscale,
+                 const float* gscale_dev, float* dlogits, cfm_stream_t stream);
+
+/* Optimizer step over flat f32 buffers (module.py:140-143 Adam; executor.py:150 gradient_clip_val):  g' = g * (*grad_scale) + wd * p;
+ * m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)   (torch.optim.Adam).
+ * grad_scale: optional DEVICE scalar (the clip coefficient), so nothing synchronises between backward and step.
+ * cfm_sumsq: out[0] = sum x^2 (two-stage, n_partials <= 4096 workgroups). */
+int cfm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, const float* grad_scale, cfm_stream_t stream);
+int cfm_sumsq(const float* x, int64_t n, float* partials, int32_t n_partials, float* out, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling table (aux subsystem: tracing).  When enabled, every kernel launch made through this

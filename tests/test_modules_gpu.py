@@ -579,7 +579,7 @@ def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(torch.zeros(2, 3, 16))
-    layer = pkg.encoder_layer.ConformerEncoderLayer(16, 15, 0.0, 0.0, 32, 2, True).to(DEV)      # train mode
+    layer = pkg.encoder_layer.ConformerEncoderLayer(16, 15, 0.1, 0.0, 32, 2, True).to(DEV)      # train mode with ACTIVE dropout: not built, refused
     with pytest.raises(NotImplementedError):
         layer(torch.zeros(1, 4, 16, device=DEV), torch.ones((0, 0, 0)), torch.zeros(1, 1, 16, device=DEV))
 

@@ -1,0 +1,289 @@
+"""GPU: TRAIN-mode forward + backward of the drop-in modules (autograd Functions over the C ABI) against
+ (1) the reference's own losses / parameter gradients / BatchNorm running statistics (tests/golden/train_*.npz, produced by running
+     the reference in train mode with every dropout probability 0), and
+ (2) the CPU oracle under torch.autograd on shapes the goldens do not cover (BASELINE config 4's d = 512, h = 8).
+
+Gradient error metric (conftest.grad_err): max|d| / max(max|ref|, floor) per tensor, floor = 1e-2 (modules) or 1e-3 (whole encoder) of
+the largest gradient of the case -- structurally-zero gradients (depthwise bias under BatchNorm, pos_bias_v, linear_pos, linear_k.bias)
+are rounding noise in the reference and exact or near-exact zeros here.
+Gates:  fp32 ("f32-accurate") <= 1e-3 (the north-star tolerance);  fp16 / bf16: about 1.5x what was measured on MI355X (printed).
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import grad_err, grad_ref_max, load_golden
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["bf16", "fp16", "fp32"]
+DEV = "cuda"
+# module-level gates: (forward output, gradients)
+MOD_TOL = {"fp32": (1e-4, 1e-3), "fp16": (5e-3, 1.5e-2), "bf16": (3e-2, 6e-2)}
+# whole encoder + CTC: (loss relative, output, gradients)
+ENC_TOL = {"fp32": (1e-4, 1e-3, 1e-3), "fp16": (5e-3, 5e-3, 1e-2), "bf16": (3e-2, 3e-2, 5e-2)}
+# The two front-end convolutions sit behind ReLUs on a few thousand positions.  A forward difference of one rounding error flips isolated
+# ReLU mask bits, and each flipped bit moves an entry of a convolution's weight gradient by one full term of a ~sqrt(positions)-sized sum:
+# the max-norm error of those tensors is a property of the fixture's size (T = 83..200 frames), not of the kernels (fp32 mode reproduces
+# them to 1e-5 when no bit flips).  They get their own max-norm gate.
+FRONT_TOL = {"fp32": 2e-2, "fp16": 1e-1, "bf16": 1.5e-1}
+
+
+def is_front(name):
+    return "conv.0." in name or "conv.2." in name
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import cfm
+    import attention
+    import convolution
+    import decoder
+    import encoder
+    import encoder_layer
+    import feedforward
+    assert torch.cuda.is_available()
+    assert cfm.lib().cfm_device_ok() == 1, cfm.lib().cfm_last_error()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.cfm, ns.attention, ns.convolution, ns.decoder, ns.encoder, ns.encoder_layer, ns.feedforward = (
+        cfm, attention, convolution, decoder, encoder, encoder_layer, feedforward)
+    yield ns
+    cfm.set_precision("bf16")
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def pad_valid(lens, T):
+    return (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).unsqueeze(1).to(DEV)
+
+
+def run_case(g, tag, mod, x, call, gseed, mode, want_dx=True, ftol=None, gtol=None, skip=()):
+    mod.zero_grad()
+    xr = x.clone().requires_grad_(want_dx)
+    out = call(mod, xr)
+    G = dev(synth.normal(gseed, tuple(out.shape)))
+    (out * G).sum().backward()
+    ftol = MOD_TOL[mode][0] if ftol is None else ftol
+    gtol = MOD_TOL[mode][1] if gtol is None else gtol
+    e_out = grad_err(g, tag + ":out", out.detach().float().cpu().numpy())
+    names = [k for k, p in mod.named_parameters()]
+    floor = 1e-2 * max([grad_ref_max(g, tag + ":grad:" + k) for k in names] + ([grad_ref_max(g, tag + ":dx")] if want_dx else []))
+    worst, worst_front = (0.0, ""), (0.0, "")
+    if want_dx:
+        worst = max(worst, (grad_err(g, tag + ":dx", xr.grad.float().cpu().numpy(), floor), "dx"))
+    for k, p in mod.named_parameters():
+        assert p.grad is not None, (tag, k)
+        assert bool(torch.isfinite(p.grad).all()), (tag, k)
+        if k in skip:
+            continue
+        e = (grad_err(g, tag + ":grad:" + k, p.grad.float().cpu().numpy(), floor), k)
+        if is_front(k):
+            worst_front = max(worst_front, e)
+        else:
+            worst = max(worst, e)
+    print("  [%s] %-18s out %.3e   worst gradient %.3e (%s)   front-end convs %.3e (%s)" % (mode, tag, e_out, worst[0], worst[1], worst_front[0], worst_front[1]))
+    assert e_out < ftol, (tag, mode, e_out)
+    assert worst[0] < gtol, (tag, mode, worst)
+    assert worst_front[0] < FRONT_TOL[mode], (tag, mode, worst_front)
+    return out
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_module_gradients_match_reference(pkg, mode):
+    g, meta = load_golden("train_mods_d144")
+    D, H, FF, K, B, T = (meta[k] for k in ("D", "H", "FF", "K", "B", "T"))
+    pkg.cfm.set_precision(mode)
+    pad = pad_valid(meta["lens"], T)
+    from oracle import conformer_oracle as O
+    chunk_all = torch.from_numpy(O.chunk_mask(T, 5, 1)).to(DEV).unsqueeze(0).expand(B, T, T).contiguous()
+    chunk_pad = chunk_all & pad
+    rpe = pkg.attention.RelativePositionalEncoding(D, 0.0)
+    pos_b = rpe.pe[0:B].to(DEV)
+
+    x = dev(synth.normal(41, (B, T, D)))
+    m = synth.load_synth_(pkg.feedforward.PositionwiseFeedForwardModule(D, 0.0, FF), 31).to(DEV).train()
+    run_case(g, "ffn", m, x, lambda mod, xr: mod(xr), 61, mode)
+
+    x = dev(synth.normal(42, (B, T, D)))
+    m = synth.load_synth_(pkg.attention.RelativeMultiHeadSelfAttentionModule(D, H, 0.0), 32).to(DEV).train()
+    run_case(g, "relmhsa_pad", m, x, lambda mod, xr: mod(xr, xr, xr, pad, pos_b)[0], 62, mode)
+    run_case(g, "relmhsa_chunk", m, x, lambda mod, xr: mod(xr, xr, xr, chunk_all, pos_b)[0], 63, mode)
+    run_case(g, "relmhsa_chunkpad", m, x, lambda mod, xr: mod(xr, xr, xr, chunk_pad, pos_b)[0], 64, mode)      # fully masked rows
+    m = synth.load_synth_(pkg.attention.MultiHeadSelfAttentionModule(D, H, 0.0), 36).to(DEV).train()
+    run_case(g, "mhsa_pad", m, x, lambda mod, xr: mod(xr, xr, xr, pad)[0], 65, mode)
+
+    x = dev(synth.normal(43, (B, T, D)))
+    m = synth.load_synth_(pkg.convolution.ConvolutionModule(D, K, FF), 33).to(DEV).train()
+    run_case(g, "conv_pad", m, x, lambda mod, xr: mod(xr, pad)[0], 66, mode)
+    rtol = 1e-5 if mode == "fp32" else 2e-2
+    assert np.abs(m.norm.running_mean.cpu().numpy() - g["conv_pad:running_mean"]).max() < rtol
+    assert np.abs(m.norm.running_var.cpu().numpy() - g["conv_pad:running_var"]).max() < rtol
+    assert int(m.norm.num_batches_tracked) == int(g["conv_pad:num_batches_tracked"][0]) == 1
+
+    xf = dev(synth.fbank(44, 3, 83))
+    padf = pad_valid(meta["sub_lens"], 83)
+    m = synth.load_synth_(pkg.convolution.ConvolutionSubSampling(80, D, pkg.attention.RelativePositionalEncoding(D, 0.0)), 34).to(DEV).train()
+    run_case(g, "sub", m, xf, lambda mod, xr: mod(xr, padf)[0], 67, mode, want_dx=False)
+
+    x = dev(synth.normal(45, (B, T, D)))
+    m = synth.load_synth_(pkg.encoder_layer.ConformerEncoderLayer(D, K, 0.0, 0.0, FF, H, True), 35).to(DEV).train()
+    run_case(g, "layer", m, x, lambda mod, xr: mod(xr, pad, pos_b, pad)[0], 68, mode)
+    m = synth.load_synth_(pkg.encoder_layer.ConformerEncoderLayer(D, K, 0.0, 0.0, FF, H, False), 37).to(DEV).train()
+    run_case(g, "layer_norel", m, x, lambda mod, xr: mod(xr, pad, None, pad)[0], 69, mode)
+
+
+def build_train_case(pkg, name, mode):
+    g, meta = load_golden(name)
+    cfg = meta["cfg"]
+    pkg.cfm.set_precision(mode)
+    enc = pkg.encoder.ConformerEncoder(cmvn=None, **dict(cfg, **meta["ctor"]))
+    synth.load_synth_(enc, meta["wseed"])
+    dec = synth.load_synth_(pkg.decoder.CTCDecoder(meta["V"], cfg["encoder_dim"], 0.0), meta["cseed"])
+    enc, dec = enc.to(DEV).train(), dec.to(DEV).train()
+    x = dev(synth.fbank(meta["xseed"], meta["batch"], meta["frames"]))
+    lens = torch.tensor(meta["lens"], dtype=torch.int32, device=DEV)
+    return g, meta, enc, dec, x, lens
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["train_cfg1", "train_cfg1_chunk", "train_cfg2s"])
+def test_encoder_ctc_training_step_matches_reference(pkg, name, mode):
+    """BASELINE config 3's step at golden size: encoder (train mode) + CTC loss + backward; loss, every parameter gradient and the
+    BatchNorm running statistics against the reference's."""
+    g, meta, enc, dec, x, lens = build_train_case(pkg, name, mode)
+    y, m = enc(x, lens, **meta["fw"])
+    enc_lens = m.squeeze(1).sum(1)
+    assert np.array_equal(enc_lens.cpu().numpy(), g["enc_lens"])
+    loss = dec(y, enc_lens, dev(g["labels"]), dev(g["label_lens"]))
+    loss.backward()
+    tl, ty, tg = ENC_TOL[mode]
+    e_loss = abs(float(loss) - float(g["loss"][0])) / abs(float(g["loss"][0]))
+    e_y = grad_err(g, "y", y.detach().float().cpu().numpy())
+    named = [("enc." + k, p) for k, p in enc.named_parameters()] + [("ctc." + k, p) for k, p in dec.named_parameters()]
+    floor = 1e-3 * max(grad_ref_max(g, "grad:" + k) for k, _ in named)
+    errs = []
+    for k, p in named:
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        errs.append((grad_err(g, "grad:" + k, p.grad.float().cpu().numpy(), floor), k))
+    worst = max(e for e in errs if not is_front(e[1]))
+    worst_front = max(e for e in errs if is_front(e[1]))
+    med = float(np.median([e for e, _ in errs]))
+    print("  [%s] %-16s loss %.3e   y %.3e   gradients: worst %.3e (%s), median %.3e, front-end convs %.3e (%s)" % (
+        mode, name, e_loss, e_y, worst[0], worst[1], med, worst_front[0], worst_front[1]))
+    assert e_loss < tl and e_y < ty, (e_loss, e_y)
+    assert worst[0] < tg, worst
+    assert worst_front[0] < FRONT_TOL[mode], worst_front
+    rtol = 1e-5 if mode == "fp32" else 3e-2
+    for k, v in enc.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert np.abs(v.cpu().numpy() - g["bn:" + k]).max() < rtol, k
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 1
+
+
+def test_training_step_is_deterministic_and_accumulates(pkg):
+    """two identical steps give bitwise-identical gradients when the weight-gradient GEMMs run unsplit ... here: accumulation semantics --
+    a second backward ADDS into .grad (gradient accumulation, train.sh:36 accum_grad 2)."""
+    g, meta, enc, dec, x, lens = build_train_case(pkg, "train_cfg1", "fp32")
+    def step():
+        y, m = enc(x, lens)
+        dec(y, m.squeeze(1).sum(1), dev(g["labels"]), dev(g["label_lens"])).backward()
+    step()
+    g1 = {k: p.grad.clone() for k, p in enc.named_parameters()}
+    step()
+    gmax = max(float(v.abs().max()) for v in g1.values())
+    for k, p in enc.named_parameters():
+        a, b = p.grad, 2 * g1[k]                                        # BatchNorm running stats moved, the forward did not (batch statistics)
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-3 * gmax), k
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_config4_shape_gradients_against_oracle(pkg, mode):
+    """d = 512, h = 8, ff = 2048 (BASELINE config 4's encoder shape), 2 layers, ragged batch: gradients against the CPU oracle under
+    torch.autograd (the goldens stop at d = 256)."""
+    from oracle import conformer_oracle as O
+    from test_oracle_golden import encoder_shapes
+    cfg = dict(input_dim=80, kernel_size=15, encoder_dim=512, dropout=0.0, attention_dropout=0.0, pos_enc_dropout=0.0, hidden_dim=2048, num_heads=8,
+               encoder_num_layers=2, max_len=5000, use_relative=True)
+    B, T, V, Umax = 3, 160, 300, 6
+    lens = [160, 131, 90]
+    pkg.cfm.set_precision(mode)
+    enc = synth.load_synth_(pkg.encoder.ConformerEncoder(cmvn=None, **cfg), 71)
+    dec = synth.load_synth_(pkg.decoder.CTCDecoder(V, 512, 0.0), 72)
+    x = synth.fbank(73, B, T)
+    rs = np.random.RandomState(74)
+    labels = rs.randint(1, V, size=(B, Umax))
+    label_lens = np.array([6, 4, 3])
+    for b in range(B):
+        labels[b, label_lens[b]:] = 0
+    # oracle (CPU, f32, autograd)
+    P = {k: v.detach().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k) for k, v in enc.state_dict().items()}
+    Pc = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    y_o, m_o = O.encoder_forward(P, O.Config(**cfg), torch.from_numpy(x), lens, train=True)
+    el = m_o.squeeze(1).sum(1).numpy()
+    loss_o = O.ctc_head_loss_autograd(Pc, "", y_o, el, labels, label_lens)
+    loss_o.backward()
+    # device
+    enc, dec = enc.to(DEV).train(), dec.to(DEV).train()
+    y, m = enc(dev(x), torch.tensor(lens, dtype=torch.int32, device=DEV))
+    loss = dec(y, m.squeeze(1).sum(1), dev(labels), dev(label_lens))
+    loss.backward()
+    tl, ty, tg = ENC_TOL[mode]
+    assert abs(float(loss) - float(loss_o)) / abs(float(loss_o)) < tl
+    gmax = max(float(P[k].grad.abs().max()) for k, _ in enc.named_parameters())
+    worst, worst_front, worst_l2 = (0.0, ""), (0.0, ""), (0.0, "")
+    for k, p in list(enc.named_parameters()) + [("ctc." + k, p) for k, p in dec.named_parameters()]:
+        ref = (Pc[k[4:]] if k.startswith("ctc.") else P[k]).grad.double()
+        d = p.grad.cpu().double() - ref
+        e = (float(d.abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax), k)
+        l2 = (float(d.norm()) / max(float(ref.norm()), 1e-3 * gmax * ref.numel() ** 0.5), k)
+        worst_l2 = max(worst_l2, l2)
+        if is_front(k):
+            worst_front = max(worst_front, e)
+        else:
+            worst = max(worst, e)
+    print("  [%s] config-4 shape: loss %.5f vs %.5f, worst gradient %.3e (%s), front-end convs %.3e (%s), worst rel-L2 %.3e (%s)" % (
+        mode, float(loss), float(loss_o), worst[0], worst[1], worst_front[0], worst_front[1], worst_l2[0], worst_l2[1]))
+    assert worst[0] < tg, worst
+    assert worst_front[0] < FRONT_TOL[mode], worst_front
+    assert worst_l2[0] < tg, worst_l2                                   # isolated mask flips do not move the L2 error
+
+
+def test_reference_style_driver_trains_on_dropin_modules(pkg):
+    """the reference's own encoder.py loop (embed -> blocks -> after_norm, encoder.py:62-74) spelled out over the drop-in modules in
+    train mode gives the same loss and gradients as ConformerEncoder.forward."""
+    g, meta, enc, dec, x, lens = build_train_case(pkg, "train_cfg1", "fp32")
+    y, m = enc(x, lens)
+    dec(y, m.squeeze(1).sum(1), dev(g["labels"]), dev(g["label_lens"])).backward()
+    ref = {k: p.grad.clone() for k, p in enc.named_parameters()}
+    enc.zero_grad()
+    for mod in enc.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.reset_running_stats()
+    pad = ~pkg.encoder.make_pad_mask(lens, x.size(1)).unsqueeze(1)
+    out, pos, pad_s = enc.embed(x, pad)
+    am = pkg.encoder.make_attn_mask(out, pad_s, False, False, 0, -1, -1)
+    for blk in enc.encoders:
+        out, am, _, _ = blk(out, am, pos, pad_s)
+    out = enc.after_norm(out)           # nn.LayerNorm itself: torch's op, autograd-aware
+    dec(out, pad_s.squeeze(1).sum(1), dev(g["labels"]), dev(g["label_lens"])).backward()
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for k, p in enc.named_parameters():
+        assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * max(float(ref[k].abs().max()), 1e-3 * gmax), k
+
+
+def test_train_mode_refuses_what_is_not_built(pkg):
+    D = 144
+    m = pkg.feedforward.PositionwiseFeedForwardModule(D, 0.1, 576).to(DEV).train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4, D, device=DEV))
+    enc = pkg.encoder.ConformerEncoder(80, 15, D, 0.0, 0.0, 0.0, 576, 4, 1, use_relative=True).to(DEV).train()
+    empty = torch.zeros((0, 0, 0, 0), device=DEV)
+    with pytest.raises(NotImplementedError):
+        enc.forward_chunk(torch.zeros(1, 67, 80, device=DEV), 0, 16, empty, empty)

@@ -1,0 +1,136 @@
+"""CPU, world_size 2, gloo: the data-parallel step harness (conformer-pytorch-lightning_amd/trainer.py) on dummy gradients --
+flat parameter / gradient buffers, ready-order buckets, all-reduce only on the last accumulated micro-batch (no_sync), clip by the
+global norm of the averaged gradient, Adam, WarmupLR -- against a single-process torch reference that sees both ranks' data.
+The elementwise kernels are the torch stand-ins of tests/ref_step_kernels.py; the HIP ones are covered by tests/test_train_ops_gpu.py and
+the harness on the GPU by tests/test_trainer_gpu.py."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+for p in (PKG, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def make_model(seed=0):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8))
+
+
+def make_batches(rank, steps, accum):
+    rs = np.random.RandomState(100 + rank)
+    return [[(torch.from_numpy(rs.standard_normal((5, 16)).astype(np.float32)), torch.from_numpy(rs.standard_normal((5, 8)).astype(np.float32)) * 30)
+             for _ in range(accum)] for _ in range(steps)]
+
+
+def reference_run(world, steps, accum, clip, lr, warmup):
+    """What Lightning-DDP would do, in one process: average over ranks and micro-batches, clip, Adam, WarmupLR."""
+    import trainer as T
+    model = make_model()
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    data = [make_batches(r, steps, accum) for r in range(world)]
+    norms = []
+    for s in range(steps):
+        opt.zero_grad()
+        for r in range(world):
+            for (x, y) in data[r][s]:
+                (torch.nn.functional.mse_loss(model(x), y) / (accum * world)).backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), clip)))
+        for gparam in opt.param_groups:
+            gparam["lr"] = T.warmup_lr(lr, warmup, s + 1)
+        opt.step()
+    return [p.detach().clone() for p in model.parameters()], norms
+
+
+def worker(rank, world, port, steps, accum, clip, lr, warmup, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import trainer as T
+    from ref_step_kernels import TorchStepKernels
+    torch.set_num_threads(1)
+    model = make_model()
+    mods = [model[0], model[2], model[4]]                                 # forward order
+    kern = TorchStepKernels()
+    tr = T.DataParallelTrainer(mods, lambda b: torch.nn.functional.mse_loss(model(b[0]), b[1]), lr=lr, warmup_steps=warmup, accum_grad=accum,
+                               grad_clip=clip, bucket_mb=64 * 64 * 4 / (1 << 20), kernels=kern)
+    # layout: gradient-ready order = reverse of forward order; every grad is a view into the flat buffer
+    assert tr.params[0] is model[4].bias and tr.params[-1] is model[0].weight
+    assert all(p.grad.data_ptr() >= tr.flat_g.data_ptr() and p.grad.data_ptr() < tr.flat_g.data_ptr() + tr.numel * 4 for p in model.parameters())
+    assert len(tr.buckets) >= 2 and tr.buckets[0][0] == 0 and tr.buckets[-1][1] == tr.numel
+    calls = []
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return orig(t, *a, **k)
+    dist.all_reduce = counting
+    data = make_batches(rank, steps, accum)
+    norms = []
+    for s in range(steps):
+        n0 = len(calls)
+        loss = tr.step(data[s])
+        assert len(calls) - n0 == len(tr.buckets), "one all-reduce per bucket per optimizer step (none for the no_sync micro-batches)"
+        assert tr.reduce_log == sorted(tr.reduce_log), "buckets are reduced in gradient-ready order"
+        assert float(tr.flat_g.abs().max()) == 0.0
+        norms.append(float(tr.last_grad_norm))
+        assert torch.isfinite(loss)
+    assert kern.epochs == steps + 1
+    dist.all_reduce = orig
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered), "ranks diverged"
+    if rank == 0:
+        torch.save({"params": [p.detach().clone() for p in model.parameters()], "norms": norms}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_trainer_two_ranks_gloo_matches_single_process_reference(tmp_path, world):
+    steps, accum, clip, lr, warmup = 3, 2, 4.0, 1e-2, 2
+    out = str(tmp_path / "r0.pt")
+    port = 29600 + (os.getpid() % 200)
+    mp.spawn(worker, args=(world, port, steps, accum, clip, lr, warmup, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    ref_params, ref_norms = reference_run(world, steps, accum, clip, lr, warmup)
+    assert max(ref_norms) > clip, "the test data must actually trigger the clip"
+    for a, b in zip(got["norms"], ref_norms):
+        assert abs(a - b) < 1e-4 * b
+    for a, b in zip(got["params"], ref_params):
+        assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
+
+
+def test_trainer_single_process_no_collective():
+    import trainer as T
+    from ref_step_kernels import TorchStepKernels
+    model = make_model()
+    tr = T.DataParallelTrainer([model[0], model[2], model[4]], lambda b: torch.nn.functional.mse_loss(model(b[0]), b[1]), lr=1e-2, warmup_steps=2,
+                               accum_grad=2, grad_clip=4.0, kernels=TorchStepKernels())
+    data = make_batches(0, 2, 2)
+    for s in range(2):
+        tr.step(data[s])
+    ref, _ = reference_run(1, 2, 2, 4.0, 1e-2, 2)
+    for a, b in zip(model.parameters(), ref):
+        assert float((a - b).abs().max()) < 2e-6
+    assert abs(T.warmup_lr(1e-3, 25000, 25000) - 1e-3) < 1e-12 and T.warmup_lr(1e-3, 25000, 1) < 1e-6
+
+
+def test_librispeech_shaped_batches():
+    import trainer as T
+    rs = np.random.RandomState(1234)
+    for _ in range(20):
+        feats, lens, labels, label_lens = T.librispeech_shaped_batch(rs)
+        B, Tm, F = feats.shape
+        assert F == 80 and B * Tm <= 8000 and Tm == lens[0] and list(lens) == sorted(lens, reverse=True)
+        assert lens.min() >= 200 and lens.max() <= 1650 and labels.shape == (B, label_lens.max())
+        assert labels.max() <= 5000 and all((labels[b, :label_lens[b]] >= 2).all() and (labels[b, label_lens[b]:] == 0).all() for b in range(B))
+        assert all(1 <= label_lens[b] <= 200 and label_lens[b] == max(1, lens[b] // 30) for b in range(B))
