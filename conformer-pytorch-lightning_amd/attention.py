@@ -65,9 +65,12 @@ class RelativePositionalEncoding(_SinusoidBase):
 class PositionalEncoding(_SinusoidBase):
     _table_dtype = torch.float16            # the reference stores this table in half precision (attention.py:113)
 
-    def forward(self, inputs, offset=0):
+    def forward(self, inputs, offset=0, rows=None):
+        """rows: the (B,1,D) table rows to add, in a caller-owned buffer, instead of the slice at `offset` (a captured HIP graph must
+        not bake the offset in: StreamingSession refreshes that buffer between replays)."""
         self._table_like(inputs)
-        rows = self.position_encoding(offset, inputs.size(0), False)          # (B,1,D): one row per batch item
+        if rows is None:
+            rows = self.position_encoding(offset, inputs.size(0), False)      # (B,1,D): one row per batch item
         if inputs.is_cuda and inputs.dtype == torch.float32 and inputs.is_contiguous() and rows.size(0) == inputs.size(0):
             x = inputs.clone()
             cfm.add_rows(x.view(-1, x.size(-1)), rows.reshape(rows.size(0), -1).contiguous(), inputs.size(1))

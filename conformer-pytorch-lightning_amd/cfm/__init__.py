@@ -32,7 +32,7 @@ class GemmDesc(ctypes.Structure):
                 ("a_dtype", c_i32), ("w_dtype", c_i32), ("c_dtype", c_i32),
                 ("act", c_i32), ("alpha", ctypes.c_float),
                 ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
-                ("tile", c_i32), ("mask_mode", c_i32), ("W_frag", c_p),
+                ("tile", c_i32), ("mask_mode", c_i32),
                 ("C_pre", c_p), ("ld_pre", c_i64), ("pre_dtype", c_i32), ("aux_dtype", c_i32), ("aux", c_p), ("ld_aux", c_i64)]
 
 
@@ -69,20 +69,13 @@ class FfnDesc(ctypes.Structure):
                 ("add_x", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
-class FfnPartialDesc(ctypes.Structure):
-    _fields_ = [("x", c_p), ("py0", c_p), ("py1", c_p), ("pb2", c_p), ("pln_g", c_p), ("pln_b", c_p), ("head_a", c_p), ("head_w", c_p),
-                ("head_b", c_p), ("head_mask", c_p), ("x_out", c_p), ("ln_g", c_p), ("ln_b", c_p), ("w1f", c_p), ("w2f", c_p), ("b1", c_p),
-                ("y0", c_p), ("y1", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32), ("w_dtype", c_i32), ("palpha", ctypes.c_float),
-                ("eps", ctypes.c_float)]
-
-
 class RowChainDesc(ctypes.Structure):
-    _fields_ = [("x", c_p), ("py0", c_p), ("py1", c_p), ("pb2", c_p), ("pln_g", c_p), ("pln_b", c_p), ("head_a", c_p), ("head_w", c_p), ("head_b", c_p), ("head_res", c_p), ("head_mask", c_p),
+    _fields_ = [("x", c_p), ("head_a", c_p), ("head_w", c_p), ("head_b", c_p), ("head_res", c_p), ("head_mask", c_p),
                 ("ln_g", c_p), ("ln_b", c_p), ("ln_mask", c_p), ("w1f", c_p), ("w2n", c_p), ("b1", c_p), ("b2", c_p),
                 ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p), ("ln2_b", c_p), ("out_f32", c_p), ("out16", c_p),
                 ("tail_w", c_p), ("tail_b", c_p), ("tail_out", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32),
                 ("tail_N", c_i32), ("tail_glu", c_i32), ("w_dtype", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float),
-                ("palpha", ctypes.c_float), ("out2_f32", c_p), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32)]
+                ("out2_f32", c_p), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32)]
 
 
 _LAYER_W_FIELDS = [
@@ -98,14 +91,14 @@ class LayerWeights(ctypes.Structure):
 
 
 class LayerScratch(ctypes.Structure):
-    _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw", "xs2", "yp0", "yp1", "yq0", "yq1")]
+    _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw")]
 
 
 class LayerIO(ctypes.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("FF", c_i32), ("ktaps", c_i32),
                 ("act_dtype", c_i32), ("w_dtype", c_i32),
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64),
-                ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32), ("pending_in", c_i32), ("defer_final", c_i32), ("pend_b2", c_p), ("pend_ln_g", c_p), ("pend_ln_b", c_p),
+                ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32),
                 ("pos_proj", c_p), ("pos_proj_ld", c_i64),
                 ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p), ("after_g", c_p), ("after_b", c_p), ("after_out", c_p), ("pos_shared", c_i32)]
 
@@ -135,8 +128,6 @@ def lib():
         L.cfm_ffn_fused.argtypes = [ctypes.POINTER(FfnDesc), c_p]
         L.cfm_rowchain.argtypes = [ctypes.POINTER(RowChainDesc), c_p]
         L.cfm_rowchain_supported.argtypes = [c_i32, c_i32]
-        L.cfm_ffn_partial.argtypes = [ctypes.POINTER(FfnPartialDesc), c_p]
-        L.cfm_ffn_partial_supported.argtypes = [c_i32, c_i32]
         L.cfm_layernorm.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, ctypes.c_float, c_i64, c_i32, c_p]
         L.cfm_kv_cache_pack.argtypes = [c_p, c_i32, c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_dwconv_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
@@ -175,7 +166,7 @@ def lib():
         L.cfm_prof_collect.restype = ctypes.c_int
         L.cfm_prof_entry.argtypes = [c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_ffn_partial", "cfm_ffn_partial_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma",
+        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",

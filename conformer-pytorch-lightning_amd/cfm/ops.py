@@ -6,9 +6,9 @@ import torch
 
 import cfm as _c
 
-__all__ = ["gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
+__all__ = ["set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
            "ctc_nll_train", "ctc_grad", "adam_step", "sumsq", "scratch_stats",
-           "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "ffn_partial", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
+           "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -47,7 +47,7 @@ def scratch_stats():
 
 
 def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, residual=None, alpha=1.0, row_mask=None,
-         mask_mode=0, conv=None, tile=0, n_out=None, w_frag=None, pre_out=None, aux=None):
+         mask_mode=0, conv=None, tile=0, n_out=None, pre_out=None, aux=None):
     """out = epilogue(a[M,K] . w[N,K]^T); see include/cfm.h cfm_gemm.  conv=(C,T1,F1,T2,F2,M) selects the implicit
     3x3/stride-2 convolution over a channels-last image `a` of shape [B,T1,F1,C]."""
     _c.require_hip(a, w, bias, w_lo, out, residual, row_mask)
@@ -85,11 +85,6 @@ def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, 
         raise ValueError("cfm.gemm: row_mask must be contiguous uint8 [M]")
     if w_lo is not None and (w_lo.shape != w.shape or w_lo.dtype != w.dtype or not w_lo.is_contiguous()):
         raise ValueError("cfm.gemm: w_lo must match w")
-    if w_frag is not None:
-        _c.require_hip(w_frag)
-        if w_frag.dtype != w.dtype or w_frag.numel() < N * K:
-            raise ValueError("cfm.gemm: w_frag must be the fragment-major pack of w")
-        d.W_frag = _c.ptr(w_frag)
     if pre_out is not None:                      # training: acc + bias before the activation, all N columns
         _c.require_hip(pre_out)
         pre_out = _rows2d(pre_out, "gemm(pre_out)")
@@ -146,26 +141,8 @@ def rowchain_supported(D, FF, prec):
     return (not prec.split) and bool(_c.lib().cfm_rowchain_supported(D, FF))
 
 
-def ffn_partial(x, ln, w1f, w2f, b1, FF, y0, y1, pending=None, head=None, x_out=None, eps=1e-5):
-    """Partial feed-forward over FF halves on 64-row tiles (include/cfm.h cfm_ffn_partial): writes y0, y1 (f32 [M,D]).
-    pending = (py0, py1, pb2, palpha, pln | None);  head = (a16, w_frag, bias, mask | None)."""
-    _c.require_hip(x, w1f, w2f, b1, y0, y1, x_out)
-    M, D = x.shape
-    d = _c.FfnPartialDesc()
-    d.x, d.ln_g, d.ln_b, d.w1f, d.w2f, d.b1, d.y0, d.y1, d.x_out = (_c.ptr(x), _c.ptr(ln[0]), _c.ptr(ln[1]), _c.ptr(w1f), _c.ptr(w2f),
-                                                                     _c.ptr(b1), _c.ptr(y0), _c.ptr(y1), _c.ptr(x_out))
-    if pending is not None:
-        d.py0, d.py1, d.pb2, d.palpha = _c.ptr(pending[0]), _c.ptr(pending[1]), _c.ptr(pending[2]), pending[3]
-        if pending[4] is not None:
-            d.pln_g, d.pln_b = _c.ptr(pending[4][0]), _c.ptr(pending[4][1])
-    if head is not None:
-        d.head_a, d.head_w, d.head_b, d.head_mask = _c.ptr(head[0]), _c.ptr(head[1]), _c.ptr(head[2]), _c.ptr(head[3])
-    d.M, d.D, d.FF, d.w_dtype, d.eps = M, D, FF, _c.dt_code(w1f), eps
-    _c.check(_c.lib().cfm_ffn_partial(ctypes.byref(d), _c.stream()), "cfm_ffn_partial")
-
-
 def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, alpha=1.0, ln1=None, ln2=None, out_f32=None, out16=None,
-             tail=None, eps=1e-5, pending=None, dw=None):
+             tail=None, eps=1e-5, dw=None):
     """One-launch row-local chain (include/cfm.h cfm_rowchain).
     dw = (taps f32 [D,15], bias, bn_scale, bn_shift, T): depthwise conv + BatchNorm + SiLU applied to the head input first;
     head = (a16 [M,D], w_frag, bias, residual f32 [M,D], out_mask u8 [M] | None);  ffn = (w1f, w2n, b1, b2, FF) with
@@ -187,10 +164,6 @@ def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, a
         d.w1f, d.w2n, d.b1, d.b2, d.FF = _c.ptr(ffn[0]), _c.ptr(ffn[1]), _c.ptr(ffn[2]), _c.ptr(ffn[3]), ffn[4]
     if tail is not None:
         d.tail_w, d.tail_b, d.tail_N, d.tail_glu, d.tail_out = _c.ptr(tail[0]), _c.ptr(tail[1]), tail[2], 1 if tail[3] else 0, _c.ptr(tail[4])
-    if pending is not None:                     # (py0, py1, pb2, palpha, pln | None): finish a partial FFN while loading the rows
-        d.py0, d.py1, d.pb2, d.palpha = _c.ptr(pending[0]), _c.ptr(pending[1]), _c.ptr(pending[2]), pending[3]
-        if pending[4] is not None:
-            d.pln_g, d.pln_b = _c.ptr(pending[4][0]), _c.ptr(pending[4][1])
     if dw is not None:
         _c.require_hip(*dw[:4])
         d.dw_w, d.dw_b, d.dw_scale, d.dw_shift, d.dw_T, d.dw_K = _c.ptr(dw[0]), _c.ptr(dw[1]), _c.ptr(dw[2]), _c.ptr(dw[3]), dw[4], dw[0].shape[1]
@@ -415,6 +388,15 @@ def prof_table():
 # ----------------------------------------------------------------------------------------------------------------------
 # training (include/cfm.h "Training"): thin wrappers, outputs allocated here, workspaces from the per-stream arena
 # ----------------------------------------------------------------------------------------------------------------------
+_deterministic = [False]
+
+
+def set_deterministic(on=True):
+    """Bitwise-reproducible gradients: the weight-gradient GEMM then runs ONE workgroup per output tile over all M rows (no split-M
+    atomics, whose arrival order varies from run to run).  Slower on small batches; for tests and debugging."""
+    _deterministic[0] = bool(on)
+
+
 def gemm_tn(a, b, out=None, want_colsum=False, row_mask=None, alpha=1.0, conv=None, split=False, splits=0, mma_code=_c.BF16, accumulate=False,
             colsum=None):
     """C[N,K] (+)= alpha * a[M,N]^T . b[M,K]  (f32) and optionally colsum[N] = alpha * sum_m a[m,:]: the weight / bias gradient of a
@@ -452,7 +434,7 @@ def gemm_tn(a, b, out=None, want_colsum=False, row_mask=None, alpha=1.0, conv=No
     d.lda, d.ldc = a.stride(0), out.stride(0)
     d.M, d.N, d.K = M, N, K
     d.a_dtype, d.b_dtype, d.mma_dtype = _c.dt_code(a), _c.dt_code(b), mma_code
-    d.split, d.accumulate, d.splits, d.alpha = 1 if split else 0, 1 if accumulate else 0, splits, alpha
+    d.split, d.accumulate, d.splits, d.alpha = 1 if split else 0, 1 if accumulate else 0, (1 if _deterministic[0] else splits), alpha
     _c.check(_c.lib().cfm_gemm_tn(ctypes.byref(d), _c.stream()), "cfm_gemm_tn")
     return out, colsum
 

@@ -78,36 +78,13 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     // ---- 6-launch path: the three row-local chains of rowchain.hip -----------------------------------------------------
     const bool chains = !c.split && w->ffm_w1f && w->ffm_w2n && w->ff_w1f && w->ff_w2n && w->qkv_wf && w->out_wf && w->pw1_wf &&
                         w->pw2_wf && cfm_rowchain_supported(D, FF);
-    // ---- partial-FFN pipeline (ffnpart.hip): each CU streams HALF of an FFN's weights for 64 rows ---------------------
-    const bool parts = chains && w->ffm_w2f && w->ff_w2f && s->xs2 && s->yp0 && s->yp1 && s->yq0 && s->yq1 && cfm_ffn_partial_supported(D, FF);
-    CFM_CHECK_ARG(!io->after_out || (!parts && io->after_g && io->after_b), "encoder layer: after_out needs after_g / after_b and is not available in the partial-FFN pipeline");
+    CFM_CHECK_ARG(!io->after_out || (io->after_g && io->after_b), "encoder layer: after_out needs after_g / after_b");
     // after_out outside the chain path: one more LayerNorm launch at the end (same result, nothing fused)
     auto after_tail = [&]() -> int {
         if (!io->after_out) return CFM_OK;
         return cfm_layernorm(x_out, io->after_g, io->after_b, io->after_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, eps, M, D, stream);
     };
-    CFM_CHECK_ARG(!io->pending_in || parts, "encoder layer: pending_in needs the partial-FFN pipeline (scratch slabs)");
-    CFM_CHECK_ARG(!io->defer_final || parts, "encoder layer: defer_final needs the partial-FFN pipeline (scratch slabs)");
-    if (parts) {
-        // A: (finish the previous block's FFN + norm_final ->) LN_ffm -> macaron FFN partial sums
-        cfm_ffn_partial_desc pa = {};
-        if (io->pending_in) {
-            CFM_CHECK_ARG(io->pend_b2 && io->pend_ln_g && io->pend_ln_b, "encoder layer: pending_in needs pend_b2 / pend_ln_*");
-            pa.x = s->xs2; pa.py0 = s->yp0; pa.py1 = s->yp1; pa.pb2 = io->pend_b2; pa.pln_g = io->pend_ln_g; pa.pln_b = io->pend_ln_b;
-            pa.palpha = 0.5f; pa.x_out = x_out;
-        } else {
-            pa.x = x_in;
-        }
-        pa.ln_g = w->ln_ffm_g; pa.ln_b = w->ln_ffm_b; pa.w1f = w->ffm_w1f; pa.w2f = w->ffm_w2f; pa.b1 = w->ffm_b1; pa.y0 = s->yq0; pa.y1 = s->yq1;
-        pa.M = M; pa.D = D; pa.FF = FF; pa.w_dtype = c.w_dt; pa.eps = eps;
-        CFM_TRY(cfm_ffn_partial(&pa, stream));
-        // B: x1 = x + 1/2 (Y0 + Y1 + b2) -> LN_mha -> fused QKV
-        cfm_rowchain_desc m = {};
-        m.x = io->pending_in ? x_out : x_in; m.py0 = s->yq0; m.py1 = s->yq1; m.pb2 = w->ffm_b2; m.palpha = 0.5f;
-        m.ln_g = w->ln_mha_g; m.ln_b = w->ln_mha_b; m.out_f32 = x_out; m.tail_w = w->qkv_wf; m.tail_b = w->qkv_b; m.tail_out = s->qkv;
-        m.M = M; m.D = D; m.FF = FF; m.tail_N = 3 * D; m.tail_glu = 0; m.w_dtype = c.w_dt; m.alpha = 1.0f; m.eps = eps;
-        CFM_TRY(cfm_rowchain(&m, stream));
-    } else if (chains) {
+    if (chains) {
         cfm_rowchain_desc m = {};
         m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2n = w->ffm_w2n; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
         m.ln2_g = w->ln_mha_g; m.ln2_b = w->ln_mha_b; m.out_f32 = x_out; m.tail_w = w->qkv_wf; m.tail_b = w->qkv_b; m.tail_out = s->qkv;
@@ -119,7 +96,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
                            FF % 32 == 0 && FF <= 2048;
 
     // (1) macaron feed-forward: x1 = x + 1/2 W2 silu(W1 LN(x));  (2a) norm_mha
-    if (chains || parts) {
+    if (chains) {
         // done above, together with the QKV projection
     } else if (fused_ffn) {
         CFM_TRY(ffn_fused(c, x_in, w->ln_ffm_g, w->ln_ffm_b, w->ffm_w1f, w->ffm_w2f, w->ffm_b1, w->ffm_b2, nullptr, nullptr,
@@ -169,24 +146,10 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         ci.ln_mask = io->pad_valid; ci.out_f32 = x_out; ci.tail_w = w->pw1_wf; ci.tail_b = w->pw1_b; ci.tail_out = s->glu;
         ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
         CFM_TRY(cfm_rowchain(&ci, stream));
-        // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise, and for the partial pipeline, on its own
-        const bool dw_fused = !parts && io->ktaps == 15;
+        // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own
+        const bool dw_fused = io->ktaps == 15;
         if (!dw_fused)
             CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
-        if (parts) {
-            // D: pointwise-conv-2 + pad mask + residual -> (rows to xs2) -> LN_ff -> FFN partial sums
-            cfm_ffn_partial_desc pd = {};
-            pd.x = x_out; pd.head_a = s->dw; pd.head_w = w->pw2_wf; pd.head_b = w->pw2_b; pd.head_mask = io->pad_valid; pd.x_out = s->xs2;
-            pd.ln_g = w->ln_ff_g; pd.ln_b = w->ln_ff_b; pd.w1f = w->ff_w1f; pd.w2f = w->ff_w2f; pd.b1 = w->ff_b1; pd.y0 = s->yp0; pd.y1 = s->yp1;
-            pd.M = M; pd.D = D; pd.FF = FF; pd.w_dtype = c.w_dt; pd.eps = eps;
-            CFM_TRY(cfm_ffn_partial(&pd, stream));
-            if (io->defer_final) return CFM_OK;            // the next block's kernel A (or the driver) finishes it
-            // E: out = norm_final( xs2 + 1/2 (Y0 + Y1 + b2) )
-            cfm_rowchain_desc fe = {};
-            fe.x = s->xs2; fe.py0 = s->yp0; fe.py1 = s->yp1; fe.pb2 = w->ff_b2; fe.palpha = 0.5f; fe.pln_g = w->ln_final_g; fe.pln_b = w->ln_final_b;
-            fe.out_f32 = x_out; fe.M = M; fe.D = D; fe.FF = FF; fe.w_dtype = c.w_dt; fe.alpha = 1.0f; fe.eps = eps;
-            return cfm_rowchain(&fe, stream);
-        }
         // final chain: pointwise-conv-2 + pad mask + residual -> LN_ff -> FFN -> +res -> LN_final, in place on x_out
         cfm_rowchain_desc fi = {};
         fi.head_a = dw_fused ? s->glu : s->dw; fi.head_w = w->pw2_wf;

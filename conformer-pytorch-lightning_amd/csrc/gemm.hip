@@ -30,7 +30,6 @@ struct GemmArgs {
     const void* A;
     const u16* W;
     const u16* Wlo;
-    const u16* Wf;   // optional fragment-major weights: the W operand then goes global -> VGPR in MFMA layout, not through LDS
     const float* bias;
     const float* res;
     const uint8_t* mask;
@@ -46,7 +45,7 @@ struct GemmArgs {
     int convC, T1, F1, T2, F2;
 };
 
-template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV, bool WDIR = false>
+template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV>
 __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   // two workgroups per CU: <= 256 registers per wavefront
     constexpr int CPR = BK / 8;      // 16-byte chunks per LDS row
     constexpr int RPP = 256 / CPR;   // tile rows staged per pass of the 256 threads
@@ -56,15 +55,9 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     constexpr int FN = BN / 32;      // 16-col fragments per wave along N
     constexpr int RPB = 16 / CPR;    // LDS rows per 256-byte bank row
     constexpr int A_PLANE = BM * CPR;
-    // WDIR: weights are read straight from a fragment-major pack (one wavefront-load = one MFMA A fragment), so only the
-    // activation tile is staged.  Per K tile a workgroup then writes 16 KB into LDS instead of 32 and reads 32 KB back instead of
-    // 64 -- the LDS pipe, not the MFMA, was what a 128x128 tile kept busy (670 cycles of LDS traffic per 512 of MFMA).
-    // MEASURED SLOWER on the front-end (conv2 250 -> 280 us, linear 51 -> 64 us): a wavefront now issues 8 more 1 KB global loads per
-    // K tile at ~64 clk each, and with one or two wavefronts per SIMD that issue time is on the critical path.  Kept as an opt-in
-    // (cfm_gemm_desc.W_frag; bit-identical to the LDS-staged kernel, tests/test_ops_gpu.py), not used by the modules.
-    constexpr int W_PLANE = WDIR ? 0 : BN * CPR;
-    constexpr int KSB = BK / 32;     // 32-wide k slices per K tile
-    static_assert(!WDIR || (!SPLIT && !A_F32), "direct weights: 16-bit operands, no hi/lo split");
+    // (Reading the weight operand straight from a fragment-major pack, only A through LDS, was built and measured slower on the front-end --
+    // conv2 250 -> 280 us: 8 more 1 KB global loads per K tile and wavefront at ~64 clk of issue each.  scripts/experiments/README.md.)
+    constexpr int W_PLANE = BN * CPR;
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int BUF = (A_PLANE + W_PLANE) * NPL;
     static_assert(!SPLIT || A_F32, "split mode reads f32 activations");
@@ -127,11 +120,10 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
 
     // register prefetch ring: PF K-tiles in flight per workgroup.  The K loops here are SHORT (4 tiles at K=256) and the
     // grids small (250-1000 workgroups on 256 CUs), so occupancy cannot hide global-load latency; depth has to.
-    constexpr int PF = (A_F32 || WDIR) ? 2 : 3;
+    constexpr int PF = A_F32 ? 2 : 3;
     u32x4 ra[PF][A_F32 ? 1 : ACH];
     f32x4 fa[PF][A_F32 ? ACH : 1][2];
-    u32x4 rw[PF][WDIR ? 1 : WCH];
-    u32x4 wdr[2][WDIR ? FN * KSB : 1];   // direct weights: this K tile's fragments and the next one's
+    u32x4 rw[PF][WCH];
     u32x4 rwl[PF][SPLIT ? WCH : 1];
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
@@ -161,29 +153,10 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
                 ra[S][i] = kv ? *(const u32x4*)((const u16*)g.A + (a_off[i] + koff)) : z4;
             }
         }
-        if constexpr (!WDIR) {
 #pragma unroll
-            for (int j = 0; j < WCH; ++j) {
-                rw[S][j] = kv ? *(const u32x4*)(g.W + (w_off[j] + (unsigned)k0)) : z4;
-                if constexpr (SPLIT) rwl[S][j] = kv ? *(const u32x4*)(g.Wlo + (w_off[j] + (unsigned)k0)) : z4;
-            }
-        }
-    };
-
-    const int KS = g.K / 32;
-    auto wload = [&](int kt, auto slot_c) {            // WDIR: the FN x KSB weight fragments of K tile kt for this wavefront
-        constexpr int S = decltype(slot_c)::value;
-        const u32x4* wf = (const u32x4*)g.Wf + lane;
-        const int nfr_max = g.N / 16 - 1;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            int nfr = (n0 + wc * (BN / 2) + j * 16) >> 4;
-            nfr = nfr < nfr_max ? nfr : nfr_max;            // columns past N: any valid fragment (their outputs are not stored)
-#pragma unroll
-            for (int kk = 0; kk < KSB; ++kk) {
-                const int ks = kt * KSB + kk;
-                wdr[S][j * KSB + kk] = ks < KS ? wf[((int64_t)nfr * KS + ks) * 64] : z4;
-            }
+        for (int j = 0; j < WCH; ++j) {
+            rw[S][j] = kv ? *(const u32x4*)(g.W + (w_off[j] + (unsigned)k0)) : z4;
+            if constexpr (SPLIT) rwl[S][j] = kv ? *(const u32x4*)(g.Wlo + (w_off[j] + (unsigned)k0)) : z4;
         }
     };
 
@@ -205,13 +178,11 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
                 As[idx] = ra[S][i];
             }
         }
-        if constexpr (!WDIR) {
 #pragma unroll
-            for (int j = 0; j < WCH; ++j) {
-                const int idx = lds_idx(j * RPP + rl, kc);
-                Ws[idx] = rw[S][j];
-                if constexpr (SPLIT) Ws[W_PLANE + idx] = rwl[S][j];
-            }
+        for (int j = 0; j < WCH; ++j) {
+            const int idx = lds_idx(j * RPP + rl, kc);
+            Ws[idx] = rw[S][j];
+            if constexpr (SPLIT) Ws[W_PLANE + idx] = rwl[S][j];
         }
     };
 
@@ -221,8 +192,7 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf, auto wslot_c) {
-        constexpr int WS = decltype(wslot_c)::value;
+    auto compute = [&](int buf) {
         const u32x4* As = smem + buf * BUF;
         const u32x4* Ws = As + A_PLANE * NPL;
 #pragma unroll
@@ -238,13 +208,9 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                if constexpr (WDIR) {
-                    wf[j] = wdr[WS][j * KSB + kk];
-                } else {
-                    const int idx = lds_idx(wc * (BN / 2) + j * 16 + (lane & 15), c);
-                    wf[j] = Ws[idx];
-                    if constexpr (SPLIT) wfl[j] = Ws[W_PLANE + idx];
-                }
+                const int idx = lds_idx(wc * (BN / 2) + j * 16 + (lane & 15), c);
+                wf[j] = Ws[idx];
+                if constexpr (SPLIT) wfl[j] = Ws[W_PLANE + idx];
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -267,14 +233,9 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     auto body = [&](int kt, auto s) {           // tile kt lives in register slot s = kt % PF
         lstore(kt & 1, s);                       // waits (compiler-counted vmcnt) for tile kt only
         if (kt + PF < nkt) gload(kt + PF, s);    // refill the slot that was just drained
-        constexpr int S = decltype(s)::value;
-        if constexpr (WDIR) {                    // PF == 2: the register slot index is also kt & 1
-            if (kt + 1 < nkt) wload(kt + 1, std::integral_constant<int, (S + 1) & 1>{});
-        }
         __syncthreads();
-        compute(kt & 1, std::integral_constant<int, WDIR ? (S & 1) : 0>{});
+        compute(kt & 1);
     };
-    if constexpr (WDIR) wload(0, std::integral_constant<int, 0>{});
     prologue(std::integral_constant<int, 0>{});
     prologue(std::integral_constant<int, 1>{});
     if constexpr (PF > 2) prologue(std::integral_constant<int, 2>{});
@@ -587,16 +548,16 @@ namespace {
 
 constexpr int CFM_PERSIST_GRID = 512;   // two resident workgroups on each of the 256 CUs (a multiple of 8: XCD round-robin)
 
-template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV, bool WDIR = false>
+template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV>
 int launch(const GemmArgs& a, hipStream_t s, const char* name) {
     const int tiles = (((a.M - a.m_begin + BM - 1) / BM + 7) / 8) * 8 * ((a.N + BN - 1) / BN);   // M tiles padded to a multiple of 8 (XCD groups)
-    static const std::string nm = std::string(name) + (WDIR ? "_wdir_" : "_") + std::to_string(BM) + "x" + std::to_string(BN);
+    static const std::string nm = std::string(name) + "_" + std::to_string(BM) + "x" + std::to_string(BN);
     const double rows = a.M - a.m_begin;
     const double flops = 2.0 * rows * (double)a.N * a.K;  // algorithmic (the 3 passes of SPLIT are not counted)
     const double bytes = rows * a.K * (A_F32 ? 4 : 2) + (double)a.N * a.K * 2 * (SPLIT ? 2 : 1) +
                          rows * a.N * (a.c_dtype == CFM_F32 ? 4 : 2);
     CfmProfScope prof(nm.c_str(), s, flops, bytes);
-    CFM_LAUNCH((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV, WDIR>), dim3(tiles), dim3(256), 0, s, a);
+    CFM_LAUNCH((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV>), dim3(tiles), dim3(256), 0, s, a);
     return cfm_launch_status(nm.c_str());
 }
 
@@ -617,7 +578,7 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
     constexpr int BK = SPLIT ? 32 : 64;
     if constexpr (!SPLIT && !A_F32 && !CONV) {
         // persistent workgroups: plain 16-bit products whose tiles are short (K <= 1024) and many (>= 8 per resident workgroup)
-        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && !a.Wf && a.m_begin == 0 && !a.Cpre && a.act < CFM_ACT_DSILU;
+        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && a.m_begin == 0 && !a.Cpre && a.act < CFM_ACT_DSILU;
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         if (tile == 7 || (tile == 0 && plain && a.K % BK == 0 && a.K <= 1024 && t128 >= 8L * CFM_PERSIST_GRID)) {
             if (!plain || a.K % BK) return cfm_fail(CFM_ERR_ARG, "cfm_gemm: the persistent tile takes bias / SiLU / ReLU epilogues only and K %% 64 == 0");
@@ -629,10 +590,6 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
         const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
         const long t64x128 = (long)((a.M - a.m_begin + 63) / 64) * ((a.N + 127) / 128);
         tile = t128 >= 224 ? 1 : (t64x128 >= 224 ? 2 : 3);
-    }
-    if constexpr (!SPLIT && !A_F32) {            // weights straight from a fragment-major pack (big tiles only)
-        if (a.Wf && tile == 1) return launch<HT, 128, 128, BK, A_F32, SPLIT, CONV, true>(a, s, base);
-        if (a.Wf && tile == 2) return launch<HT, 64, 128, BK, A_F32, SPLIT, CONV, true>(a, s, base);
     }
     switch (tile) {
         case 1: return launch<HT, 128, 128, BK, A_F32, SPLIT, CONV>(a, s, base);
@@ -686,8 +643,6 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
                        : ((int64_t)(d->M - 1) * d->lda + d->K) < ((int64_t)1 << 31),
                   "cfm_gemm: activation operand too large for 32-bit element offsets");
     GemmArgs a;
-    CFM_CHECK_ARG(!d->W_frag || (d->K % 32 == 0 && d->N % 16 == 0), "cfm_gemm: W_frag needs K %% 32 == 0 and N %% 16 == 0");
-    a.Wf = (split || d->a_dtype == CFM_F32) ? nullptr : (const u16*)d->W_frag;
     a.A = d->A; a.W = (const u16*)d->W; a.Wlo = (const u16*)d->W_lo; a.bias = d->bias; a.res = d->residual;
     a.mask = d->row_mask; a.C = d->C; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
     a.Cpre = d->C_pre; a.ld_pre = d->ld_pre; a.pre_dtype = d->pre_dtype; a.aux = dact ? d->aux : nullptr; a.ld_aux = d->ld_aux; a.aux_dtype = d->aux_dtype;
@@ -697,7 +652,7 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     const bool a32 = d->a_dtype == CFM_F32;
     long head256 = 0;
     {   // 256 x 256 tile with LDS-DMA staging (gemm256.hip): tile id 8, or chosen by a two-line cost model when it can run
-        const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->W_frag && !d->C_pre && !dact;
+        const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->C_pre && !dact;
         Gemm256Args b;
         b.A = (const u16*)d->A; b.W = (const u16*)d->W; b.bias = d->bias; b.C = d->C; b.lda = d->lda; b.ldc = d->ldc;
         b.M = d->M; b.N = d->N; b.K = d->K; b.c_dtype = d->c_dtype; b.act = d->act;

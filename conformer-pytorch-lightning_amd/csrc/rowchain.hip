@@ -46,8 +46,6 @@
 
 struct ChainArgs {
     const float* x;           // f32 rows (no HEAD)
-    const float *py0, *py1, *pb2, *pln_g, *pln_b;   // optional reduce input (pending partial FFN of the previous kernel)
-    float palpha;
     const u16* head_a;        // 16-bit [M,D] (HEAD)
     const u16* head_w;        // fragment-major [D/16][KS][64][8]
     const float* head_b;
@@ -423,30 +421,6 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                     xres[rr][it] = c < D ? *(const f32x4*)(xs + (wave * RPW + rr) * XS_STRIDE + c) : zero4;
                 }
         }
-        if constexpr (!HEAD) {
-            if (a.py0) {                                   // pending partial FFN of the previous kernel (+ its norm_final)
-#pragma unroll
-                for (int rr = 0; rr < RPW; ++rr)
-#pragma unroll
-                    for (int it = 0; it < VPL; ++it) {
-                        const int c = (lane + 64 * it) * 4;
-                        if (c < D) {
-                            const f32x4 y = *(const f32x4*)(a.py0 + grows[rr] * D + c) + *(const f32x4*)(a.py1 + grows[rr] * D + c);
-                            xres[rr][it] += a.palpha * (y + *(const f32x4*)(a.pb2 + c));
-                        }
-                    }
-                if (a.pln_g) {
-                    f32x4 pg[VPL], pb[VPL];
-#pragma unroll
-                    for (int it = 0; it < VPL; ++it) {
-                        const int c = (lane + 64 * it) * 4;
-                        pg[it] = c < D ? *(const f32x4*)(a.pln_g + c) : zero4;
-                        pb[it] = c < D ? *(const f32x4*)(a.pln_b + c) : zero4;
-                    }
-                    rows_layernorm<RPW, VPL, D>(xres, pg, pb, a.eps, lane);
-                }
-            }
-        }
         if constexpr (!MID) {                              // no FFN here: the rows ARE the new residual stream
             if (a.out_f32) {
 #pragma unroll
@@ -725,8 +699,6 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     a.b1 = d->b1; a.b2 = d->b2; a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32;
     a.out16 = d->out16; a.out2_f32 = d->out2_f32; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M;
     a.tail_N = d->tail_N; a.out16_dtype = d->w_dtype; a.alpha = d->alpha; a.eps = d->eps;
-    a.py0 = d->py0; a.py1 = d->py1; a.pb2 = d->pb2; a.pln_g = d->pln_g; a.pln_b = d->pln_b; a.palpha = d->palpha;
-    CFM_CHECK_ARG(!d->py0 || (d->py1 && d->pb2 && !head), "cfm_rowchain: the reduce input needs both slabs and the bias, and no head");
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->w_dtype == CFM_BF16;
     const int tfrags = tail ? d->tail_N / 16 : 0;

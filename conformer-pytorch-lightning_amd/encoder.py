@@ -52,11 +52,8 @@ class ConformerEncoder(nn.Module):
         new_caches = [] if caches is not None else None
         cur, ready = x, False
         prec = cfm.resolve_precision(self)
-        handover = (self.encoders[0]._use_partial_ffn and cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
-                    bool(cfm.lib().cfm_ffn_partial_supported(self.encoder_dim, self.encoders[0].hidden_dim)))
-        pending = None
         # after_norm rides in the last block's final chain when that block runs on the row chains (one launch less)
-        fuse_after = (not handover and cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
+        fuse_after = (cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
                       self.after_norm.weight.dtype == torch.float32 and self.after_norm.eps == 1e-5)
         y_after = torch.empty_like(x) if fuse_after else None
         for i, block in enumerate(self.encoders):
@@ -68,11 +65,9 @@ class ConformerEncoder(nn.Module):
                 cache_i = caches[i:i + 1]
             pp = None if proj is None else (proj[:, i * self.encoder_dim:], proj.stride(0))
             out, nc = block.fused_forward(cur, attn_mask, pos_embed, pad_mask, cache_i, xn_ready=ready, next_norm=nxt,
-                                          out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pending=pending,
-                                          defer_final=handover and i + 1 < n, pos_shared=pos_shared,
+                                          out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pos_shared=pos_shared,
                                           after=(self.after_norm.weight.detach(), self.after_norm.bias.detach(), y_after)
                                           if fuse_after and i + 1 == n else None)
-            pending = block.pending_handover(prec) if handover and i + 1 < n else None
             if new_caches is not None:
                 new_caches.append(nc[:, :, keep_from:, :])
             cur, ready = out, nxt is not None
@@ -144,7 +139,7 @@ class ConformerEncoder(nn.Module):
         y, _ = self._run_blocks(x, attn_mask, pos_embed, pad_mask, None, 0)
         return y.to(inputs.dtype), pad_mask
 
-    def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None):
+    def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None, abs_rows=None):
         if self.training:
             raise NotImplementedError("ConformerEncoder.forward_chunk: streaming is inference-only; call .eval()")
         """One streaming step.  Batch 1 as in the reference: attn_cache (L,H,Tc,2dk) or empty; returns (chunk output, new attn
@@ -159,7 +154,10 @@ class ConformerEncoder(nn.Module):
         dev = inputs.device
         attn_cache = attn_cache.to(dev)
         x = self.embed.embed_frames(inputs, cmvn)
-        x, _ = self.position_encoding(x, offset)
+        if abs_rows is not None:                    # absolute encoding, rows in a caller-owned buffer (StreamingSession)
+            x, _ = self.position_encoding(x, offset, rows=abs_rows)
+        else:
+            x, _ = self.position_encoding(x, offset)
         batched = inputs.size(0) > 1
         have = attn_cache.dim() == (5 if batched else 4) and attn_cache.size(0) > 0
         if batched and attn_cache.dim() == 4 and attn_cache.size(0) > 0:
@@ -219,6 +217,20 @@ class StreamingSession:
         self.offset = 0
         self.cache = None
         self.graph = None
+        self.relative = isinstance(encoder.position_encoding, RelativePositionalEncoding)
+
+    def _weights_signature(self):
+        """changes whenever a parameter / buffer of the encoder is updated in place, replaced or repacked: a captured graph holds raw
+        pointers to the PACKED weights of that moment, so it must be re-captured then."""
+        from cfm import packing
+        sig = packing._EPOCH[0]
+        for t in list(self.enc.parameters()) + list(self.enc.buffers()):
+            sig = sig * 1000003 + t._version + (t.data_ptr() & 0xFFFFF)
+        return sig & ((1 << 62) - 1), str(cfm.resolve_precision(self.enc))
+
+    def _abs_rows(self, batch, dev):
+        pe = self.enc.position_encoding._table_like(torch.empty(0, device=dev, dtype=torch.float32))
+        return pe[self.offset: self.offset + batch]
 
     def step(self, frames):
         """frames (B, window, F) on the GPU -> (B, chunk, D)."""
@@ -226,6 +238,8 @@ class StreamingSession:
             raise ValueError("StreamingSession.step wants windows of %d frames" % self.window)
         dev = frames.device
         empty = torch.zeros((0, 0, 0, 0), device=dev)
+        if self.graph is not None and self._weights_signature() != self._sig:
+            self.cache, self.graph = self.kv.clone(), None            # weights changed under the captured graph: back to eager, re-capture
         if self.graph is None:
             cache = self.cache if self.cache is not None else empty
             y, self.cache, _ = self.enc.forward_chunk(frames, self.offset, self.need, cache, empty)
@@ -235,6 +249,8 @@ class StreamingSession:
             return y
         self.x.copy_(frames)
         self.pos.copy_(self.enc.embed.position_encoding(offset=self.offset - self.need, size=self.need + self.chunk))
+        if not self.relative:
+            self.abs.copy_(self._abs_rows(frames.size(0), dev))
         self.graph.replay()
         self.offset += self.chunk
         return self.y
@@ -245,14 +261,18 @@ class StreamingSession:
         self.x = frames.clone()
         self.kv = self.cache.clone()
         self.pos = enc.embed.position_encoding(offset=self.offset - self.need, size=self.need + self.chunk).clone()
+        # absolute encoding (use_relative=False): the table rows added to the chunk live in a static buffer too -- sliced at `offset`
+        # inside the captured region they would be frozen at the capture step's offset
+        self.abs = None if self.relative else self._abs_rows(frames.size(0), dev).clone()
+        self._sig = self._weights_signature()
         stream = torch.cuda.Stream(device=dev)
         stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), torch.cuda.stream(stream):
-            enc.forward_chunk(self.x, self.offset, self.need, self.kv, empty, pos_rows=self.pos)      # sizes the scratch arena
+            enc.forward_chunk(self.x, self.offset, self.need, self.kv, empty, pos_rows=self.pos, abs_rows=self.abs)      # sizes the scratch arena
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                y, new_kv, _ = enc.forward_chunk(self.x, self.offset, self.need, self.kv, empty, pos_rows=self.pos)
+                y, new_kv, _ = enc.forward_chunk(self.x, self.offset, self.need, self.kv, empty, pos_rows=self.pos, abs_rows=self.abs)
                 self.kv.copy_(new_kv)
             self.y = y
         torch.cuda.current_stream(dev).wait_stream(stream)

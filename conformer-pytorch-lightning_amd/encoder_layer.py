@@ -11,7 +11,6 @@ epilogue, and LayerNorm writing the next GEMM's operand dtype directly.  The chi
 convolution) only own the parameters here; called on their own they run the same kernels op by op.
 """
 import ctypes
-import os
 
 import torch
 import torch.nn as nn
@@ -43,18 +42,11 @@ class ConformerEncoderLayer(nn.Module):
         self.use_relative = bool(use_relative)
         self.encoder_dim, self.hidden_dim, self.num_heads, self.kernel_size = encoder_dim, hidden_dim, num_heads, kernel_size
         self.return_cache = True           # the reference always materialises cat(k,v) (attention.py:76)
-        # 64-row x FF-half feed-forward pipeline (ffnpart.hip).  Correct and tested, but measured no faster end to end than the
-        # 32-row chain kernels at config 2, so it is opt-in: CFM_PARTIAL_FFN=1.
-        self._use_partial_ffn = os.environ.get("CFM_PARTIAL_FFN", "0") == "1"
         self._fused = None                 # (key, LayerWeights, keepalive)
 
     def _apply(self, fn, *a, **kw):        # .to() / .cuda() / .half(): drop every packed copy
         self._fused = None
         return super()._apply(fn, *a, **kw)
-
-    def pending_handover(self, prec):
-        """What the NEXT block needs to finish this block's last feed-forward: (w_2.bias as packed f32, norm_final)."""
-        return packing.pack_ffn(self.feed_forward, prec).b2, self.norm_final
 
     def _weights(self, prec):
         # the tensor list is rebuilt on every call: replacing a Parameter OBJECT (layer.norm_ff.weight = nn.Parameter(...), pruning /
@@ -67,7 +59,7 @@ class ConformerEncoderLayer(nn.Module):
         return self._fused[1]
 
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
-                      want_cache=True, pos_proj=None, pending=None, defer_final=False, pos_shared=False, after=None):
+                      want_cache=True, pos_proj=None, pos_shared=False, after=None):
         """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified."""
         _inference_only(self, "ConformerEncoderLayer.fused_forward")
         cfm.require_hip(x)
@@ -114,12 +106,6 @@ class ConformerEncoderLayer(nn.Module):
         s.ctx = cfm.scratch("ctx", M * D, adt, dev).data_ptr()
         s.glu = cfm.scratch("glu", M * D, adt, dev).data_ptr()
         s.dw = cfm.scratch("dw", M * D, adt, dev).data_ptr()
-        if cfm.rowchain_supported(D, FF, prec) and bool(cfm.lib().cfm_ffn_partial_supported(D, FF)) and self._use_partial_ffn:
-            for tag in ("xs2", "yp0", "yp1", "yq0", "yq1"):          # f32 rows / partial slabs of the partial-FFN pipeline
-                setattr(s, tag, cfm.scratch(tag, M * D, torch.float32, dev).data_ptr())
-        elif pending is not None or defer_final:
-            raise RuntimeError("chained feed-forward hand-over needs the partial-FFN pipeline")
-
         io = cfm.LayerIO()
         io.B, io.T, io.D, io.H, io.FF, io.ktaps = B, T, D, H, FF, self.kernel_size
         io.act_dtype, io.w_dtype = prec.act_code, prec.w_code
@@ -133,11 +119,6 @@ class ConformerEncoderLayer(nn.Module):
         if after is not None:                          # (gain, bias, f32 output [B,T,D]): the encoder's after_norm in the final chain
             io.after_g, io.after_b, io.after_out = after[0].data_ptr(), after[1].data_ptr(), after[2].data_ptr()
         io.new_cache = cfm.ptr(new_cache)
-        if pending is not None:                        # (w_2.bias f32, norm_final) of the PREVIOUS block: its last FFN is unfinished
-            io.pending_in = 1
-            io.pend_b2, io.pend_ln_g, io.pend_ln_b = pending[0].data_ptr(), pending[1].weight.data_ptr(), pending[1].bias.data_ptr()
-        io.defer_final = 1 if defer_final else 0
-
         if out is None:
             out = torch.empty_like(x)
         ng = nb = None

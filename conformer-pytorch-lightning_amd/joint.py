@@ -63,7 +63,7 @@ class TransducerJoint(nn.Module):
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("TransducerJoint: backward is not built yet (forward only)")
         cfm.require_hip(enc_out, pred_out)
-        prec = cfm.get_precision()
+        prec = cfm.resolve_precision(self)
         pk = self._weights(prec)
         B, T, e = self._rows(enc_out, 2, "enc_out")
         Bp, U, p = self._rows(pred_out, 1, "pred_out")

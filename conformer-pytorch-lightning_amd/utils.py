@@ -5,8 +5,10 @@ The mask half is on the hot path:
   subsequent_chunk_mask  utils.py:96-111  -> one launch of cfm_chunk_mask instead of a T'-iteration python loop of
                                              slice assignments (T' tiny kernels per forward in the reference)
   make_attn_mask         utils.py:115-160 -> same selector logic, host RNG draws kept (torch.randint(...).item())
-The label helpers below them are host-side data preparation, outside the accelerated path; they are provided so the
-module can stand in for the reference's ``utils`` when this directory shadows it on sys.path.
+The reference's label helpers (pad_list, load_vocabs, add_blank, add_sos_eos, reverse_sequence: utils.py:31-81,171-190) are host-side
+label preparation, OUT OF SCOPE for this build and deliberately not provided: a deployment keeps the reference's own
+``utils.py`` for them and takes only the three mask builders from here.  ``load_cmvn`` stays: GlobalCMVN
+(cmvn.py) is on the path's "next" list and is folded into the first convolution.
 """
 import json
 import math
@@ -53,7 +55,7 @@ def make_attn_mask(inputs, inputs_pad_mask, use_dynamic_chunk, use_dynamic_left_
     return inputs_pad_mask
 
 
-# ------------------------------------------------------------------------------------------- host-side helpers
+# ------------------------------------------------------------------------------------------- global CMVN statistics (cmvn.py)
 def load_cmvn(json_cmvn_file):
     """Kaldi-style accumulated stats {mean_stat, var_stat, frame_num} -> (mean, 1/std) float tensors."""
     with open(json_cmvn_file) as f:
@@ -65,45 +67,3 @@ def load_cmvn(json_cmvn_file):
         var = max(second / n - mu * mu, 1.0e-20)
         istd.append(1.0 / math.sqrt(var))
     return torch.tensor(mean), torch.tensor(istd)
-
-
-def pad_list(xs, pad_value):
-    """List of (T_i, *) tensors -> (B, T_max, *) padded with pad_value."""
-    longest = max(x.size(0) for x in xs)
-    out = xs[0].new_full((len(xs), longest) + tuple(xs[0].shape[1:]), pad_value)
-    for row, x in zip(out, xs):
-        row[:x.size(0)] = x
-    return out
-
-
-def load_vocabs(vocab_path):
-    table = {}
-    with open(vocab_path) as f:
-        for line in f:
-            token, idx = line.strip().split(' ')
-            table[token] = int(idx)
-    return table, len(table)
-
-
-def add_blank(targets, blank, ignore_id):
-    """Prepend a blank column and turn padding (ignore_id) into blank."""
-    lead = torch.full((targets.size(0), 1), blank, dtype=torch.long, device=targets.device)
-    out = torch.cat([lead, targets], dim=1)
-    return torch.where(out == ignore_id, blank, out)
-
-
-def make_subsequent_mask(length, device):
-    idx = torch.arange(length, device=device)
-    return idx.unsqueeze(0) <= idx.unsqueeze(1)
-
-
-def add_sos_eos(targets, sos, eos, ignore_id):
-    s = torch.tensor([sos], dtype=torch.long, device=targets.device)
-    e = torch.tensor([eos], dtype=torch.long, device=targets.device)
-    seqs = [row[row != ignore_id] for row in targets]
-    return pad_list([torch.cat([s, q]) for q in seqs], eos), pad_list([torch.cat([q, e]) for q in seqs], ignore_id)
-
-
-def reverse_sequence(targets, target_lengths, ignore_id):
-    flipped = [torch.flip(row.int()[:n], [0]) for row, n in zip(targets, target_lengths)]
-    return nn.utils.rnn.pad_sequence(flipped, True, ignore_id)

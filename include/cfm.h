@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFM_VERSION 100 /* 0.1.0 */
+#define CFM_VERSION 200 /* 0.2.0: training entry points; the partial-FFN experiment and the W_frag GEMM variant left the ABI */
 
 typedef void* cfm_stream_t;
 
@@ -94,8 +94,6 @@ typedef struct {
                                                               ReLU epilogues; auto when a cost model says its whole rounds beat the 128x128 tiles) */
     int32_t mask_mode;                                  /* 0: row_mask zeroes the OUTPUT row (after act, before residual);
                                                            1: row_mask zeroes the INPUT row (acc = 0, bias/act still apply) */
-    const void* W_frag; /* optional: the same weights fragment-major (see cfm_rowchain), K %% 32 == 0, N %% 16 == 0.  16-bit, non-split
-                           launches with a 128- or 64-row tile then read W global -> VGPR in MFMA layout and stage only A in LDS */
     /* training: */
     void* C_pre;        /* optional second output [M,N] (row stride ld_pre, pre_dtype): acc + bias BEFORE the activation -- what the
                            backward of SiLU / GLU needs (feedforward.py:18, convolution.py:42).  GLU: all N interleaved columns. */
@@ -173,7 +171,6 @@ int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Row-local chain on 32-row tiles, one launch (csrc/rowchain.hip):
  *     x  = head_a ? head_res + mask_out( head_a . Wh^T + head_b ) : x          (head_mask zeroes the product's row)
- *          or, with py0: x = LN?( x + palpha * (py0 + py1 + pb2) )  (a pending partial FFN, see cfm_ffn_partial)
  *     xn = LN(x; ln_g, ln_b), rows with ln_mask == 0 zeroed
  *     y  = w1f ? x + alpha * FFN(xn) : x                                         (FFN as in cfm_ffn_fused, SiLU)
  *     y1 = ln1_g ? LN(y) : y -> out_f32        (head without FFN: out_f32 receives x, the new residual stream)
@@ -189,7 +186,6 @@ int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
  */
 typedef struct {
     const float* x;
-    const float *py0, *py1, *pb2, *pln_g, *pln_b; /* optional reduce input: x = LN?(x + palpha*(py0+py1+pb2)), see cfm_ffn_partial */
     const void* head_a;
     const void* head_w;
     const float* head_b;
@@ -208,7 +204,7 @@ typedef struct {
     int64_t M;
     int32_t D, FF, tail_N, tail_glu;
     int32_t w_dtype;
-    float alpha, eps, palpha;
+    float alpha, eps;
     float* out2_f32; /* optional f32 [M,D]: y2 = LN2(y1) as well (ln2_g required) -- e.g. the encoder's after_norm (encoder.py:74) applied to
                         the last block's output in the same launch */
     /* optional depthwise input stage of the "final" chain (head + feed-forward, no tail): head_a is the GLU output and
@@ -221,38 +217,6 @@ typedef struct {
 int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
 /* 1 when cfm_rowchain has instances for all three chains of a block with these sizes (host query) */
 int cfm_rowchain_supported(int32_t D, int32_t FF);
-
-/* ------------------------------------------------------------------------------------------------
- * Feed-forward block as PARTIAL sums (csrc/ffnpart.hip): 2 x ceil(M/64) workgroups, workgroup (tile, half) streams one
- * half of W1/W2 for 64 rows and writes
- *     y_half[M,D] = SiLU( LN(x; ln_g, ln_b) . W1[half]^T + b1[half] ) . W2[:, half]^T                     (f32, no bias)
- * The consumer (this entry point's reduce input, or cfm_rowchain's) finishes  x + alpha * (y0 + y1 + b2).
- * Input rows x are one of
- *     plain     x (f32 [M,D])
- *     reduce    x = LN?( x + palpha * (py0 + py1 + pb2); pln_g, pln_b )     -- the previous block's pending FFN + norm_final
- *     head      x = x + mask( head_a . Wh^T + head_b )                      -- pointwise-conv-2 + pad mask + residual
- * and for reduce/head the rows are written to x_out (which must NOT alias x: two workgroups read each row tile).
- * Weights are the fragment-major packs of cfm_ffn_fused.  Instances: (D,FF) in {(256,2048), (144,576)}.
- */
-typedef struct {
-    const float* x;
-    const float *py0, *py1, *pb2, *pln_g, *pln_b;
-    const void* head_a;
-    const void* head_w;
-    const float* head_b;
-    const uint8_t* head_mask;
-    float* x_out;
-    const float *ln_g, *ln_b;
-    const void *w1f, *w2f;
-    const float* b1;
-    float *y0, *y1;
-    int64_t M;
-    int32_t D, FF, w_dtype;
-    float palpha, eps;
-} cfm_ffn_partial_desc;
-
-int cfm_ffn_partial(const cfm_ffn_partial_desc* d, cfm_stream_t stream);
-int cfm_ffn_partial_supported(int32_t D, int32_t FF);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (eps inside sqrt, biased variance), optionally two chained norms in one pass:
@@ -377,9 +341,6 @@ typedef struct {
 
 typedef struct {
     void *xn, *hid, *qkv, *pos, *ctx, *glu, *dw; /* activation-dtype scratch: [M,D],[M,FF],[M,3D],[R,D],[M,D],[M,D],[M,D] */
-    /* optional f32 [M,D] buffers of the partial-FFN pipeline (all five or none): the rows entering the block's last FFN,
-     * and two pairs of partial slabs (pending-from-previous-block, macaron) */
-    float *xs2, *yp0, *yp1, *yq0, *yq1;
 } cfm_layer_scratch;
 
 typedef struct {
@@ -391,12 +352,6 @@ typedef struct {
     const uint8_t* pad_valid; /* [B*T] or NULL */
     const float* pos_embed;   /* f32 [R,D] rows, R = B*P */
     int32_t pos_rows;         /* R (0: plain MHSA) */
-    /* partial-FFN pipeline chaining between consecutive blocks (used by the encoder driver; 0 / NULL otherwise):
-     *   pending_in   the PREVIOUS block left its last feed-forward unfinished: scratch xs2 holds its input rows, yp0/yp1 the
-     *                partial sums; pend_b2 / pend_ln_* are that block's w_2.bias and norm_final.  x_in is ignored.
-     *   defer_final  leave THIS block's last feed-forward pending in the same way (x_out then is NOT the block output). */
-    int32_t pending_in, defer_final;
-    const float *pend_b2, *pend_ln_g, *pend_ln_b;
     const void* pos_proj;     /* optional: linear_pos(pos_embed) already projected (act dtype), row stride pos_proj_ld;
                                  lets the driver project the positions of ALL blocks with one GEMM */
     int64_t pos_proj_ld;

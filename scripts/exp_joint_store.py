@@ -6,21 +6,20 @@ import torch, cfm
 M, K = 16 * 249 * 41, 512
 a = torch.randn(M, K, device="cuda").bfloat16()
 from cfm import packing
-def run(N, ldc, odt, tile=0, bias=True, wdir=False):
+def run(N, ldc, odt, tile=0, bias=True):
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
-    wf = packing.pack_frag_major(w.float(), torch.bfloat16) if wdir else None
     b = torch.randn(N, device="cuda") if bias else None
     buf = torch.empty((M, ldc), dtype=odt, device="cuda")
     for _ in range(2):
-        cfm.gemm(a, w, bias=b, out=buf[:, :N], tile=tile, w_frag=wf)
+        cfm.gemm(a, w, bias=b, out=buf[:, :N], tile=tile)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        cfm.gemm(a, w, bias=b, out=buf[:, :N], tile=tile, w_frag=wf)
+        cfm.gemm(a, w, bias=b, out=buf[:, :N], tile=tile)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print(("wdir " if wdir else "") + "N=%d ldc=%d %s tile=%d: %.1f us  %.1f TFLOP/s" % (N, ldc, str(odt).split(".")[-1], tile, ms * 1e3, 2.0 * M * N * K / ms / 1e9), flush=True)
+    print("N=%d ldc=%d %s tile=%d: %.1f us  %.1f TFLOP/s" % (N, ldc, str(odt).split(".")[-1], tile, ms * 1e3, 2.0 * M * N * K / ms / 1e9), flush=True)
 for odt in (torch.float32, torch.bfloat16):
     run(5002, 5002, odt)
     run(5004, 5004, odt)

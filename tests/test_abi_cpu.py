@@ -36,15 +36,14 @@ def test_library_exports_every_declared_symbol(cfm):
     assert len(names) >= 20 and "cfm_gemm" in names and "cfm_ffn_fused" in names and "cfm_encoder_layer_forward" in names
     for n in names:
         assert hasattr(lib, n), "libconformer_gfx950.so does not export %s" % n
-    assert lib.cfm_version() == 100
+    assert lib.cfm_version() == 200
     assert isinstance(lib.cfm_last_error(), bytes)
 
 
 def test_ctypes_structs_match_c_sizes(cfm, tmp_path):
     structs = {"cfm_gemm_desc": cfm.GemmDesc, "cfm_attn_desc": cfm.AttnDesc, "cfm_ffn_desc": cfm.FfnDesc,
                "cfm_layer_weights": cfm.LayerWeights, "cfm_layer_scratch": cfm.LayerScratch, "cfm_layer_io": cfm.LayerIO,
-               "cfm_gemm_tn_desc": cfm.GemmTnDesc, "cfm_attn_bwd_desc": cfm.AttnBwdDesc, "cfm_rowchain_desc": cfm.RowChainDesc,
-               "cfm_ffn_partial_desc": cfm.FfnPartialDesc}
+               "cfm_gemm_tn_desc": cfm.GemmTnDesc, "cfm_attn_bwd_desc": cfm.AttnBwdDesc, "cfm_rowchain_desc": cfm.RowChainDesc}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "cfm.h"\nint main(){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in structs) + "return 0;}\n")
@@ -57,7 +56,7 @@ def test_ctypes_structs_match_c_sizes(cfm, tmp_path):
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "c.c"
-    src.write_text('#include "cfm.h"\nint main(void){return CFM_VERSION == 100 ? 0 : 1;}\n')
+    src.write_text('#include "cfm.h"\nint main(void){return CFM_VERSION == 200 ? 0 : 1;}\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "c")], check=True)
 
 

@@ -1,11 +1,11 @@
 """GPU parity tests proper: the drop-in modules (HIP path through the C ABI) against
  (1) the committed golden fixtures produced by the REFERENCE itself, and
  (2) the CPU oracle on the same seeded inputs,
-in every precision mode.  Tolerances (max|d| / max|ref|):
-   fp32 ("f32-accurate", hi/lo bf16 split)   <= 1e-3   (the north-star tolerance; measured ~1e-5..1e-4)
-   fp16                                      <= 5e-3
-   bf16 (BASELINE config-2 dtype)            <= 3e-2   hard gate = the reference's own bf16 deviation (2.3e-2 over
-                                                       12 layers); measured values are printed
+in every precision mode.  Gates (max|d| / max|ref|) sit at about 1.5x what is MEASURED on MI355X, so a 2x regression fails:
+   fp32 ("f32-accurate", hi/lo bf16 split)   <= 5e-5   measured 6e-6 .. 3e-5   (north-star tolerance: 1e-3)
+   fp16                                      <= 1e-3   measured 4e-4 .. 6e-4   -- the north-star tolerance itself, at bf16 speed
+   bf16 (BASELINE config-2 dtype)            <= 1.2e-2 measured 3.7e-3 (2 layers) .. 7.7e-3 (12 layers, full size); the reference's own
+                                                       bf16 CPU run deviates 2.3e-2 from fp64 over 12 layers
 Masks / lengths: bit-exact.
 """
 import json
@@ -19,7 +19,7 @@ from conftest import check_joint_case, joint_case_inputs, load_golden
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 1e-3, "fp16": 5e-3, "bf16": 3e-2}
+TOL = {"fp32": 5e-5, "fp16": 1e-3, "bf16": 1.2e-2}
 MODES = ["bf16", "fp16", "fp32"]
 DEV = "cuda"
 
@@ -255,7 +255,7 @@ CFG2 = dict(input_dim=80, kernel_size=15, encoder_dim=256, dropout=0.1, attentio
             hidden_dim=2048, num_heads=4, encoder_num_layers=12, max_len=5000, use_relative=True)
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+@pytest.mark.parametrize("mode", MODES)
 def test_config2_full_size_against_oracle_and_properties(pkg, mode):
     """B=32 x (80 x 1000), 12-layer d=256: (a) two utterances against the CPU oracle, (b) size-independent properties."""
     from oracle import conformer_oracle as O
@@ -533,6 +533,98 @@ def test_streaming_session_graph_equals_eager(pkg, mode):
         assert sess.graph is not None and sess.offset == offset and torch.equal(sess.kv, cache)
 
 
+def test_streaming_session_absolute_positions(pkg):
+    """use_relative=False: forward_chunk adds table rows pe[offset : offset+B] to the chunk.  Inside a captured graph that slice would be
+    frozen at the capture step's offset: the session keeps the rows in a static buffer it refreshes before every replay."""
+    g, meta = load_golden("enc_cfg1_norel")
+    pkg.cfm.set_precision("bf16")
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    B, chunk, left, steps = 3, 4, 2, 8
+    hop, window, need = 4 * chunk, (chunk - 1) * 4 + 7, chunk * left
+    x = dev(synth.fbank(92, B, window + hop * steps))
+    empty = torch.zeros((0, 0, 0, 0), device=DEV)
+    sess = pkg.encoder.StreamingSession(enc, chunk, left)
+    with torch.no_grad():
+        cache, offset = empty, 0
+        for s in range(steps):
+            win = x[:, s * hop: s * hop + window].contiguous()
+            y_ref, cache, _ = enc.forward_chunk(win, offset, need, cache, empty)
+            offset += y_ref.size(1)
+            y = sess.step(win)
+            assert torch.equal(y, y_ref), (s, relerr(y, y_ref))
+    assert sess.graph is not None and not sess.relative
+
+
+def test_captured_graph_survives_arena_growth_and_weight_updates(pkg):
+    """(a) A graph captured at B = 4 keeps replaying correctly after a much larger forward has grown the scratch arena (superseded blocks
+    are retired, never freed); (b) after the weights change under it, the session notices, falls back to eager and re-captures."""
+    g, meta = load_golden("enc_cfg1_stream")
+    pkg.cfm.set_precision("bf16")
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    B, chunk, left = 4, 4, 2
+    hop, window, need = 4 * chunk, (chunk - 1) * 4 + 7, chunk * left
+    x = dev(synth.fbank(93, B, window + hop * 12))
+    empty = torch.zeros((0, 0, 0, 0), device=DEV)
+    sess = pkg.encoder.StreamingSession(enc, chunk, left)
+    with torch.no_grad():
+        cache, offset = empty, 0
+
+        def both(s):
+            nonlocal cache, offset
+            win = x[:, s * hop: s * hop + window].contiguous()
+            y_ref, cache, _ = enc.forward_chunk(win, offset, need, cache, empty)
+            offset += y_ref.size(1)
+            y = sess.step(win)
+            assert torch.equal(y, y_ref), (s, relerr(y, y_ref))
+        for s in range(4):
+            both(s)
+        assert sess.graph is not None
+        first_graph = sess.graph
+        live0, retired0, _ = pkg.cfm.scratch_stats()
+        big = dev(synth.fbank(94, 16, 600))
+        with torch.cuda.stream(torch.cuda.Stream()):                 # also on another stream: its scratch is its own
+            enc(big, torch.full((16,), 600, dtype=torch.int32, device=DEV))
+        enc(big, torch.full((16,), 600, dtype=torch.int32, device=DEV))
+        torch.cuda.synchronize()
+        for s in range(4, 7):
+            both(s)
+        assert sess.graph is first_graph                             # still the graph captured before the arena grew
+        # (b) in-place weight update: the packed weights the graph points at are stale now
+        enc.encoders[0].feed_forward.w_2.bias.add_(0.25)
+        both(7)
+        assert sess.graph is not first_graph
+        both(8)
+        both(9)
+
+
+def test_two_encoders_two_streams_two_precisions(pkg):
+    """Scratch is keyed per (device, stream) and precision is resolved per module: two encoders, one pinned to bf16 and one to fp32, run
+    concurrently on two streams and reproduce their serial results bit for bit (round 1: one global arena, one global precision)."""
+    g, meta = load_golden("enc_cfg1")
+    pkg.cfm.set_precision("fp16")                                    # the process default: neither encoder follows it
+    enc_a = build_encoder(pkg, meta["cfg"], meta["wseed"]).set_precision("bf16")
+    enc_b = build_encoder(pkg, meta["cfg"], meta["wseed"]).set_precision("fp32")
+    x = dev(synth.fbank(meta["xseed"], meta["batch"], meta["frames"]))
+    lens = torch.tensor(meta["lens"], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        ya, _ = enc_a(x, lens)
+        yb, _ = enc_b(x, lens)
+        check("pinned bf16 encoder", ya, g["y"], "bf16")
+        check("pinned fp32 encoder", yb, g["y"], "fp32")
+        assert relerr(ya, yb) > 1e-4                                  # they really ran in different modes
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = {}
+        for rep in range(6):
+            with torch.cuda.stream(s1):
+                outs["a"] = enc_a(x, lens)[0]
+            with torch.cuda.stream(s2):
+                outs["b"] = enc_b(x, lens)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(outs["a"], ya) and torch.equal(outs["b"], yb)
+    pkg.cfm.set_precision("bf16")
+
+
 def test_general_path_matches_chain_path_including_after_norm(pkg):
     """cfm_encoder_layer_forward picks the row chains when every fragment-major pack is present; with those packs withheld the same
     block runs on the general path (separate GEMMs, LayerNorm and depthwise kernels).  Both must agree, including the encoder's
@@ -584,26 +676,7 @@ def test_cpu_tensors_fail_loudly(pkg):
         layer(torch.zeros(1, 4, 16, device=DEV), torch.ones((0, 0, 0)), torch.zeros(1, 1, 16, device=DEV))
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
-def test_partial_ffn_pipeline_matches_reference(pkg, mode):
-    """The opt-in 64-row x FF-half feed-forward pipeline (ffnpart.hip, chained between blocks) on the 12-layer fixture and on
-    config 1, including the stand-alone block call (which must finish its own pending feed-forward)."""
-    pkg.cfm.set_precision(mode)
-    for name in ("enc_cfg2s", "enc_cfg1"):
-        g, meta = load_golden(name)
-        enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
-        for blk in enc.encoders:
-            blk._use_partial_ffn = True
-        x = dev(synth.fbank(meta["xseed"], meta["batch"], meta["frames"]))
-        lens = torch.tensor(meta["lens"], dtype=torch.int32, device=DEV)
-        with torch.no_grad():
-            y, m = enc(x, lens)
-            y2, _ = reference_style_forward(pkg, enc, x, lens)          # blocks called one by one: no hand-over between them
-        check(name + " partial-FFN pipeline (chained)", y, g["y"], mode)
-        check(name + " partial-FFN pipeline (stand-alone blocks)", y2, g["y"], mode)
-
-
-JOINT_TOL = {"fp32": 1e-4, "fp16": 5e-3, "bf16": 3e-2}
+JOINT_TOL = {"fp32": 3e-5, "fp16": 1e-3, "bf16": 6e-3}      # measured 7e-6 / 4e-4 / 3.4e-3
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -369,35 +369,6 @@ def test_attention_kv_cache_layout(cfm):
     assert relerr(out.float(), ref_o) < 2e-2
 
 
-@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
-@pytest.mark.parametrize("tile", [0, 1, 2])
-def test_gemm_direct_weights_match_lds_staged(cfm, wdt, tile):
-    """cfm_gemm with W_frag (weights global -> VGPR in MFMA layout, only A staged in LDS) runs the same MFMA sequence as the
-    LDS-staged kernel: bit-identical outputs, for the plain GEMM (ragged M, N not a multiple of the tile) and the implicit conv."""
-    from cfm import packing
-    dt = torch.bfloat16 if wdt == "bf16" else torch.float16
-    # plain: M ragged, K = 19 * 64, N = 256 / 144-like widths
-    for M, N, K in ((1000, 256, 1216), (333, 144, 160), (4096, 512, 512)):
-        a = rnd((M, K), 300).to(dt)
-        w = rnd((N, K), 301, K ** -0.5)
-        b = rnd((N,), 302, 0.1)
-        w16 = w.to(dt)
-        ref = cfm.gemm(a, w16, bias=b, act=cfm.ACT_RELU, out_dtype=torch.float32, tile=tile)
-        out = cfm.gemm(a, w16, bias=b, act=cfm.ACT_RELU, out_dtype=torch.float32, tile=tile, w_frag=packing.pack_frag_major(w, dt))
-        assert torch.equal(out, ref), (M, N, K)
-        assert relerr(out, torch.relu(a.float() @ w16.float().t() + b)) < (2e-2 if wdt == "bf16" else 3e-3)
-    # implicit 3x3 / stride-2 convolution over a channels-last image
-    B, T1, F1, C = 3, 41, 19, 64
-    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-    img = rnd((B, T1, F1, C), 303).to(dt)
-    w = rnd((C, 9 * C), 304, (9 * C) ** -0.5)
-    b = rnd((C,), 305, 0.1)
-    kw = dict(bias=b, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2), out_dtype=dt, tile=tile)
-    ref = cfm.gemm(img, w.to(dt), **kw)
-    out = cfm.gemm(img, w.to(dt), w_frag=packing.pack_frag_major(w, dt), **kw)
-    assert torch.equal(out, ref)
-
-
 @pytest.mark.parametrize("B,T,D,K", [(32, 249, 256, 15), (3, 37, 144, 15), (2, 5, 16, 15), (2, 40, 32, 7), (3, 61, 512, 15), (2, 33, 384, 15), (2, 20, 64, 15)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 def test_dwconv_bn_silu(cfm, B, T, D, K, dt):
@@ -635,62 +606,3 @@ def test_rowchain_depthwise_input_stage(cfm, B, T, D, FF, wdt):
         cfm.rowchain(M, D, code, x=x, ln=lns[0], out_f32=out, dw=(taps, tb, sc, sh, T))
 
 
-@pytest.mark.parametrize("M,D,FF", [(7968, 256, 2048), (98, 144, 576), (65, 256, 2048)])
-@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
-def test_ffn_partial_and_reduce(cfm, M, D, FF, wdt):
-    """Partial FFN (64-row tiles x FF halves) in its three input modes, finished by the reduce input of the next kernel."""
-    from cfm import packing
-    dt = W_DT[wdt]
-    code = cfm.BF16 if wdt == "bf16" else cfm.F16
-    F = torch.nn.functional
-    x = rnd((M, D), 120, 1.5) + 0.3
-    w1, w2 = rnd((FF, D), 121, D ** -0.5), rnd((D, FF), 122, FF ** -0.5)
-    b1, b2 = rnd((FF,), 123, 0.1), rnd((D,), 124, 0.1)
-    lns = [(1 + 0.1 * rnd((D,), 125 + i), 0.1 * rnd((D,), 129 + i)) for i in range(3)]
-    w1f, w2f = packing.pack_ffn_fragments(w1, w2, dt)
-    r16 = lambda t: t.to(dt).float()
-    lin = lambda a, w, b: r16(a) @ r16(w).t() + b
-    ln = lambda t, p: F.layer_norm(t, (D,), p[0], p[1], 1e-5)
-    ffn_nobias = lambda xn: r16(F.silu(lin(xn, w1, b1))) @ r16(w2).t()
-    tol = 8e-3 if wdt == "bf16" else 1e-3
-    y0, y1 = torch.empty_like(x), torch.empty_like(x)
-
-    # plain input; y0 + y1 == FFN without the second bias
-    x0 = x.clone()
-    cfm.ffn_partial(x, lns[0], w1f, w2f, b1, FF, y0, y1)
-    assert torch.equal(x, x0)
-    assert relerr(y0 + y1, ffn_nobias(ln(x, lns[0]))) < tol
-    ya, yb = y0.clone(), y1.clone()
-    cfm.ffn_partial(x, lns[0], w1f, w2f, b1, FF, y0, y1)
-    assert torch.equal(ya, y0) and torch.equal(yb, y1)                       # reproducible
-
-    # consumer 1: rowchain reduce + LN + QKV-shaped tail
-    wq, bq = rnd((3 * D, D), 133, D ** -0.5), rnd((3 * D,), 134, 0.1)
-    out = torch.empty_like(x)
-    qkv = torch.empty((M, 3 * D), dtype=dt, device="cuda")
-    cfm.rowchain(M, D, code, x=x, pending=(y0, y1, b2, 0.5, None), ln=lns[1], out_f32=out,
-                 tail=(packing.pack_frag_major(wq, dt), bq, 3 * D, False, qkv))
-    x1 = x + 0.5 * (ffn_nobias(ln(x, lns[0])) + b2)
-    assert relerr(out, x1) < tol
-    assert relerr(qkv.float(), lin(ln(x1, lns[1]), wq, bq)) < tol + (1e-2 if wdt == "bf16" else 2e-3)
-
-    # consumer 2: rows only (reduce + norm_final), no tail
-    fin = torch.empty_like(x)
-    cfm.rowchain(M, D, code, x=x, pending=(y0, y1, b2, 0.5, lns[2]), out_f32=fin)
-    assert relerr(fin, ln(x1, lns[2])) < tol
-
-    # consumer 3: the next partial FFN's own reduce input (+ norm_final), rows written back by the half-0 workgroups
-    z0, z1, xo = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    cfm.ffn_partial(x, lns[1], w1f, w2f, b1, FF, z0, z1, pending=(y0, y1, b2, 0.5, lns[2]), x_out=xo)
-    xin = ln(x1, lns[2])
-    assert relerr(xo, xin) < tol
-    assert relerr(z0 + z1, ffn_nobias(ln(xin, lns[1]))) < tol * 2
-
-    # head input: rows = x + mask(a16 . Wh^T + bh), written back
-    a16 = rnd((M, D), 135).to(dt)
-    wh, bh = rnd((D, D), 136, D ** -0.5), rnd((D,), 137, 0.1)
-    mask = (torch.rand(M, device="cuda") > 0.3).to(torch.uint8)
-    cfm.ffn_partial(x, lns[0], w1f, w2f, b1, FF, z0, z1, head=(a16, packing.pack_frag_major(wh, dt), bh, mask), x_out=xo)
-    x3 = x + lin(a16.float(), wh, bh) * mask[:, None].float()
-    assert relerr(xo, x3) < tol
-    assert relerr(z0 + z1, ffn_nobias(ln(x3, lns[0]))) < tol * 2

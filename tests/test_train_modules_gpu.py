@@ -20,18 +20,26 @@ pytestmark = pytest.mark.gpu
 MODES = ["bf16", "fp16", "fp32"]
 DEV = "cuda"
 # module-level gates: (forward output, gradients)
-MOD_TOL = {"fp32": (1e-4, 1e-3), "fp16": (5e-3, 1.5e-2), "bf16": (3e-2, 6e-2)}
+MOD_TOL = {"fp32": (5e-5, 1e-3), "fp16": (1e-3, 3e-3), "bf16": (8e-3, 2.5e-2)}
 # whole encoder + CTC: (loss relative, output, gradients)
-ENC_TOL = {"fp32": (1e-4, 1e-3, 1e-3), "fp16": (5e-3, 5e-3, 1e-2), "bf16": (3e-2, 3e-2, 5e-2)}
+ENC_TOL = {"fp32": (1e-5, 5e-5, 1e-3), "fp16": (1e-4, 2e-3, 8e-3), "bf16": (1e-3, 1.5e-2, 4.5e-2)}
 # The two front-end convolutions sit behind ReLUs on a few thousand positions.  A forward difference of one rounding error flips isolated
 # ReLU mask bits, and each flipped bit moves an entry of a convolution's weight gradient by one full term of a ~sqrt(positions)-sized sum:
 # the max-norm error of those tensors is a property of the fixture's size (T = 83..200 frames), not of the kernels (fp32 mode reproduces
 # them to 1e-5 when no bit flips).  They get their own max-norm gate.
-FRONT_TOL = {"fp32": 2e-2, "fp16": 1e-1, "bf16": 1.5e-1}
+FRONT_TOL = {"fp32": 1.2e-2, "fp16": 9e-2, "bf16": 1.25e-1}
+# Gradients that are ZERO in exact arithmetic: keys' bias and the batch path's positional parameters (constant along a softmax row), the
+# depthwise bias (removed by BatchNorm's batch mean).  The reference holds rounding noise there (1e-8 .. 1e-5 of the largest gradient), the
+# 16-bit modes somewhat more; they are checked against a 100x higher floor, i.e. as "stays negligible", not digit by digit.
+STRUCT_ZERO = ("linear_k.bias", "pos_bias_v", "linear_pos.weight", "depthwise_conv.bias")
 
 
 def is_front(name):
     return "conv.0." in name or "conv.2." in name
+
+
+def floor_for(name, floor):
+    return floor * 100.0 if name.endswith(STRUCT_ZERO) else floor
 
 
 @pytest.fixture(scope="module")
@@ -82,7 +90,7 @@ def run_case(g, tag, mod, x, call, gseed, mode, want_dx=True, ftol=None, gtol=No
         assert bool(torch.isfinite(p.grad).all()), (tag, k)
         if k in skip:
             continue
-        e = (grad_err(g, tag + ":grad:" + k, p.grad.float().cpu().numpy(), floor), k)
+        e = (grad_err(g, tag + ":grad:" + k, p.grad.float().cpu().numpy(), floor_for(k, floor)), k)
         if is_front(k):
             worst_front = max(worst_front, e)
         else:
@@ -170,7 +178,7 @@ def test_encoder_ctc_training_step_matches_reference(pkg, name, mode):
     errs = []
     for k, p in named:
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
-        errs.append((grad_err(g, "grad:" + k, p.grad.float().cpu().numpy(), floor), k))
+        errs.append((grad_err(g, "grad:" + k, p.grad.float().cpu().numpy(), floor_for(k, floor)), k))
     worst = max(e for e in errs if not is_front(e[1]))
     worst_front = max(e for e in errs if is_front(e[1]))
     med = float(np.median([e for e, _ in errs]))
@@ -241,7 +249,7 @@ def test_config4_shape_gradients_against_oracle(pkg, mode):
     for k, p in list(enc.named_parameters()) + [("ctc." + k, p) for k, p in dec.named_parameters()]:
         ref = (Pc[k[4:]] if k.startswith("ctc.") else P[k]).grad.double()
         d = p.grad.cpu().double() - ref
-        e = (float(d.abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax), k)
+        e = (float(d.abs().max()) / max(float(ref.abs().max()), floor_for(k, 1e-3 * gmax)), k)
         l2 = (float(d.norm()) / max(float(ref.norm()), 1e-3 * gmax * ref.numel() ** 0.5), k)
         worst_l2 = max(worst_l2, l2)
         if is_front(k):
@@ -275,7 +283,7 @@ def test_reference_style_driver_trains_on_dropin_modules(pkg):
     dec(out, pad_s.squeeze(1).sum(1), dev(g["labels"]), dev(g["label_lens"])).backward()
     gmax = max(float(v.abs().max()) for v in ref.values())
     for k, p in enc.named_parameters():
-        assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * max(float(ref[k].abs().max()), 1e-3 * gmax), k
+        assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * max(float(ref[k].abs().max()), 1e-2 * gmax), k
 
 
 def test_train_mode_refuses_what_is_not_built(pkg):

@@ -47,7 +47,8 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
     import trainer as T
     import torch.distributed as dist
     cfm.set_precision("fp32")
-    if use_pg:
+    cfm.set_deterministic(True)        # Adam turns a gradient's SIGN into the update: rounding-noise gradients (structurally zero ones) must
+    if use_pg:                         # be bit-identical between the two runs, so the weight-gradient GEMMs run without split-M atomics
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -78,11 +79,21 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
             assert abs(float(loss) - tot / accum) < 1e-4 * abs(tot / accum)
             assert abs(float(tr.last_grad_norm) - float(norm)) < 1e-3 * float(norm)
         assert float(norm) > clip or True
-        worst = 0.0
+        # Parameters whose gradient is zero in exact arithmetic (keys' bias, pos_bias_v / linear_pos in the batch path, the depthwise bias
+        # under BatchNorm) receive pure rounding noise, and Adam turns the SIGN of that noise into a full +-lr update: after the first step
+        # the two models differ in the last bits, the noise decorrelates, and these parameters random-walk apart by O(lr) -- in ANY
+        # implementation, the reference included.  They are bounded by the total step length instead of compared digit by digit.
+        noise = ("linear_k.bias", "pos_bias_v", "linear_pos.weight", "depthwise_conv.bias")
+        travelled = sum(T.warmup_lr(lr, warmup, s + 1) for s in range(steps))
+        worst = (0.0, "")
         for (k, a), b in zip(list(enc.named_parameters()) + list(dec.named_parameters()), params_r):
-            worst = max(worst, float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3))
-        print("  trainer vs plain autograd + torch Adam after %d steps: worst parameter difference %.3e" % (steps, worst))
-        assert worst < 2e-4            # weight-gradient atomics are order-dependent in the last bits; Adam's 1/sqrt(v) amplifies them early on
+            d = float((a - b).abs().max())
+            if k.endswith(noise):
+                assert d <= 2.0 * travelled * 1.01, (k, d, travelled)
+                continue
+            worst = max(worst, (d / max(float(b.abs().max()), 1e-3), k))
+        print("  trainer vs plain autograd + torch Adam after %d steps: worst parameter difference %.3e (%s)" % (steps, worst[0], worst[1]))
+        assert worst[0] < 2e-4, worst            # weight-gradient atomics are order-dependent in the last bits; Adam's 1/sqrt(v) amplifies them early on
         # BatchNorm running statistics advanced identically
         for (k, a), (_, b) in zip(enc.named_buffers(), enc_r.named_buffers()):
             if "running" in k:
@@ -91,6 +102,7 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
         if use_pg:
             dist.destroy_process_group()
         cfm.set_precision("bf16")
+        cfm.set_deterministic(False)
 
 
 def test_trainer_bf16_loss_goes_down():
