@@ -109,7 +109,7 @@ def _attend_train(mod, query, key, value, inputs_attn_mask, cache, relative, pre
 def _attend(mod, query, key, value, inputs_attn_mask, pos_embed, cache, relative):
     cfm.require_hip(query, key, value)
     prec = cfm.resolve_precision(mod)
-    if cfm.check_mode(mod, type(mod).__name__, (("attention dropout", mod.dropout.p),)):
+    if cfm.check_mode(mod, type(mod).__name__):
         return _attend_train(mod, query, key, value, inputs_attn_mask, cache, relative, prec)
     pk = packing.pack_mhsa(mod, prec, relative)
     B, Tq, D = query.shape

@@ -33,7 +33,8 @@ class GemmDesc(ctypes.Structure):
                 ("act", c_i32), ("alpha", ctypes.c_float),
                 ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
                 ("tile", c_i32), ("mask_mode", c_i32),
-                ("C_pre", c_p), ("ld_pre", c_i64), ("pre_dtype", c_i32), ("aux_dtype", c_i32), ("aux", c_p), ("ld_aux", c_i64)]
+                ("C_pre", c_p), ("ld_pre", c_i64), ("pre_dtype", c_i32), ("aux_dtype", c_i32), ("aux", c_p), ("ld_aux", c_i64),
+                ("drop_p", ctypes.c_float), ("drop2_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("drop2_seed", ctypes.c_uint32)]
 
 
 class GemmTnDesc(ctypes.Structure):
@@ -49,7 +50,8 @@ class AttnBwdDesc(ctypes.Structure):
                 ("grad_q", c_p), ("grad_k", c_p), ("grad_v", c_p), ("delta", c_p),
                 ("q_sb", c_i64), ("q_st", c_i64), ("k_sb", c_i64), ("k_st", c_i64), ("v_sb", c_i64), ("v_st", c_i64), ("m_sb", c_i64), ("m_sq", c_i64),
                 ("B", c_i32), ("H", c_i32), ("Tq", c_i32), ("Tk", c_i32), ("dk", c_i32),
-                ("io_dtype", c_i32), ("dout_dtype", c_i32), ("mma_dtype", c_i32), ("split", c_i32), ("scale", ctypes.c_float)]
+                ("io_dtype", c_i32), ("dout_dtype", c_i32), ("mma_dtype", c_i32), ("split", c_i32), ("scale", ctypes.c_float),
+                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32)]
 
 
 class AttnDesc(ctypes.Structure):
@@ -59,7 +61,7 @@ class AttnDesc(ctypes.Structure):
                 ("m_sb", c_i64), ("m_sq", c_i64),
                 ("B", c_i32), ("H", c_i32), ("Tq", c_i32), ("Tk", c_i32), ("dk", c_i32),
                 ("q_dtype", c_i32), ("kv_dtype", c_i32), ("p_dtype", c_i32), ("out_dtype", c_i32), ("mma_dtype", c_i32),
-                ("split", c_i32), ("scale", ctypes.c_float), ("lse", c_p)]
+                ("split", c_i32), ("scale", ctypes.c_float), ("lse", c_p), ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32)]
 
 
 class FfnDesc(ctypes.Structure):
@@ -158,6 +160,8 @@ def lib():
         L.cfm_ctc_grad.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]
         L.cfm_adam_step.argtypes = [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p, c_p]
         L.cfm_sumsq.argtypes = [c_p, c_i64, c_p, c_i32, c_p, c_p]
+        L.cfm_dropout_rows.argtypes = [c_p, c_i32, c_p, c_i32, c_p, c_f, c_f, ctypes.c_uint32, c_f, ctypes.c_uint32, c_i64, c_i32, c_p]
+        L.cfm_dropout_mask.argtypes = [c_p, c_i64, c_f, ctypes.c_uint32, c_p]
         for name in ("cfm_layernorm_bwd_ws", "cfm_dwconv_bn_ws", "cfm_conv1_wgrad_ws"):
             getattr(L, name).restype = c_i64
         L.cfm_prof_enable.argtypes = [c_i32]
@@ -170,7 +174,7 @@ def lib():
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
-                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq"):
+                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib
@@ -259,16 +263,11 @@ def resolve_precision(module=None):
 _warned = set()
 
 
-def check_mode(module, what, dropouts=()):
+def check_mode(module, what):
     """Shared train / eval gate of the drop-in modules.  Returns True when the module must take its TRAIN path (module.training):
-    BatchNorm batch statistics, autograd Functions.  Active dropout (p > 0 in train mode) is applied by torch around the fused
-    Functions where the reference applies it between modules, and is refused inside them until the in-kernel generator lands.
+    BatchNorm batch statistics, dropout from the kernels' counter-based generator, autograd Functions.
     In eval mode the forward is inference-only: gradients do not flow (warned once when someone might expect them to)."""
     if module.training:
-        for name, p in dropouts:
-            if p > 0.0:
-                raise NotImplementedError("%s: train mode with %s = %g: in-kernel dropout is not built yet; construct the model with "
-                                          "dropout 0 (parity and throughput are measured at p = 0)" % (what, name, p))
         return True
     if torch.is_grad_enabled() and what not in _warned and any(q.requires_grad for q in module.parameters()):
         _warned.add(what)

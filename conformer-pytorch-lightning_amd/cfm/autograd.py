@@ -23,35 +23,47 @@ def _f32c(t):
     return (t if t.dtype == torch.float32 else t.float()).contiguous()
 
 
-def _split(prec):
-    return prec.split
+def draw_seed():
+    """A fresh 31-bit base seed for one Function call's dropout masks, from torch's CPU generator (torch.manual_seed makes a run
+    reproducible; no device round trip).  Sites add small odd offsets."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+def _drop(p, seed, site):
+    return (float(p), (seed + 0x9E3779B1 * site) & 0xFFFFFFFF) if p and p > 0.0 else None
 
 
 # ======================================================================================================================
 # raw forward / backward pieces (no autograd inside): tensors in, tensors + saved state out
 # ======================================================================================================================
-def ffn_fwd(pk, x, ln, prec, alpha, act=cfm.ACT_SILU):
-    """x f32 [M,D] -> (x + alpha * FFN(LN(x)), saved).  ln = (gain, bias) or None (no norm, no residual: the bare module)."""
+def ffn_fwd(pk, x, ln, prec, alpha, act=cfm.ACT_SILU, drop_h=None, drop_o=None):
+    """x f32 [M,D] -> (x + alpha * drop_o(FFN(LN(x))), saved).  ln = (gain, bias) or None (no norm, no residual: the bare module).
+    drop_h: dropout on the hidden activation (feedforward.py:19); drop_o: on the branch output (encoder_layer.py:58,69); (p, seed) | None."""
     adt = prec.act_dtype
     M = x.shape[0]
     FF = pk.w1.shape[0]
     xn = cfm.layernorm(x, ln[0], ln[1], out1_dtype=adt)[0] if ln is not None else (x if x.dtype == adt else cfm.cast(x, adt))
     z = torch.empty((M, FF), dtype=adt, device=x.device)
-    h = cfm.gemm(xn, pk.w1, bias=pk.b1, w_lo=pk.w1_lo, act=act, out_dtype=adt, pre_out=z)
+    h = cfm.gemm(xn, pk.w1, bias=pk.b1, w_lo=pk.w1_lo, act=act, out_dtype=adt, pre_out=z, drop=drop_h)
     if ln is not None:
-        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, residual=x, alpha=alpha)
+        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, residual=x, alpha=alpha, drop=drop_o)
     else:
-        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, out_dtype=torch.float32)
+        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, out_dtype=torch.float32, drop=drop_o)
     return y, (x, xn, z, h)
 
 
-def ffn_bwd(pk, saved, dy, ln, prec, alpha, act=cfm.ACT_SILU):
+def ffn_bwd(pk, saved, dy, ln, prec, alpha, act=cfm.ACT_SILU, drop_h=None, drop_o=None):
     """dy f32 [M,D] = d loss / d output -> (dx, grads).  With ln: dx = dy + dLN(...) computed in place over dy."""
     x, xn, z, h = saved
     mma, sp = prec.w_code, prec.split
     dact = cfm.ACT_DSILU if act == cfm.ACT_SILU else cfm.ACT_DRELU
-    dW2, db2 = cfm.gemm_tn(dy, h, want_colsum=True, alpha=alpha, mma_code=mma, split=sp)
-    dz = cfm.gemm(dy, pk.w2t, w_lo=pk.w2t_lo, act=dact, aux=z, alpha=alpha, out_dtype=prec.act_dtype)
+    dyb = dy
+    if drop_o is not None:                                          # the branch gradient through the output dropout, as a GEMM operand
+        dyb, alpha = cfm.dropout_rows(dy, prec.act_dtype, alpha=alpha, drop=drop_o), 1.0
+    if drop_h is not None and dact != cfm.ACT_DSILU:
+        raise NotImplementedError("hidden dropout with a ReLU feed-forward in train mode")
+    dW2, db2 = cfm.gemm_tn(dyb, h, want_colsum=True, alpha=alpha, mma_code=mma, split=sp)
+    dz = cfm.gemm(dyb, pk.w2t, w_lo=pk.w2t_lo, act=dact, aux=z, alpha=alpha, out_dtype=prec.act_dtype, drop=drop_h)
     dW1, db1 = cfm.gemm_tn(dz, xn, want_colsum=True, mma_code=mma, split=sp)
     dxn = cfm.gemm(dz, pk.w1t, w_lo=pk.w1t_lo, out_dtype=torch.float32)
     grads = {"w_1.weight": dW1, "w_1.bias": db1, "w_2.weight": dW2, "w_2.bias": db2}
@@ -61,8 +73,10 @@ def ffn_bwd(pk, saved, dy, ln, prec, alpha, act=cfm.ACT_SILU):
     return dx, grads, (dg, db)
 
 
-def mhsa_fwd(mod, pk, x, ln, B, T, mask8, m_str, prec, relative):
-    """x f32 [B*T,D] -> (x + MHSA(LN(x)) (ln given) or MHSA(x), saved).  Batch path: no cache, positional term not evaluated."""
+def mhsa_fwd(mod, pk, x, ln, B, T, mask8, m_str, prec, relative, drop_a=None, drop_o=None, drop_o2=None):
+    """x f32 [B*T,D] -> (x + drop_o(MHSA(LN(x))) (ln given) or MHSA(x), saved).  Batch path: no cache, positional term not evaluated.
+    drop_a: dropout on the probabilities (attention.py:93); drop_o / drop_o2: on the projected output (encoder_layer.py:61; the plain
+    MHSA's own dropout after linear_out, attention.py:177)."""
     adt = prec.act_dtype
     M, D = x.shape
     H, dk = mod.num_heads, mod.d_k
@@ -72,25 +86,30 @@ def mhsa_fwd(mod, pk, x, ln, B, T, mask8, m_str, prec, relative):
     lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
     st = (T * 3 * D, 3 * D)
     cfm.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], B, H, T, T, dk, st, st + (dk,), st + (dk,), ctx, mask=mask8, mask_str=m_str, mma_code=prec.w_code,
-                  split=prec.split, lse=lse)
+                  split=prec.split, lse=lse, drop=drop_a)
+    if drop_o is None and drop_o2 is not None:
+        drop_o, drop_o2 = drop_o2, None
     if ln is not None:
-        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, residual=x, alpha=1.0)
+        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, residual=x, alpha=1.0, drop=drop_o, drop2=drop_o2)
     else:
-        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, out_dtype=torch.float32)
+        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, out_dtype=torch.float32, drop=drop_o, drop2=drop_o2)
     return y, (x, xn, qkv, ctx, lse)
 
 
-def mhsa_bwd(mod, pk, saved, dy, ln, B, T, mask8, m_str, prec, relative):
+def mhsa_bwd(mod, pk, saved, dy, ln, B, T, mask8, m_str, prec, relative, drop_a=None, drop_o=None, drop_o2=None):
     x, xn, qkv, ctx, lse = saved
     M, D = x.shape
     H, dk = mod.num_heads, mod.d_k
     mma, sp = prec.w_code, prec.split
-    dWo, dbo = cfm.gemm_tn(dy, ctx, want_colsum=True, mma_code=mma, split=sp)
-    dctx = cfm.gemm(dy, pk.out_t, w_lo=pk.out_t_lo, out_dtype=prec.act_dtype)
+    if drop_o is None and drop_o2 is not None:
+        drop_o, drop_o2 = drop_o2, None
+    dyb = dy if drop_o is None else cfm.dropout_rows(dy, prec.act_dtype, drop=drop_o, drop2=drop_o2)
+    dWo, dbo = cfm.gemm_tn(dyb, ctx, want_colsum=True, mma_code=mma, split=sp)
+    dctx = cfm.gemm(dyb, pk.out_t, w_lo=pk.out_t_lo, out_dtype=prec.act_dtype)
     dqkv = torch.empty_like(qkv)
     st = (T * 3 * D, 3 * D)
     cfm.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ctx, dctx, lse, B, H, T, T, dk, st, st, st, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], mask=mask8,
-                      mask_str=m_str, mma_code=mma, split=sp)
+                      mask_str=m_str, mma_code=mma, split=sp, drop=drop_a)
     dWqkv, dbqkv = cfm.gemm_tn(dqkv, xn, want_colsum=True, mma_code=mma, split=sp)
     dxn = cfm.gemm(dqkv, pk.qkv_t, w_lo=pk.qkv_t_lo, out_dtype=torch.float32)
     grads = {"linear_q.weight": dWqkv[:D], "linear_k.weight": dWqkv[D:2 * D], "linear_v.weight": dWqkv[2 * D:],
@@ -108,7 +127,7 @@ def mhsa_bwd(mod, pk, saved, dy, ln, B, T, mask8, m_str, prec, relative):
     return dx, grads, (dg, db)
 
 
-def conv_module_fwd(mod, pk, x, ln, B, T, keep, prec):
+def conv_module_fwd(mod, pk, x, ln, B, T, keep, prec, drop_o=None):
     """x f32 [B*T,D] -> (x + ConvModule(mask(LN(x))) (ln given) or ConvModule(mask(x)), saved); BatchNorm in training mode."""
     adt = prec.act_dtype
     M, D = x.shape
@@ -131,18 +150,19 @@ def conv_module_fwd(mod, pk, x, ln, B, T, keep, prec):
     if bn.track_running_stats:
         bn.num_batches_tracked += 1
     if ln is not None:
-        y = cfm.gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, residual=x, alpha=1.0)
+        y = cfm.gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, residual=x, alpha=1.0, drop=drop_o)
     else:
         y = cfm.gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, out_dtype=torch.float32)
     return y, (x, xn, u, glu, c, stats, s)
 
 
-def conv_module_bwd(mod, pk, saved, dy, ln, B, T, keep, prec):
+def conv_module_bwd(mod, pk, saved, dy, ln, B, T, keep, prec, drop_o=None):
     x, xn, u, glu, c, stats, s = saved
     M, D = x.shape
     adt, mma, sp = prec.act_dtype, prec.w_code, prec.split
-    dW2, db2 = cfm.gemm_tn(dy, s.view(M, D), want_colsum=True, row_mask=keep, mma_code=mma, split=sp)
-    ds = cfm.gemm(dy, pk.pw2_t, w_lo=pk.pw2_t_lo, row_mask=keep, mask_mode=1, out_dtype=adt)     # masked OUTPUT rows have no gradient
+    dyb = dy if drop_o is None else cfm.dropout_rows(dy, adt, drop=drop_o)
+    dW2, db2 = cfm.gemm_tn(dyb, s.view(M, D), want_colsum=True, row_mask=keep, mma_code=mma, split=sp)
+    ds = cfm.gemm(dyb, pk.pw2_t, w_lo=pk.pw2_t_lo, row_mask=keep, mask_mode=1, out_dtype=adt)     # masked OUTPUT rows have no gradient
     dglu, ddw_w, ddw_b, dgamma, dbeta = cfm.dwconv_bn_train_bwd(ds.view(B, T, D), c, stats, glu.view(B, T, D), pk.dw_w, adt)
     du = cfm.glu_bwd(u, dglu.view(M, D), adt)
     # pointwise-conv-1 saw zeroed padded rows: xn already is (LayerNorm path) or is masked here (bare module)
@@ -244,13 +264,14 @@ class FeedForwardFn(torch.autograd.Function):
     def forward(ctx, x, mod, prec, act, *params):
         pk = packing.pack_ffn_train(mod, prec)
         x2 = _f32c(x.reshape(-1, x.shape[-1]))
-        y, saved = ffn_fwd(pk, x2, None, prec, 1.0, act)
+        ctx.drop_h = _drop(mod.dropout.p, draw_seed(), 1) if mod.dropout.p > 0 else None
+        y, saved = ffn_fwd(pk, x2, None, prec, 1.0, act, drop_h=ctx.drop_h)
         ctx.mod, ctx.prec, ctx.pk, ctx.saved, ctx.act, ctx.shape = mod, prec, pk, saved, act, x.shape
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        dx, grads, _ = ffn_bwd(ctx.pk, ctx.saved, _f32c(dy.reshape(-1, dy.shape[-1])), None, ctx.prec, 1.0, ctx.act)
+        dx, grads, _ = ffn_bwd(ctx.pk, ctx.saved, _f32c(dy.reshape(-1, dy.shape[-1])), None, ctx.prec, 1.0, ctx.act, drop_h=ctx.drop_h)
         names, tensors = _params(ctx.mod)
         return (dx.view(ctx.shape), None, None, None) + tuple(_ordered(names, grads, tensors))
 
@@ -260,14 +281,17 @@ class AttentionFn(torch.autograd.Function):
     def forward(ctx, x, mod, prec, relative, mask8, m_str, *params):
         pk = packing.pack_mhsa_train(mod, prec, relative)
         B, T, D = x.shape
-        y, saved = mhsa_fwd(mod, pk, _f32c(x.reshape(B * T, D)), None, B, T, mask8, m_str, prec, relative)
-        ctx.args = (mod, prec, relative, mask8, m_str, pk, saved, B, T, D)
+        p = mod.dropout.p
+        seed = draw_seed() if p > 0 else 0
+        drops = (_drop(p, seed, 1), None, None if relative else _drop(p, seed, 2))      # probabilities; the plain MHSA also drops its output
+        y, saved = mhsa_fwd(mod, pk, _f32c(x.reshape(B * T, D)), None, B, T, mask8, m_str, prec, relative, *drops)
+        ctx.args = (mod, prec, relative, mask8, m_str, pk, saved, B, T, D, drops)
         return y.view(B, T, D)
 
     @staticmethod
     def backward(ctx, dy):
-        mod, prec, relative, mask8, m_str, pk, saved, B, T, D = ctx.args
-        dx, grads, _ = mhsa_bwd(mod, pk, saved, _f32c(dy.reshape(B * T, D)), None, B, T, mask8, m_str, prec, relative)
+        mod, prec, relative, mask8, m_str, pk, saved, B, T, D, drops = ctx.args
+        dx, grads, _ = mhsa_bwd(mod, pk, saved, _f32c(dy.reshape(B * T, D)), None, B, T, mask8, m_str, prec, relative, *drops)
         names, tensors = _params(mod)
         return (dx.view(B, T, D), None, None, None, None, None) + tuple(_ordered(names, grads, tensors))
 
@@ -327,17 +351,24 @@ class EncoderLayerFn(torch.autograd.Function):
                packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
         ln = lambda m: (m.weight.detach(), m.bias.detach())
         x0 = _f32c(x.reshape(B * T, D))
-        x1, s1 = ffn_fwd(pks[0], x0, ln(layer.norm_ff_macaron), prec, 0.5)
-        x2, s2 = mhsa_fwd(layer.self_attn, pks[1], x1, ln(layer.norm_mha), B, T, mask8, m_str, prec, rel)
-        x3, s3 = conv_module_fwd(layer.conv_module, pks[2], x2, ln(layer.norm_conv), B, T, keep, prec)
-        x4, s4 = ffn_fwd(pks[3], x3, ln(layer.norm_ff), prec, 0.5)
+        # dropout (encoder_layer.py:56-69 under module.train()): the shared nn.Dropout(feedforward_dropout) on each of the four branch
+        # outputs, each FFN's own dropout on its hidden activation, the attention's on its probabilities (and, plain MHSA only, on its output)
+        p_br, p_a = layer.dropout.p, layer.self_attn.dropout.p
+        p_hm, p_h = layer.feed_forward_macaron.dropout.p, layer.feed_forward.dropout.p
+        seed = draw_seed() if max(p_br, p_a, p_hm, p_h) > 0 else 0
+        dr = dict(hm=_drop(p_hm, seed, 1), om=_drop(p_br, seed, 2), a=_drop(p_a, seed, 3), oa=_drop(p_br, seed, 4),
+                  oa2=None if rel else _drop(p_a, seed, 5), oc=_drop(p_br, seed, 6), h=_drop(p_h, seed, 7), o=_drop(p_br, seed, 8))
+        x1, s1 = ffn_fwd(pks[0], x0, ln(layer.norm_ff_macaron), prec, 0.5, drop_h=dr["hm"], drop_o=dr["om"])
+        x2, s2 = mhsa_fwd(layer.self_attn, pks[1], x1, ln(layer.norm_mha), B, T, mask8, m_str, prec, rel, dr["a"], dr["oa"], dr["oa2"])
+        x3, s3 = conv_module_fwd(layer.conv_module, pks[2], x2, ln(layer.norm_conv), B, T, keep, prec, drop_o=dr["oc"])
+        x4, s4 = ffn_fwd(pks[3], x3, ln(layer.norm_ff), prec, 0.5, drop_h=dr["h"], drop_o=dr["o"])
         y = cfm.layernorm(x4, *ln(layer.norm_final))[0]
-        ctx.args = (layer, prec, mask8, m_str, keep, pks, (s1, s2, s3, s4, x4), B, T, D)
+        ctx.args = (layer, prec, mask8, m_str, keep, pks, (s1, s2, s3, s4, x4), B, T, D, dr)
         return y.view(B, T, D)
 
     @staticmethod
     def backward(ctx, dy):
-        layer, prec, mask8, m_str, keep, pks, (s1, s2, s3, s4, x4), B, T, D = ctx.args
+        layer, prec, mask8, m_str, keep, pks, (s1, s2, s3, s4, x4), B, T, D, dr = ctx.args
         rel = layer.use_relative
         ln = lambda m: (m.weight.detach(), m.bias.detach())
         grads = {}
@@ -349,13 +380,13 @@ class EncoderLayerFn(torch.autograd.Function):
 
         d, dgf, dbf = cfm.layernorm_bwd(x4, _f32c(dy.reshape(B * T, D)), layer.norm_final.weight.detach())
         grads["norm_final.weight"], grads["norm_final.bias"] = dgf, dbf
-        d, g, lng = ffn_bwd(pks[3], s4, d, ln(layer.norm_ff), prec, 0.5)
+        d, g, lng = ffn_bwd(pks[3], s4, d, ln(layer.norm_ff), prec, 0.5, drop_h=dr["h"], drop_o=dr["o"])
         put("feed_forward.", g, "norm_ff", lng)
-        d, g, lng = conv_module_bwd(layer.conv_module, pks[2], s3, d, ln(layer.norm_conv), B, T, keep, prec)
+        d, g, lng = conv_module_bwd(layer.conv_module, pks[2], s3, d, ln(layer.norm_conv), B, T, keep, prec, drop_o=dr["oc"])
         put("conv_module.", g, "norm_conv", lng)
-        d, g, lng = mhsa_bwd(layer.self_attn, pks[1], s2, d, ln(layer.norm_mha), B, T, mask8, m_str, prec, rel)
+        d, g, lng = mhsa_bwd(layer.self_attn, pks[1], s2, d, ln(layer.norm_mha), B, T, mask8, m_str, prec, rel, dr["a"], dr["oa"], dr["oa2"])
         put("self_attn.", g, "norm_mha", lng)
-        d, g, lng = ffn_bwd(pks[0], s1, d, ln(layer.norm_ff_macaron), prec, 0.5)
+        d, g, lng = ffn_bwd(pks[0], s1, d, ln(layer.norm_ff_macaron), prec, 0.5, drop_h=dr["hm"], drop_o=dr["om"])
         put("feed_forward_macaron.", g, "norm_ff_macaron", lng)
         names, tensors = _params(layer)
         return (d.view(B, T, D), None, None, None, None, None) + tuple(_ordered(names, grads, tensors))

@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
+__all__ = ["dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
            "ctc_nll_train", "ctc_grad", "adam_step", "sumsq", "scratch_stats",
            "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
@@ -47,7 +47,7 @@ def scratch_stats():
 
 
 def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, residual=None, alpha=1.0, row_mask=None,
-         mask_mode=0, conv=None, tile=0, n_out=None, pre_out=None, aux=None):
+         mask_mode=0, conv=None, tile=0, n_out=None, pre_out=None, aux=None, drop=None, drop2=None):
     """out = epilogue(a[M,K] . w[N,K]^T); see include/cfm.h cfm_gemm.  conv=(C,T1,F1,T2,F2,M) selects the implicit
     3x3/stride-2 convolution over a channels-last image `a` of shape [B,T1,F1,C]."""
     _c.require_hip(a, w, bias, w_lo, out, residual, row_mask)
@@ -97,6 +97,10 @@ def gemm(a, w, bias=None, w_lo=None, out=None, out_dtype=None, act=_c.ACT_NONE, 
         if tuple(aux.shape) != (M, N):
             raise ValueError("cfm.gemm: aux is %s, expected (%d,%d)" % (tuple(aux.shape), M, N))
         d.aux, d.ld_aux, d.aux_dtype = _c.ptr(aux), aux.stride(0), _c.dt_code(aux)
+    if drop is not None and drop[0] > 0.0:       # (p, seed): output dropout in the epilogue (train mode)
+        d.drop_p, d.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
+        if drop2 is not None and drop2[0] > 0.0:
+            d.drop2_p, d.drop2_seed = float(drop2[0]), int(drop2[1]) & 0xFFFFFFFF
     d.A, d.W, d.W_lo, d.bias, d.residual, d.row_mask, d.C = _c.ptr(a), _c.ptr(w), _c.ptr(w_lo), _c.ptr(bias), _c.ptr(residual), _c.ptr(row_mask), _c.ptr(out)
     d.ldc = out.stride(0)
     d.M, d.N, d.K = M, N, K
@@ -203,7 +207,7 @@ def as_u8_mask(mask):
 
 
 def attention(q, k, v, B, H, Tq, Tk, dk, q_str, k_str, v_str, out, p=None, p_str=(0, 0), bias_u=None, bias_v=None, mask=None,
-              mask_str=(0, 0), mma_code=_c.BF16, split=False, scale=None, lse=None):
+              mask_str=(0, 0), mma_code=_c.BF16, split=False, scale=None, lse=None, drop=None):
     """Fused attention; *_str are (batch stride, time stride[, head stride]) in ELEMENTS (see include/cfm.h).  lse: optional f32 [B,H,Tq]
     output (training): the log-sum-exp of each row's scaled masked scores."""
     _c.require_hip(q, k, v, p, out, mask, bias_u, bias_v, lse)
@@ -223,6 +227,8 @@ def attention(q, k, v, B, H, Tq, Tk, dk, q_str, k_str, v_str, out, p=None, p_str
     d.mma_dtype, d.split = mma_code, 1 if split else 0
     d.scale = scale if scale is not None else float(dk) ** -0.5
     d.lse = _c.ptr(lse)
+    if drop is not None and drop[0] > 0.0:       # (p, seed): dropout on the probabilities (train mode)
+        d.drop_p, d.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     _c.check(_c.lib().cfm_attention(ctypes.byref(d), _c.stream()), "cfm_attention")
     return out
 
@@ -536,7 +542,7 @@ def conv1_wgrad(dh1, x, cmvn=None):
 
 
 def attention_bwd(q, k, v, out, dout, lse, B, H, Tq, Tk, dk, q_str, k_str, v_str, dq, dkk, dv, mask=None, mask_str=(0, 0), mma_code=_c.BF16, split=False,
-                  scale=None):
+                  scale=None, drop=None):
     """Backward of attention(); q/k/v and dq/dkk/dv share strides ((batch, time) in elements, head h at h*dk); see include/cfm.h."""
     _c.require_hip(q, k, v, out, dout, lse, dq, dkk, dv, mask)
     d = _c.AttnBwdDesc()
@@ -553,6 +559,8 @@ def attention_bwd(q, k, v, out, dout, lse, B, H, Tq, Tk, dk, q_str, k_str, v_str
         raise ValueError("cfm.attention_bwd: q, k, v, out and the gradients must share one dtype")
     d.io_dtype, d.dout_dtype, d.mma_dtype, d.split = _c.dt_code(q), _c.dt_code(dout), mma_code, 1 if split else 0
     d.scale = scale if scale is not None else float(dk) ** -0.5
+    if drop is not None and drop[0] > 0.0:
+        d.drop_p, d.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     _c.check(_c.lib().cfm_attention_bwd(ctypes.byref(d), _c.stream()), "cfm_attention_bwd")
 
 
@@ -621,3 +629,27 @@ def sumsq(x):
     out = torch.empty((1,), dtype=torch.float32, device=x.device)
     _c.check(_c.lib().cfm_sumsq(_c.ptr(x), n, _c.ptr(part), nb, _c.ptr(out), _c.stream()), "cfm_sumsq")
     return out
+
+
+def dropout_rows(x, out_dtype, alpha=1.0, drop=None, drop2=None, row_mask=None):
+    """y = alpha * x * keep(seed, element) / (1 - p), rows with row_mask == 0 zeroed: the gradient of a residual branch
+    x + alpha * dropout(f) as a GEMM operand (include/cfm.h cfm_dropout_rows).  drop / drop2 = (p, seed) or None."""
+    _c.require_hip(x, row_mask)
+    x = _rows2d(x, "dropout_rows(x)")
+    if not x.is_contiguous():
+        raise ValueError("cfm.dropout_rows: x must be contiguous")
+    M, N = x.shape
+    y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    p1, s1 = (float(drop[0]), int(drop[1]) & 0xFFFFFFFF) if drop is not None else (0.0, 0)
+    p2, s2 = (float(drop2[0]), int(drop2[1]) & 0xFFFFFFFF) if drop2 is not None else (0.0, 0)
+    _c.check(_c.lib().cfm_dropout_rows(_c.ptr(x), _c.dt_code(x), _c.ptr(y), _c.dt_code(y), _c.ptr(row_mask), alpha, p1, s1, p2, s2, M, N, _c.stream()),
+             "cfm_dropout_rows")
+    return y
+
+
+def dropout_mask(n, p, seed, device):
+    """the 0/1 keep mask the kernels regenerate for (p, seed) over element indices 0..n-1 (bool tensor; for tests)."""
+    out = torch.empty((n,), dtype=torch.uint8, device=device)
+    _c.require_hip(out)
+    _c.check(_c.lib().cfm_dropout_mask(_c.ptr(out), n, float(p), int(seed) & 0xFFFFFFFF, _c.stream()), "cfm_dropout_mask")
+    return out.view(torch.bool)

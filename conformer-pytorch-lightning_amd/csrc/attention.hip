@@ -36,6 +36,7 @@ struct AttnArgs {
     int q_dtype, kv_dtype, p_dtype, out_dtype;
     float scale;
     float* lse;      // optional f32 [B,H,Tq]: log-sum-exp of each row's scaled masked scores (training)
+    CfmDrop drop;    // dropout on the probabilities (training): element ((b*H + h)*Tq + i)*Tk + j
 };
 
 namespace {
@@ -172,6 +173,13 @@ __global__ __launch_bounds__(256) void cfm_attn_kernel(const AttnArgs a) {
         m_run = m_new;
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc_o[i] *= alpha;
+        if (a.drop.thresh) {                               // dropout(softmax(..)): the normaliser is the undropped row's
+            const unsigned rowbase = (unsigned)(((int64_t)b * a.H + h) * a.Tq + qc) * (unsigned)a.Tk;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sv[f][r] = cfm_drop(a.drop, rowbase + (unsigned)(k0 + f * 16 + g * 4 + r), sv[f][r]);
+        }
 
         // ---- O^T += V^T . P^T over the tile's two 32-key steps ------------------------------------
 #pragma unroll
@@ -445,6 +453,13 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
         m_run = m_new;
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc_o[i] *= alpha;
+        if (a.drop.thresh) {
+            const unsigned rowbase = (unsigned)(((int64_t)b * a.H + h) * a.Tq + qc) * (unsigned)a.Tk;
+#pragma unroll
+            for (int f = 0; f < 16; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[f][r] = cfm_drop(a.drop, rowbase + (unsigned)(ks + f * 16 + g * 4 + r), s[f][r]);
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) {
             const u32x4 ph = pack8<HT>(s[2 * k2], s[2 * k2 + 1]);
@@ -564,6 +579,9 @@ extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
     a.v_sb = d->v_sb; a.v_st = d->v_st; a.v_sh = d->v_sh; a.p_sb = d->p_sb; a.p_st = d->p_st; a.m_sb = d->m_sb; a.m_sq = d->m_sq;
     a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk; a.dk = d->dk;
     a.q_dtype = d->q_dtype; a.kv_dtype = d->kv_dtype; a.p_dtype = d->p_dtype; a.out_dtype = d->out_dtype; a.scale = d->scale; a.lse = d->lse;
+    CFM_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "cfm_attention: dropout probability must be in [0, 1)");
+    CFM_CHECK_ARG(d->drop_p == 0.f || (int64_t)d->B * d->H * d->Tq * d->Tk < ((int64_t)1 << 32), "cfm_attention: dropout needs fewer than 2^32 score elements");
+    a.drop = cfm_make_drop(d->drop_p, d->drop_seed);
     hipStream_t s = (hipStream_t)stream;
     const bool pos = d->p != nullptr;
     // v2 fast path: d_k = 64, 16-bit q (and p) of the MFMA type, K/V either that type or f32 (streaming cache), 16-byte

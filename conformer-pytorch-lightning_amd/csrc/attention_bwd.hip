@@ -27,6 +27,7 @@ struct AttnBwdArgs {
     int B, H, Tq, Tk, dk;
     int io_dt, do_dt;
     float scale;
+    CfmDrop drop;
 };
 
 namespace {
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(256) void cfm_attn_bwd_dq_kernel(const AttnBwdArgs 
                 bool ok = kj < a.Tk && lse_q != -INFINITY;
                 if (ok && a.mask) ok = a.mask[(int64_t)b * a.m_sb + (int64_t)qc * a.m_sq + kj] != 0;
                 const float p = ok ? __expf(s[f][r] * a.scale - lse_q) : 0.f;
-                s[f][r] = p * (dp[f][r] - delta_q) * a.scale;  // dS
+                float dpe = dp[f][r];                          // d loss / d P through the forward's dropout mask
+                if (a.drop.thresh) dpe = cfm_drop(a.drop, (unsigned)rid * (unsigned)a.Tk + (unsigned)kj, dpe);
+                s[f][r] = p * (dpe - delta_q) * a.scale;       // dS
             }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -254,8 +257,14 @@ __global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_kernel(const AttnBwdArgs
                 bool ok = qq < a.Tq && kj < a.Tk && L != -INFINITY;
                 if (ok && a.mask) ok = a.mask[(int64_t)b * a.m_sb + (int64_t)qq * a.m_sq + kj] != 0;
                 const float p = ok ? __expf(s[f][r] * a.scale - L) : 0.f;
-                pv[f][r] = p;
-                s[f][r] = p * (dp[f][r] - Ds[ql]) * a.scale;   // dS
+                float pd = p, dpe = dp[f][r];
+                if (a.drop.thresh) {
+                    const unsigned e = (unsigned)(rb + (qq < a.Tq ? qq : 0)) * (unsigned)a.Tk + (unsigned)(kj < a.Tk ? kj : 0);
+                    pd = cfm_drop(a.drop, e, p);               // the probabilities the forward multiplied V with
+                    dpe = cfm_drop(a.drop, e, dpe);
+                }
+                pv[f][r] = pd;
+                s[f][r] = p * (dpe - Ds[ql]) * a.scale;        // dS
             }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -316,6 +325,8 @@ extern "C" int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream
     a.dq = d->grad_q; a.dkk = d->grad_k; a.dv = d->grad_v; a.delta = d->delta;
     a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st; a.m_sb = d->m_sb; a.m_sq = d->m_sq;
     a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk; a.dk = d->dk; a.io_dt = d->io_dtype; a.do_dt = d->dout_dtype; a.scale = d->scale;
+    CFM_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "cfm_attention_bwd: dropout probability must be in [0, 1)");
+    a.drop = cfm_make_drop(d->drop_p, d->drop_seed);
     hipStream_t s = (hipStream_t)stream;
     if (d->split) return launch_bwd<BF16, true>(a, s, "attn_bwd_dq_bf16x3", "attn_bwd_dkv_bf16x3");
     if (d->mma_dtype == CFM_BF16) return launch_bwd<BF16, false>(a, s, "attn_bwd_dq_bf16", "attn_bwd_dkv_bf16");

@@ -117,6 +117,36 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 
+// ---------------------------------------------------------------------------------------------
+// dropout: a counter-based generator -- keep(seed, element index) is a pure function, so the backward regenerates the forward's
+// mask instead of reading it from memory (nothing of the size of an activation is stored for dropout).  murmur3's 32-bit finaliser
+// over (index * golden ratio) ^ seed: 2 multiplies, 3 shifts, 4 xors per element.  No bit-parity with torch's Philox stream (SURVEY 2.2:
+// parity is defined at p = 0); statistics and forward/backward consistency are tested.
+// ---------------------------------------------------------------------------------------------
+struct CfmDrop {
+    unsigned seed, thresh;   // keep iff hash >= thresh;  thresh = p * 2^32 (0: dropout off)
+    float scale;             // 1 / (1 - p)
+};
+__device__ __forceinline__ unsigned cfm_hash32(unsigned seed, unsigned idx) {
+    unsigned h = (idx * 0x9E3779B1u) ^ seed;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float cfm_drop(const CfmDrop& d, unsigned idx, float v) {
+    return cfm_hash32(d.seed, idx) >= d.thresh ? v * d.scale : 0.f;
+}
+static inline CfmDrop cfm_make_drop(float p, unsigned seed) {
+    CfmDrop d;
+    d.seed = seed;
+    d.thresh = p <= 0.f ? 0u : (p >= 1.f ? 0xFFFFFFFFu : (unsigned)((double)p * 4294967296.0));
+    d.scale = p <= 0.f ? 1.f : (p >= 1.f ? 0.f : 1.f / (1.f - p));
+    return d;
+}
+
 // generic scalar load/store by runtime dtype (slow paths, edges)
 __device__ __forceinline__ float load_as_f32(const void* p, int64_t i, int dt) {
     if (dt == CFM_F32) return ((const float*)p)[i];

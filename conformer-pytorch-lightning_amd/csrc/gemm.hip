@@ -38,6 +38,7 @@ struct GemmArgs {
     const void* aux; // training: pre-activation (DSILU) / forward output (DRELU) of the layer whose input gradient this GEMM computes
     int64_t lda, ldc, ldr, ld_pre, ld_aux;
     int pre_dtype, aux_dtype;
+    CfmDrop drop, drop2;   // output dropout (train mode): a pure function of (seed, m * N_out + n)
     int M, N, K;
     int m_begin;     // first row this launch computes (rows [m_begin, M)); 0 except for the tail of a split launch (see cfm_gemm)
     int c_dtype, act, mask_mode;
@@ -333,6 +334,10 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             } else if (g.act == CFM_ACT_DSILU) {               // d silu(z)/dz = s (1 + z (1 - s)), s = sigmoid(z)
+                if (g.drop.thresh) {                           // the gradient arrives at dropout(silu(z)): same mask as the forward's hidden
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = cfm_drop(g.drop, (unsigned)row * (unsigned)g.N + (unsigned)(col + r), v[r]);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z = res_r[i][j][r], sg = sigmoidf_(z);
@@ -341,6 +346,15 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
             } else if (g.act == CFM_ACT_DRELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = res_r[i][j][r] > 0.f ? g.alpha * v[r] : 0.f;
+            }
+            if (g.drop.thresh && g.act != CFM_ACT_DSILU) {
+                const unsigned nout = glu ? (unsigned)g.N >> 1 : (unsigned)g.N;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned e = (unsigned)row * nout + (unsigned)(ocol + r);
+                    v[r] = cfm_drop(g.drop, e, v[r]);
+                    if (g.drop2.thresh) v[r] = cfm_drop(g.drop2, e, v[r]);
+                }
             }
             if (!keep && g.mask_mode == 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (g.res) v = res_r[i][j] + g.alpha * v;
@@ -578,7 +592,7 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
     constexpr int BK = SPLIT ? 32 : 64;
     if constexpr (!SPLIT && !A_F32 && !CONV) {
         // persistent workgroups: plain 16-bit products whose tiles are short (K <= 1024) and many (>= 8 per resident workgroup)
-        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && a.m_begin == 0 && !a.Cpre && a.act < CFM_ACT_DSILU;
+        const bool plain = !a.res && !a.mask && a.act != CFM_ACT_GLU && a.m_begin == 0 && !a.Cpre && a.act < CFM_ACT_DSILU && !a.drop.thresh;
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         if (tile == 7 || (tile == 0 && plain && a.K % BK == 0 && a.K <= 1024 && t128 >= 8L * CFM_PERSIST_GRID)) {
             if (!plain || a.K % BK) return cfm_fail(CFM_ERR_ARG, "cfm_gemm: the persistent tile takes bias / SiLU / ReLU epilogues only and K %% 64 == 0");
@@ -645,6 +659,11 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     GemmArgs a;
     a.A = d->A; a.W = (const u16*)d->W; a.Wlo = (const u16*)d->W_lo; a.bias = d->bias; a.res = d->residual;
     a.mask = d->row_mask; a.C = d->C; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
+    CFM_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f && d->drop2_p >= 0.f && d->drop2_p < 1.f, "cfm_gemm: dropout probabilities must be in [0, 1)");
+    CFM_CHECK_ARG((d->drop_p == 0.f && d->drop2_p == 0.f) || (d->N % 4 == 0 && (int64_t)d->M * d->N < ((int64_t)1 << 32)),
+                  "cfm_gemm: dropout needs N %% 4 == 0 and fewer than 2^32 output elements");
+    CFM_CHECK_ARG(d->drop2_p == 0.f || d->drop_p > 0.f, "cfm_gemm: drop2 is a second mask on top of drop");
+    a.drop = cfm_make_drop(d->drop_p, d->drop_seed); a.drop2 = cfm_make_drop(d->drop2_p, d->drop2_seed);
     a.Cpre = d->C_pre; a.ld_pre = d->ld_pre; a.pre_dtype = d->pre_dtype; a.aux = dact ? d->aux : nullptr; a.ld_aux = d->ld_aux; a.aux_dtype = d->aux_dtype;
     a.M = d->M; a.N = d->N; a.K = d->K; a.m_begin = 0; a.c_dtype = d->c_dtype; a.act = d->act; a.alpha = d->alpha; a.mask_mode = d->mask_mode;
     a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
@@ -652,7 +671,7 @@ extern "C" int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream) {
     const bool a32 = d->a_dtype == CFM_F32;
     long head256 = 0;
     {   // 256 x 256 tile with LDS-DMA staging (gemm256.hip): tile id 8, or chosen by a two-line cost model when it can run
-        const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->C_pre && !dact;
+        const bool can256 = !split && !a32 && !d->residual && !d->row_mask && d->act != CFM_ACT_GLU && !d->C_pre && !dact && d->drop_p == 0.f;
         Gemm256Args b;
         b.A = (const u16*)d->A; b.W = (const u16*)d->W; b.bias = d->bias; b.C = d->C; b.lda = d->lda; b.ldc = d->ldc;
         b.M = d->M; b.N = d->N; b.K = d->K; b.c_dtype = d->c_dtype; b.act = d->act;

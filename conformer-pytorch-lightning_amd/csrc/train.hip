@@ -489,6 +489,30 @@ __global__ __launch_bounds__(256) void cfm_sumsq_kernel(const float* __restrict_
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+__global__ void cfm_dropout_rows_kernel(const void* __restrict__ x, int x_dt, void* __restrict__ y, int y_dt, const uint8_t* __restrict__ mask, float alpha,
+                                        CfmDrop d1, CfmDrop d2, int64_t M, int N) {
+    const int qpr = N / 4;
+    const int64_t n = M * qpr;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = id / qpr;
+        f32x4 v = load4(x, x_dt, id * 4);
+        const bool keep = mask ? mask[row] != 0 : true;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = keep ? v[e] * alpha : 0.f;
+            if (d1.thresh) t = cfm_drop(d1, (unsigned)(id * 4 + e), t);
+            if (d2.thresh) t = cfm_drop(d2, (unsigned)(id * 4 + e), t);
+            v[e] = t;
+        }
+        store4(y, y_dt, id * 4, v);
+    }
+}
+
+__global__ void cfm_dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, CfmDrop d) {
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x)
+        out[id] = cfm_hash32(d.seed, (unsigned)id) >= d.thresh ? 1 : 0;
+}
+
 inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
     int64_t b = (n + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -621,6 +645,25 @@ extern "C" int cfm_conv1_wgrad(const void* dh1, int32_t dh1_dtype, const float* 
         if (int rc = cfm_launch_status("cfm_conv1_wgrad")) return rc;
     }
     return reduce_partials(ws, B * nbt, 10 * C, 9 * C, 1.0f, dw, db, s, "cfm_conv1_wgrad (reduce)");     // dw [9][C] tap-major (the packed layout), db [C]
+}
+
+extern "C" int cfm_dropout_rows(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, const uint8_t* row_mask, float alpha, float p, uint32_t seed,
+                                float p2, uint32_t seed2, int64_t M, int32_t N, cfm_stream_t stream) {
+    CFM_CHECK_ARG(x && y && M > 0 && N > 0 && N % 4 == 0, "cfm_dropout_rows: bad arguments (N %% 4 == 0)");
+    CFM_CHECK_ARG(p >= 0.f && p < 1.f && p2 >= 0.f && p2 < 1.f && M * N < ((int64_t)1 << 32), "cfm_dropout_rows: p in [0,1), fewer than 2^32 elements");
+    hipStream_t s = (hipStream_t)stream;
+    CfmProfScope prof("dropout_rows", s, 0.0, (double)M * N * (cfm_elt_size(x_dtype) + cfm_elt_size(y_dtype)));
+    CFM_LAUNCH(cfm_dropout_rows_kernel, dim3((unsigned)grid_for(M * (N / 4))), dim3(256), 0, s, x, x_dtype, y, y_dtype, row_mask, alpha, cfm_make_drop(p, seed),
+               cfm_make_drop(p2, seed2), M, N);
+    return cfm_launch_status("cfm_dropout_rows");
+}
+
+extern "C" int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream_t stream) {
+    CFM_CHECK_ARG(out && n > 0 && n < ((int64_t)1 << 32) && p >= 0.f && p < 1.f, "cfm_dropout_mask: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    CfmProfScope prof("dropout_mask", s, 0.0, (double)n);
+    CFM_LAUNCH(cfm_dropout_mask_kernel, dim3((unsigned)grid_for(n)), dim3(256), 0, s, out, n, cfm_make_drop(p, seed));
+    return cfm_launch_status("cfm_dropout_mask");
 }
 
 extern "C" int cfm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,

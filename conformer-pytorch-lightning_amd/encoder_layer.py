@@ -144,8 +144,7 @@ class ConformerEncoderLayer(nn.Module):
         return ag.EncoderLayerFn.apply(inputs, self, cfm.resolve_precision(self), m8, m_str, keep, *self.parameters())
 
     def forward(self, inputs, inputs_attn_mask, pos_embed, inputs_pad_mask=_ABSENT, attn_cache=_ABSENT, cnn_cache=_ABSENT):
-        if cfm.check_mode(self, "ConformerEncoderLayer", (("feedforward dropout", self.dropout.p), ("feed_forward.dropout", self.feed_forward.dropout.p),
-                                                           ("attention dropout", self.self_attn.dropout.p))):
+        if cfm.check_mode(self, "ConformerEncoderLayer"):
             if attn_cache is not None and attn_cache.dim() == 4 and attn_cache.size(0) > 0:
                 raise NotImplementedError("ConformerEncoderLayer: a KV cache in train mode (streaming is inference-only)")
             out = self.train_forward(inputs, inputs_attn_mask, inputs_pad_mask)

@@ -33,7 +33,7 @@ class PositionwiseFeedForwardModule(nn.Module):
     def forward(self, inputs):
         cfm.require_hip(inputs)
         prec = cfm.resolve_precision(self)
-        if cfm.check_mode(self, "PositionwiseFeedForwardModule", (("dropout", self.dropout.p),)):
+        if cfm.check_mode(self, "PositionwiseFeedForwardModule"):
             from cfm import autograd as ag
             act = cfm.ACT_SILU if isinstance(self.activation, nn.SiLU) else cfm.ACT_RELU
             return ag.FeedForwardFn.apply(inputs, self, prec, act, *self.parameters())

@@ -102,6 +102,12 @@ typedef struct {
     int32_t aux_dtype;  /* CFM_ACT_DSILU / CFM_ACT_DRELU: dtype and row stride of aux [M,N] */
     const void* aux;
     int64_t ld_aux;
+    /* dropout on the OUTPUT element (m,n), after the activation and before row_mask / residual (train mode): kept with probability 1-p and
+     * scaled by 1/(1-p); the mask is a pure function of (seed, m*N_out + n) (csrc/cfm_common.h cfm_hash32), so the backward passes the same
+     * (p, seed) instead of reading a stored mask.  CFM_ACT_DSILU applies it to acc (the gradient arriving at the dropped activation).
+     * drop2: a second, independent mask on the same element (the plain MHSA's extra dropout after linear_out, attention.py:177). */
+    float drop_p, drop2_p;
+    uint32_t drop_seed, drop2_seed;
 } cfm_gemm_desc;
 
 int cfm_gemm(const cfm_gemm_desc* d, cfm_stream_t stream);
@@ -255,6 +261,8 @@ typedef struct {
     int32_t split;                                            /* 1: hi/lo bf16 split (f32-accurate) */
     float scale;
     float* lse;        /* optional (training): f32 [B,H,Tq], log-sum-exp of each row's scaled masked scores (-inf: fully masked) */
+    float drop_p;      /* dropout on the attention probabilities (attention.py:93), element ((b*H+h)*Tq+i)*Tk+j; the softmax normaliser is */
+    uint32_t drop_seed;/* that of the undropped row, as torch's softmax -> dropout gives */
 } cfm_attn_desc;
 
 int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream);
@@ -456,6 +464,8 @@ typedef struct {
     int32_t dout_dtype;
     int32_t mma_dtype, split;
     float scale;
+    float drop_p;                   /* the forward's probability dropout (same p, same seed) */
+    uint32_t drop_seed;
 } cfm_attn_bwd_desc;
 int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream);
 
@@ -470,6 +480,14 @@ int cfm_ctc_nll_train(const float* logits, int64_t ld, int32_t B, int32_t T, int
 int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
                  const int32_t* label_lens, const float* work, float* alpha_beta, const float* lse, const float* nll_shifted, float gscale,
                  const float* gscale_dev, float* dlogits, cfm_stream_t stream);
+
+/* Dropout as an elementwise pass:  y[m,n] = keep(seed, m*N + n) ? alpha * x[m,n] / (1-p) : 0, rows with row_mask == 0 zeroed.  The backward of
+ * a residual branch x + alpha * dropout(f(..)) needs d f = alpha * mask/(1-p) * dx as a GEMM operand (encoder_layer.py:58,61,64,69); the
+ * forward of the same dropout is fused into the producing GEMM's epilogue (cfm_gemm_desc.drop_p), this pass only regenerates its mask.
+ * cfm_dropout_mask writes the 0/1 keep mask itself (tests). */
+int cfm_dropout_rows(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, const uint8_t* row_mask, float alpha, float p, uint32_t seed,
+                     float p2, uint32_t seed2, int64_t M, int32_t N, cfm_stream_t stream);
+int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream_t stream);
 
 /* Optimizer step over flat f32 buffers (module.py:140-143 Adam; executor.py:150 gradient_clip_val):  g' = g * (*grad_scale) + wd * p;
  * m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)   (torch.optim.Adam).

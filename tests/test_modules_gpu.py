@@ -671,9 +671,9 @@ def test_cpu_tensors_fail_loudly(pkg):
     m = pkg.feedforward.PositionwiseFeedForwardModule(16, 0.0, 32).eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(torch.zeros(2, 3, 16))
-    layer = pkg.encoder_layer.ConformerEncoderLayer(16, 15, 0.1, 0.0, 32, 2, True).to(DEV)      # train mode with ACTIVE dropout: not built, refused
-    with pytest.raises(NotImplementedError):
-        layer(torch.zeros(1, 4, 16, device=DEV), torch.ones((0, 0, 0)), torch.zeros(1, 1, 16, device=DEV))
+    layer = pkg.encoder_layer.ConformerEncoderLayer(16, 15, 0.0, 0.0, 32, 2, True).to(DEV).train()
+    with pytest.raises(NotImplementedError):                       # a KV cache in train mode: streaming is inference-only
+        layer(torch.zeros(1, 4, 16, device=DEV), torch.ones((0, 0, 0)), torch.zeros(1, 1, 16, device=DEV), attn_cache=torch.zeros(1, 2, 3, 16, device=DEV))
 
 
 JOINT_TOL = {"fp32": 3e-5, "fp16": 1e-3, "bf16": 6e-3}      # measured 7e-6 / 4e-4 / 3.4e-3

@@ -286,11 +286,61 @@ def test_reference_style_driver_trains_on_dropin_modules(pkg):
         assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * max(float(ref[k].abs().max()), 1e-2 * gmax), k
 
 
+@pytest.mark.parametrize("rel", [True, False])
+def test_dropout_gradients_by_finite_differences(pkg, rel):
+    """Train mode with ACTIVE dropout (p = 0.1 everywhere, the reference's train.sh setting).  The masks come from the kernels' counter-based
+    generator, seeded from torch's CPU generator -- no bit-parity with torch's own dropout -- so the check is the derivative itself: with
+    the seed re-armed before every forward the block is a fixed smooth function, and its analytic gradient (one backward) must match central
+    differences along random directions, for the input and for parameters of every sub-block.  fp32 (f32-accurate) mode."""
+    pkg.cfm.set_precision("fp32")
+    D, H, FF, K, B, T = 144, 4, 576, 15, 2, 29
+    layer = synth.load_synth_(pkg.encoder_layer.ConformerEncoderLayer(D, K, 0.1, 0.1, FF, H, rel), 35).to(DEV).train()
+    pad = pad_valid([29, 21], T)
+    pos_b = pkg.attention.RelativePositionalEncoding(D, 0.0).pe[0:B].to(DEV) if rel else None
+    x = dev(synth.normal(45, (B, T, D)))
+    G = dev(synth.normal(46, (B, T, D)))
+
+    def loss(xv):
+        torch.manual_seed(2024)                                     # same dropout masks on every call
+        return float((layer(xv, pad, pos_b, pad)[0].double() * G.double()).sum())
+
+    xr = x.clone().requires_grad_(True)
+    torch.manual_seed(2024)
+    out = layer(xr, pad, pos_b, pad)[0]
+    (out.double() * G.double()).sum().backward()
+    with torch.no_grad():
+        y0 = layer.eval()(x, pad, pos_b, pad)[0]
+        layer.train()
+    assert float((out - y0).abs().max()) > 1e-2                      # dropout really is active
+    torch.manual_seed(2024)
+    assert torch.equal(layer(x, pad, pos_b, pad)[0], out.detach())   # reproducible under the same seed
+    torch.manual_seed(2025)
+    assert not torch.equal(layer(x, pad, pos_b, pad)[0], out.detach())
+    eps = 2e-2
+    v = dev(synth.normal(47, (B, T, D)))
+    fd = (loss(x + eps * v) - loss(x - eps * v)) / (2 * eps)
+    an = float((xr.grad.double() * v.double()).sum())
+    print("  dropout 0.1, rel=%s: d/dx analytic %.5f vs central difference %.5f" % (rel, an, fd))
+    assert abs(fd - an) < 2e-2 * max(abs(an), 1.0)
+    for name in ("feed_forward_macaron.w_1.weight", "self_attn.linear_v.weight", "self_attn.linear_q.bias", "conv_module.pointwise_conv1.weight",
+                 "conv_module.depthwise_conv.weight", "conv_module.norm.weight", "feed_forward.w_2.weight", "norm_mha.weight"):
+        prm = dict(layer.named_parameters())[name]
+        d = dev(synth.normal(48, tuple(prm.shape))) * float(prm.detach().abs().mean())
+        an = float((prm.grad.double() * d.double()).sum())
+        with torch.no_grad():
+            prm.add_(eps * d)
+            lp = loss(x)
+            prm.sub_(2 * eps * d)
+            lm = loss(x)
+            prm.add_(eps * d)
+        fd = (lp - lm) / (2 * eps)
+        print("    %-40s analytic %.5f vs central difference %.5f" % (name, an, fd))
+        assert abs(fd - an) < 3e-2 * max(abs(an), 0.5), name
+    pkg.cfm.set_precision("bf16")
+
+
 def test_train_mode_refuses_what_is_not_built(pkg):
     D = 144
-    m = pkg.feedforward.PositionwiseFeedForwardModule(D, 0.1, 576).to(DEV).train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 4, D, device=DEV))
     enc = pkg.encoder.ConformerEncoder(80, 15, D, 0.0, 0.0, 0.0, 576, 4, 1, use_relative=True).to(DEV).train()
     empty = torch.zeros((0, 0, 0, 0), device=DEV)
     with pytest.raises(NotImplementedError):

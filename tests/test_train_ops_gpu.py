@@ -321,3 +321,74 @@ def test_adam_and_sumsq(cfm, n):
         cfm.adam_step(p, g, m, v, 1e-3, (0.9, 0.98), 1e-9, 0.0, step, grad_scale=scale)
     assert float((p - ref_p.detach()).abs().max()) < 1e-6
     assert relerr(cfm.sumsq(g), (g.double() ** 2).sum().view(1)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------ dropout
+def test_dropout_generator_statistics_and_rows(cfm):
+    n = 1 << 20
+    for p in (0.1, 0.5):
+        m = cfm.dropout_mask(n, p, 12345, "cuda")
+        rate = float(m.float().mean())
+        assert abs(rate - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n) + 1e-4, (p, rate)
+        m2 = cfm.dropout_mask(n, p, 12346, "cuda")
+        assert abs(float((m & m2).float().mean()) - (1 - p) ** 2) < 3e-3          # different seeds: independent masks
+        assert torch.equal(m, cfm.dropout_mask(n, p, 12345, "cuda"))             # a pure function of (seed, index)
+    M, N = 777, 256
+    x = rnd((M, N), 50)
+    rm = (torch.rand(M, generator=torch.Generator().manual_seed(51)) > 0.3).to("cuda")
+    y = cfm.dropout_rows(x, torch.float32, alpha=0.5, drop=(0.1, 99), drop2=(0.2, 100), row_mask=rm.view(torch.uint8))
+    k = cfm.dropout_mask(M * N, 0.1, 99, "cuda").view(M, N) & cfm.dropout_mask(M * N, 0.2, 100, "cuda").view(M, N)
+    ref = 0.5 * x * k / (0.9 * 0.8) * rm[:, None]
+    assert relerr(y, ref) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(500, 576, 144), (1992, 256, 2048)])
+def test_gemm_epilogue_dropout(cfm, M, N, K):
+    dt = torch.bfloat16
+    a, w, bias, res = rnd((M, K), 52).to(dt), rnd((N, K), 53, K ** -0.5).to(dt), rnd((N,), 54, 0.1), rnd((M, N), 55)
+    keep = cfm.dropout_mask(M * N, 0.1, 777, "cuda").view(M, N)
+    z = a.float() @ w.float().t() + bias
+    # SiLU + dropout (the FFN's hidden activation), pre-activation untouched
+    pre = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    h = cfm.gemm(a, w, bias=bias, act=cfm.ACT_SILU, out_dtype=torch.float32, pre_out=pre, drop=(0.1, 777))
+    assert relerr(pre, z) < 1e-5 and relerr(h, torch.nn.functional.silu(z) * keep / 0.9) < 1e-5
+    # residual + alpha * dropout(v)
+    y = cfm.gemm(a, w, bias=bias, residual=res, alpha=0.5, drop=(0.1, 777))
+    assert relerr(y, res + 0.5 * z * keep / 0.9) < 1e-5
+    # backward epilogue: dz = (dy . W2) * mask/(1-p) * silu'(z)
+    dy, w2 = rnd((M, K), 56).to(dt), rnd((N, K), 57, K ** -0.5).to(dt)
+    zz = pre.clone().requires_grad_(True)
+    (torch.nn.functional.silu(zz) * keep / 0.9).backward(dy.float() @ w2.float().t())
+    dz = cfm.gemm(dy, w2, act=cfm.ACT_DSILU, aux=pre, alpha=1.0, out_dtype=torch.float32, drop=(0.1, 777))
+    assert relerr(dz, zz.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,T,H,dk", [(2, 100, 4, 64), (3, 37, 4, 36)])
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_attention_dropout_forward_backward(cfm, B, T, H, dk, mode):
+    D = H * dk
+    split = mode == "fp32"
+    dt = torch.float32 if split else torch.bfloat16
+    p, seed = 0.1, 4242
+    qkv = rnd((B * T, 3 * D), 58, 0.7).to(dt)
+    dout = rnd((B * T, D), 59).to(dt)
+    lens = [T, max(1, T - T // 4), max(1, T // 2)][:B]
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).cuda()[:, None, :]
+    keep = cfm.dropout_mask(B * H * T * T, p, seed, "cuda").view(B, H, T, T)
+    x = qkv.double().view(B, T, 3, H, dk).requires_grad_(True)
+    s = torch.einsum("bihd,bjhd->bhij", x[:, :, 0], x[:, :, 1]) * dk ** -0.5
+    s = s.masked_fill(~mask.unsqueeze(1), float("-inf"))
+    pr = torch.softmax(s, -1) * keep / (1 - p)
+    o_ref = torch.einsum("bhij,bjhd->bihd", pr, x[:, :, 2]).reshape(B, T, D)
+    o_ref.backward(dout.double().view(B, T, D))
+    g_ref = x.grad.reshape(B * T, 3 * D)
+    ctx = torch.empty((B * T, D), dtype=dt, device="cuda")
+    lse = torch.empty((B, H, T), dtype=torch.float32, device="cuda")
+    m8, mstr, st = mask.contiguous().view(torch.uint8), (T, 0), (T * 3 * D, 3 * D)
+    cfm.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], B, H, T, T, dk, st, st + (dk,), st + (dk,), ctx, mask=m8, mask_str=mstr, split=split, lse=lse, drop=(p, seed))
+    assert relerr(ctx.float(), o_ref.reshape(B * T, D)) < (3e-5 if split else 2e-2)
+    dqkv = torch.zeros_like(qkv)
+    cfm.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ctx, dout, lse, B, H, T, T, dk, st, st, st, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], mask=m8, mask_str=mstr,
+                      split=split, drop=(p, seed))
+    for sl in (slice(0, D), slice(D, 2 * D), slice(2 * D, 3 * D)):
+        assert relerr(dqkv[:, sl].float(), g_ref[:, sl]) < (1e-4 if split else 3e-2)
