@@ -102,7 +102,8 @@ class LayerIO(ctypes.Structure):
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64),
                 ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32),
                 ("pos_proj", c_p), ("pos_proj_ld", c_i64),
-                ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p), ("after_g", c_p), ("after_b", c_p), ("after_out", c_p), ("pos_shared", c_i32)]
+                ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p), ("after_g", c_p), ("after_b", c_p), ("after_out", c_p),
+                ("kv_ring", c_p), ("stream_offset", c_p), ("ring_T", c_i32), ("causal_conv", c_i32), ("conv_cache", c_p), ("pos_shared", c_i32)]
 
 
 _lib = None
@@ -162,6 +163,11 @@ def lib():
         L.cfm_sumsq.argtypes = [c_p, c_i64, c_p, c_i32, c_p, c_p]
         L.cfm_dropout_rows.argtypes = [c_p, c_i32, c_p, c_i32, c_p, c_f, c_f, ctypes.c_uint32, c_f, ctypes.c_uint32, c_i64, c_i32, c_p]
         L.cfm_dropout_mask.argtypes = [c_p, c_i64, c_f, ctypes.c_uint32, c_p]
+        L.cfm_stream_prep.argtypes = [c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]
+        L.cfm_kv_ring_write.argtypes = [c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_stream_advance.argtypes = [c_p, c_p, c_i32, c_i32, c_p]
+        L.cfm_dwconv_causal_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
+        L.cfm_conv_cache_update.argtypes = [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         for name in ("cfm_layernorm_bwd_ws", "cfm_dwconv_bn_ws", "cfm_conv1_wgrad_ws"):
             getattr(L, name).restype = c_i64
         L.cfm_prof_enable.argtypes = [c_i32]
@@ -174,7 +180,8 @@ def lib():
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
-                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask"):
+                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask",
+                     "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib

@@ -6,7 +6,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
+__all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
            "ctc_nll_train", "ctc_grad", "adam_step", "sumsq", "scratch_stats",
            "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
@@ -653,3 +653,41 @@ def dropout_mask(n, p, seed, device):
     _c.require_hip(out)
     _c.check(_c.lib().cfm_dropout_mask(_c.ptr(out), n, float(p), int(seed) & 0xFFFFFFFF, _c.stream()), "cfm_dropout_mask")
     return out.view(torch.bool)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# per-stream streaming state (include/cfm.h, csrc/stream.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+def stream_prep(offsets, T, need, ring_T, pe, slot_mask, pos_rows, abs_rows=None):
+    """offsets int32 [B] -> slot_mask u8 [B,ring_T], pos_rows f32 [B,ring_T,D] (= pe[frame held by the slot]), abs_rows f32 [B,D] = pe[offset]."""
+    _c.require_hip(offsets, pe, slot_mask, pos_rows, abs_rows)
+    B = offsets.numel()
+    D = pe.shape[-1]
+    if offsets.dtype != torch.int32 or pe.dtype != torch.float32 or not pe.is_contiguous() or slot_mask.numel() != B * ring_T or pos_rows.numel() != B * ring_T * D:
+        raise ValueError("cfm.stream_prep: offsets int32 [B], pe contiguous f32 [max_len,D], slot_mask [B,ring_T], pos_rows [B,ring_T,D]")
+    _c.check(_c.lib().cfm_stream_prep(_c.ptr(offsets), B, T, need, ring_T, _c.ptr(pe), pe.numel() // D, D, _c.ptr(slot_mask), _c.ptr(pos_rows), _c.ptr(abs_rows),
+                                      _c.stream()), "cfm_stream_prep")
+
+
+def stream_advance(offsets, T, active=None):
+    _c.require_hip(offsets, active)
+    _c.check(_c.lib().cfm_stream_advance(_c.ptr(offsets), _c.ptr(active), offsets.numel(), T, _c.stream()), "cfm_stream_advance")
+
+
+def dwconv_causal_bn_silu(x, w, dw_bias, bn_scale, bn_shift, cache=None, out_dtype=None):
+    """OPT-IN causal depthwise conv + folded BatchNorm + SiLU over [cache | x]; x [B,T,D], cache f32 [B,K-1,D] or None (zeros)."""
+    _c.require_hip(x, w, dw_bias, bn_scale, bn_shift, cache)
+    B, T, D = x.shape
+    K = w.shape[1]
+    if not x.is_contiguous() or (cache is not None and (cache.dtype != torch.float32 or tuple(cache.shape) != (B, K - 1, D) or not cache.is_contiguous())):
+        raise ValueError("cfm.dwconv_causal_bn_silu: x contiguous [B,T,D], cache contiguous f32 [B,K-1,D]")
+    y = torch.empty((B, T, D), dtype=out_dtype or x.dtype, device=x.device)
+    _c.check(_c.lib().cfm_dwconv_causal_bn_silu(_c.ptr(x), _c.dt_code(x), _c.ptr(cache), _c.ptr(w), _c.ptr(dw_bias), _c.ptr(bn_scale), _c.ptr(bn_shift), _c.ptr(y),
+                                                _c.dt_code(y), B, T, D, K, _c.stream()), "cfm_dwconv_causal_bn_silu")
+    return y
+
+
+def conv_cache_update(x, cache, ktaps):
+    _c.require_hip(x, cache)
+    B, T, D = x.shape
+    _c.check(_c.lib().cfm_conv_cache_update(_c.ptr(x), _c.dt_code(x), _c.ptr(cache), B, T, D, ktaps, _c.stream()), "cfm_conv_cache_update")

@@ -46,6 +46,10 @@ class ConvolutionModule(nn.Module):
         self.activation = nn.SiLU()
         self.pointwise_conv2 = nn.Conv1d(input_dim, input_dim, kernel_size=1, stride=1, padding=0)
         self._pack = packing.PackCache()
+        # OPT-IN extension, not in the reference (which has no causal mode and ignores its cache, convolution.py:34-39): the depthwise taps
+        # reach back kernel_size-1 frames instead of (kernel_size-1)/2 each way, and `cache` (B, kernel_size-1, D) carries the left context
+        # between chunks -- then chunk-by-chunk output equals the whole-utterance output.  False = the reference's convolution, bit for bit.
+        self.causal = False
 
     def forward(self, inputs, inputs_pad_mask, cache=_NO_CACHE):
         cfm.require_hip(inputs)
@@ -65,6 +69,15 @@ class ConvolutionModule(nn.Module):
         x = _rows_f32(inputs)
         glu = cfm.gemm(x, pk.pw1_w, bias=pk.pw1_b, w_lo=pk.pw1_w_lo, act=cfm.ACT_GLU, row_mask=keep, mask_mode=1,
                        out_dtype=prec.act_dtype)
+        if self.causal:
+            K = self.depthwise_conv.kernel_size[0]
+            have = cache is not None and cache.dim() == 3 and cache.size(0) > 0
+            ctx = cache.to(device=inputs.device, dtype=torch.float32).contiguous() if have else None
+            dw = cfm.dwconv_causal_bn_silu(glu.view(B, T, D), pk.dw_w, pk.dw_b, pk.bn_scale, pk.bn_shift, cache=ctx)
+            new_ctx = ctx.clone() if have else torch.zeros((B, K - 1, D), dtype=torch.float32, device=inputs.device)
+            cfm.conv_cache_update(glu.view(B, T, D), new_ctx, K)
+            out = cfm.gemm(dw.view(B * T, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, out_dtype=torch.float32)
+            return out.view(B, T, D).to(inputs.dtype), new_ctx
         dw = cfm.dwconv_bn_silu(glu.view(B, T, D), pk.dw_w, pk.dw_b, pk.bn_scale, pk.bn_shift)
         out = cfm.gemm(dw.view(B * T, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0,
                        out_dtype=torch.float32)

@@ -63,8 +63,11 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     const int M = c.M, D = c.D, FF = c.FF, H = io->H, dk = D / H, adt = c.act_dt;
     const float eps = 1e-5f;
     const bool has_pos = io->pos_rows > 0 && w->pos_w;
+    const bool ring = io->kv_ring != nullptr;
+    CFM_CHECK_ARG(!ring || (io->stream_offset && io->ring_T >= io->T && !io->attn_cache && !io->new_cache),
+                  "encoder layer: the K/V ring needs stream_offset and ring_T >= T, and excludes attn_cache / new_cache");
     const int Tc = io->attn_cache ? io->cache_T : 0;
-    const int Tk = Tc + io->T;
+    const int Tk = ring ? io->ring_T : Tc + io->T;
     int P = 0;
     if (has_pos) {
         CFM_CHECK_ARG((io->pos_embed || io->pos_proj) && (io->pos_shared || io->pos_rows % io->B == 0),
@@ -119,9 +122,14 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
     if (io->new_cache)
         CFM_TRY(cfm_kv_cache_pack(io->attn_cache, Tc, kq, vq, adt, sb, stt, sb, stt, io->new_cache, io->B, H, io->T, dk, stream));
+    if (ring)
+        CFM_TRY(cfm_kv_ring_write(kq, vq, adt, sb, stt, sb, stt, io->kv_ring, io->stream_offset, io->B, H, io->T, dk, io->ring_T, stream));
     cfm_attn_desc a = {};
     a.q = s->qkv; a.q_sb = sb; a.q_st = stt; a.q_dtype = adt;
-    if (Tc > 0) {  // keys/values = [cache | new], already concatenated in new_cache (f32)
+    if (ring) {    // keys/values: every slot of the ring; the slot mask picks this step's context
+        a.k = io->kv_ring; a.v = io->kv_ring + dk; a.kv_dtype = CFM_F32;
+        a.k_sb = a.v_sb = (int64_t)H * Tk * 2 * dk; a.k_sh = a.v_sh = (int64_t)Tk * 2 * dk; a.k_st = a.v_st = 2 * dk;
+    } else if (Tc > 0) {  // keys/values = [cache | new], already concatenated in new_cache (f32)
         a.k = io->new_cache; a.v = io->new_cache + dk; a.kv_dtype = CFM_F32;
         a.k_sb = a.v_sb = (int64_t)H * Tk * 2 * dk; a.k_sh = a.v_sh = (int64_t)Tk * 2 * dk; a.k_st = a.v_st = 2 * dk;
     } else {
@@ -147,8 +155,11 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
         CFM_TRY(cfm_rowchain(&ci, stream));
         // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own
-        const bool dw_fused = io->ktaps == 15;
-        if (!dw_fused)
+        const bool dw_fused = io->ktaps == 15 && !io->causal_conv;
+        if (io->causal_conv) {
+            CFM_TRY(cfm_dwconv_causal_bn_silu(s->glu, adt, io->conv_cache, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+            if (io->conv_cache) CFM_TRY(cfm_conv_cache_update(s->glu, adt, io->conv_cache, io->B, io->T, D, io->ktaps, stream));
+        } else if (!dw_fused)
             CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
         // final chain: pointwise-conv-2 + pad mask + residual -> LN_ff -> FFN -> +res -> LN_final, in place on x_out
         cfm_rowchain_desc fi = {};
@@ -165,7 +176,11 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     // (3) convolution module: mask -> pw1+GLU -> depthwise+BN+SiLU -> pw2 -> mask
     CFM_TRY(cfm_layernorm(x_out, w->ln_conv_g, w->ln_conv_b, nullptr, 0, nullptr, nullptr, s->xn, adt, io->pad_valid, eps, M, D, stream));
     CFM_TRY(gemm(c, s->xn, adt, D, w->pw1_w, w->pw1_w_lo, w->pw1_b, s->glu, adt, D, M, 2 * D, D, CFM_ACT_GLU, nullptr, 0.f, nullptr));
-    CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+    if (io->causal_conv) {
+        CFM_TRY(cfm_dwconv_causal_bn_silu(s->glu, adt, io->conv_cache, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+        if (io->conv_cache) CFM_TRY(cfm_conv_cache_update(s->glu, adt, io->conv_cache, io->B, io->T, D, io->ktaps, stream));
+    } else
+        CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
     CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, io->pad_valid));
 
     // (4) feed-forward + (5) norm_final: in place on x_out (a workgroup reads its 32 rows completely before writing them)

@@ -43,8 +43,9 @@ class ConformerEncoder(nn.Module):
         self.static_chunk_size = static_chunk_size
 
     # ------------------------------------------------------------------------------------------------------------
-    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from, pos_shared=False, proj=None):
-        """x (B,T',D) f32 -> after_norm(blocks(x)); returns (y, [trimmed per-layer caches] | None)."""
+    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from, pos_shared=False, proj=None, ring=None, conv=None):
+        """x (B,T',D) f32 -> after_norm(blocks(x)); returns (y, [trimmed per-layer caches] | None).
+        ring = (kv f32 [L,B,H,ring_T,2dk], offsets int32 [B]), conv = f32 [L,B,K-1,D] | None: per-stream streaming state (StreamingBatch)."""
         n = len(self.encoders)
         if proj is None:
             proj = self._project_positions(pos_embed, x)
@@ -66,6 +67,7 @@ class ConformerEncoder(nn.Module):
             pp = None if proj is None else (proj[:, i * self.encoder_dim:], proj.stride(0))
             out, nc = block.fused_forward(cur, attn_mask, pos_embed, pad_mask, cache_i, xn_ready=ready, next_norm=nxt,
                                           out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pos_shared=pos_shared,
+                                          ring=None if ring is None else (ring[0][i], ring[1]), conv_cache=None if conv is None else conv[i],
                                           after=(self.after_norm.weight.detach(), self.after_norm.bias.detach(), y_after)
                                           if fuse_after and i + 1 == n else None)
             if new_caches is not None:
@@ -278,3 +280,121 @@ class StreamingSession:
         torch.cuda.current_stream(dev).wait_stream(stream)
         self.kv.copy_(self.cache)                                  # the capture pass and its warm-up advanced the static cache: restore
         self.graph = graph
+
+
+
+class StreamingBatch:
+    """B independent streams, each at ITS OWN position, advanced together one chunk per step (BASELINE config 5:
+    64 streams, chunk 16, cached left context) -- what the reference cannot do: its forward_chunk serves one stream at a time
+    (encoder.py:78-123: the positional view fails at batch > 1) and rebuilds the attention cache with cat + slice every step (:117).
+
+      * per-stream state lives on the device: `offsets` int32 [B] (encoder frames consumed) and, per layer, a K/V RING buffer
+        f32 [B,H,need+chunk,2dk] -- frame f in slot f mod ring_T; a step writes its `chunk` new frames and moves nothing;
+      * a step is: front-end on the B windows, cfm_stream_prep (slot mask + positional rows per stream from `offsets`), one projection
+        of those rows for all layers, the blocks with attention over the ring under the slot mask, cfm_stream_advance;
+      * no host-side scalar enters the step, so it is captured ONCE as a HIP graph and replayed (graph=True);
+      * item b of the output equals the reference's batch-1 forward_chunk on stream b with its own cache and offset (tests: against
+        the CPU oracle looped per stream) to the precision mode's tolerance -- not bit for bit, the softmax sums run in slot order;
+      * causal_conv=True is the OPT-IN extension (not in the reference, which has no causal convolution and ignores cnn_cache):
+        every block's depthwise conv becomes causal with a (K-1)-frame left context per stream.  Off = the reference's arithmetic.
+
+    step(frames (B, (chunk-1)*4+7, F)) -> (B, chunk, D) in a buffer the next step overwrites.  reset(streams) starts new utterances."""
+
+    def __init__(self, encoder, streams, decoding_chunk_size, num_decoding_left_chunks, causal_conv=False, graph=True):
+        if num_decoding_left_chunks < 0:
+            raise ValueError("StreamingBatch needs a bounded left context (num_decoding_left_chunks >= 0)")
+        if encoder.training:
+            raise NotImplementedError("StreamingBatch: streaming is inference-only; call encoder.eval()")
+        self.enc, self.B = encoder, int(streams)
+        self.chunk, self.need = int(decoding_chunk_size), int(decoding_chunk_size) * int(num_decoding_left_chunks)
+        self.ring_T = self.need + self.chunk
+        self.window = (self.chunk - 1) * 4 + 7
+        self.relative = isinstance(encoder.position_encoding, RelativePositionalEncoding)
+        blk = encoder.encoders[0]
+        L, H, D, K = len(encoder.encoders), blk.num_heads, encoder.encoder_dim, blk.kernel_size
+        dev = next(encoder.parameters()).device
+        cfm.require_hip(next(encoder.parameters()))
+        self.dev = dev
+        self.offsets = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+        self.kv = torch.zeros((L, self.B, H, self.ring_T, 2 * (D // H)), dtype=torch.float32, device=dev)      # zero: masked slots must stay finite
+        self.slot_mask = torch.zeros((self.B, 1, self.ring_T), dtype=torch.uint8, device=dev)
+        self.pos_rows = torch.zeros((self.B * self.ring_T, 1, D), dtype=torch.float32, device=dev)
+        self.abs_rows = None if self.relative else torch.zeros((self.B, 1, D), dtype=torch.float32, device=dev)
+        self.causal = bool(causal_conv)
+        self.conv = torch.zeros((L, self.B, K - 1, D), dtype=torch.float32, device=dev) if self.causal else None
+        self.pe = encoder.position_encoding.pe.reshape(-1, D).to(device=dev, dtype=torch.float32).contiguous()
+        self.x = None
+        self.use_graph, self.graph, self.y, self._sig = bool(graph), None, None, None
+        self.steps = 0
+
+    def reset(self, streams=None):
+        """start new utterances on the given streams (all by default): position 0, empty left context."""
+        if streams is None:
+            self.offsets.zero_()
+            if self.conv is not None:
+                self.conv.zero_()
+        else:
+            idx = torch.as_tensor(list(streams), dtype=torch.long, device=self.dev)
+            self.offsets[idx] = 0
+            if self.conv is not None:
+                self.conv[:, idx] = 0
+
+    def _signature(self):
+        from cfm import packing
+        sig = packing._EPOCH[0]
+        for t in list(self.enc.parameters()) + list(self.enc.buffers()):
+            sig = sig * 1000003 + t._version + (t.data_ptr() & 0xFFFFF)
+        return sig & ((1 << 62) - 1), str(cfm.resolve_precision(self.enc))
+
+    def _step_impl(self):
+        enc = self.enc
+        for blk in enc.encoders:
+            blk.conv_module.causal = self.causal
+        try:
+            inputs, cmvn = enc._cmvn_args(self.x)
+            x = enc.embed.embed_frames(inputs, cmvn)
+            cfm.stream_prep(self.offsets, self.chunk, self.need, self.ring_T, self.pe, self.slot_mask, self.pos_rows, self.abs_rows)
+            if self.relative:
+                x, _ = enc.position_encoding(x, 0)
+            else:
+                x, _ = enc.position_encoding(x, 0, rows=self.abs_rows)
+            proj = enc._project_positions(self.pos_rows, x)
+            y, _ = enc._run_blocks(x, self.slot_mask.view(torch.bool), self.pos_rows, None, None, 0, proj=proj, ring=(self.kv, self.offsets), conv=self.conv)
+            cfm.stream_advance(self.offsets, self.chunk)
+        finally:
+            for blk in enc.encoders:
+                blk.conv_module.causal = False
+        return y
+
+    def step(self, frames):
+        if tuple(frames.shape[:2]) != (self.B, self.window):
+            raise ValueError("StreamingBatch.step wants (%d, %d, F) frames, got %s" % (self.B, self.window, tuple(frames.shape)))
+        cfm.require_hip(frames)
+        if self.x is None:
+            self.x = torch.empty_like(frames, dtype=torch.float32).contiguous()
+        self.x.copy_(frames)
+        self.steps += 1
+        with torch.no_grad():
+            if not self.use_graph:
+                return self._step_impl()
+            if self.graph is not None and self._signature() != self._sig:
+                self.graph = None                                         # weights changed under the captured graph
+            if self.graph is None:
+                y = self._step_impl()                                     # this step runs eagerly (it also sizes the arena and packs the weights)
+                stream = torch.cuda.Stream(device=self.dev)
+                stream.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(stream):
+                    saved = self.offsets.clone(), None if self.conv is None else self.conv.clone()
+                    self._step_impl()                                     # warm-up ON the capture stream (its own scratch arena) ...
+                    stream.synchronize()
+                    self.offsets.copy_(saved[0])                          # ... with the state it advanced put back (ring slots rewritten: same data)
+                    if self.conv is not None:
+                        self.conv.copy_(saved[1])
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=stream):
+                        self.y = self._step_impl()
+                torch.cuda.current_stream(self.dev).wait_stream(stream)
+                self.graph, self._sig = graph, self._signature()
+                return y
+            self.graph.replay()
+            return self.y

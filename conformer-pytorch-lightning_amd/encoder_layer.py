@@ -59,8 +59,11 @@ class ConformerEncoderLayer(nn.Module):
         return self._fused[1]
 
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
-                      want_cache=True, pos_proj=None, pos_shared=False, after=None):
-        """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified."""
+                      want_cache=True, pos_proj=None, pos_shared=False, after=None, ring=None, conv_cache=None):
+        """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified.
+        ring = (kv_ring f32 [B,H,ring_T,2dk], offsets int32 [B]): per-stream streaming state (include/cfm.h cfm_layer_io.kv_ring);
+        attn_mask is then the (B,1,ring_T) slot mask and pos_embed the B*ring_T positional rows.  conv_cache f32 [B,K-1,D]: the
+        opt-in causal convolution's left context (only with conv_module.causal)."""
         _inference_only(self, "ConformerEncoderLayer.fused_forward")
         cfm.require_hip(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
@@ -73,10 +76,12 @@ class ConformerEncoderLayer(nn.Module):
         dev = x.device
         M = B * T
 
+        if ring is not None:
+            attn_cache, want_cache = None, False
         have_cache = attn_cache is not None and attn_cache.dim() == 4 and attn_cache.size(0) > 0
         cache = attn_cache.to(device=dev, dtype=torch.float32).contiguous() if have_cache else None
         Tc = cache.size(2) if have_cache else 0
-        Tk = Tc + T
+        Tk = Tc + T if ring is None else ring[0].size(2)
         if have_cache and tuple(cache.shape) != (B, H, Tc, 2 * dk):
             raise RuntimeError("attn_cache of shape %s, expected (%d,%d,Tc,%d)" % (tuple(cache.shape), B, H, 2 * dk))
         new_cache = torch.empty((B, H, Tk, 2 * dk), dtype=torch.float32, device=dev) if (have_cache or want_cache) else None
@@ -119,6 +124,21 @@ class ConformerEncoderLayer(nn.Module):
         if after is not None:                          # (gain, bias, f32 output [B,T,D]): the encoder's after_norm in the final chain
             io.after_g, io.after_b, io.after_out = after[0].data_ptr(), after[1].data_ptr(), after[2].data_ptr()
         io.new_cache = cfm.ptr(new_cache)
+        if ring is not None:
+            kv, offs = ring
+            if kv.dtype != torch.float32 or tuple(kv.shape) != (B, H, Tk, 2 * dk) or not kv.is_contiguous() or offs.dtype != torch.int32 or offs.numel() != B:
+                raise RuntimeError("ring: kv must be contiguous float32 (B,H,ring_T,2dk) and offsets int32 (B,)")
+            cfm.require_hip(kv, offs)
+            io.kv_ring, io.stream_offset, io.ring_T = kv.data_ptr(), offs.data_ptr(), Tk
+        if getattr(self.conv_module, "causal", False):
+            io.causal_conv = 1
+            if conv_cache is not None:
+                if conv_cache.dtype != torch.float32 or tuple(conv_cache.shape) != (B, self.kernel_size - 1, D) or not conv_cache.is_contiguous():
+                    raise RuntimeError("conv_cache must be contiguous float32 (B, kernel_size-1, D)")
+                cfm.require_hip(conv_cache)
+                io.conv_cache = conv_cache.data_ptr()
+        elif conv_cache is not None:
+            raise RuntimeError("a conv cache needs the opt-in causal convolution (conv_module.causal = True)")
         if out is None:
             out = torch.empty_like(x)
         ng = nb = None

@@ -315,6 +315,27 @@ int cfm_chunk_mask(uint8_t* out, int32_t size, int32_t chunk, int32_t left, cfm_
 int cfm_attn_mask(const uint8_t* valid, const uint8_t* chunk, uint8_t* out, int32_t B, int32_t T,
                   cfm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-stream state of the batched streaming step (csrc/stream.hip) -- beyond the reference, whose forward_chunk serves one stream at a
+ * time (encoder.py:78-123) and rebuilds its cache with cat + slice (:117).  offsets int32 [B] on the device: encoder frames each stream has
+ * consumed.  need = chunk * left_chunks cached frames, ring_T >= need + T slots.
+ *  cfm_stream_prep     slot_mask u8 [B,ring_T] = slot holds a frame of [offset-min(offset,need), offset+T); pos_rows f32 [B,ring_T,D] = pe[that
+ *                      frame] (pe f32 [max_len,D], the sinusoid table of attention.py:12-16); abs_rows f32 [B,D] = pe[offset] (optional: the
+ *                      absolute encoding's row, attention.py:119-120)
+ *  cfm_kv_ring_write   K / V rows of the T new frames (addressed like cfm_attn_desc k / v, head h at h*dk) -> ring slots (offset+t) mod ring_T
+ *  cfm_stream_advance  offset[b] += T for streams with active[b] != 0 (active NULL: all)
+ *  cfm_dwconv_causal_bn_silu  y = SiLU(BN_eval(causal depthwise conv over [cache | x])), cache f32 [B,ktaps-1,D] or NULL (zeros)
+ *  cfm_conv_cache_update      cache <- last ktaps-1 frames of [cache | x], in place
+ */
+int cfm_stream_prep(const int32_t* offsets, int32_t B, int32_t T, int32_t need, int32_t ring_T, const float* pe, int32_t max_len, int32_t D,
+                    uint8_t* slot_mask, float* pos_rows, float* abs_rows, cfm_stream_t stream);
+int cfm_kv_ring_write(const void* k, const void* v, int32_t kv_dtype, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, float* ring,
+                      const int32_t* offsets, int32_t B, int32_t H, int32_t T, int32_t dk, int32_t ring_T, cfm_stream_t stream);
+int cfm_stream_advance(int32_t* offsets, const uint8_t* active, int32_t B, int32_t T, cfm_stream_t stream);
+int cfm_dwconv_causal_bn_silu(const void* x, int32_t x_dtype, const float* cache, const float* w, const float* dw_bias, const float* bn_scale,
+                              const float* bn_shift, void* y, int32_t y_dtype, int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream);
+int cfm_conv_cache_update(const void* x, int32_t x_dtype, float* cache, int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream);
+
 /* element-wise dtype conversion:  dst = cast(src) */
 int cfm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, cfm_stream_t stream);
 /* x[r,:] += add[r / group, :]   (f32, in place; the absolute positional encoding of attention.py:119-120,
@@ -369,6 +390,18 @@ typedef struct {
     const float *after_g, *after_b; /* optional, chain path only: ALSO write LN(x_out; after_g, after_b) to after_out (f32 [B*T,D]) -- the
                                        encoder's after_norm fused into the last block's final chain */
     float* after_out;
+    /* Batched streaming with PER-STREAM state (csrc/stream.hip; beyond the reference): when kv_ring is set, this layer's keys /
+     * values live in a ring buffer f32 [B,H,ring_T,2dk] (frame f of a stream in slot f mod ring_T); the step's T new frames of stream b are
+     * frames stream_offset[b] .. +T-1 and are written to their slots, attention runs over all ring_T slots with attn_mask = the (B,1,ring_T)
+     * slot mask and pos_rows = B*ring_T positional rows (both from cfm_stream_prep).  attn_cache / new_cache are unused then. */
+    float* kv_ring;
+    const int32_t* stream_offset;
+    int32_t ring_T;
+    /* OPT-IN causal depthwise convolution (not in the reference, which has no causal mode and ignores cnn_cache: convolution.py:34-39):
+     * taps reach back ktaps-1 frames instead of (ktaps-1)/2 each way; conv_cache f32 [B,ktaps-1,D] (optional) is the left context of this
+     * chunk -- the last GLU outputs of the previous one -- and is updated in place.  0 = the reference's symmetric convolution. */
+    int32_t causal_conv;
+    float* conv_cache;
     int32_t pos_shared;       /* 1: the pos_rows == Tk positional rows are the SAME for every batch item (batched streaming step: all
                                  streams at one offset).  Beyond the reference, whose forward_chunk only works at batch 1
                                  (attention.py:78-88); per item it equals that batch-1 call. */

@@ -212,10 +212,12 @@ def mhsa(P, prefix, x, mask, cache=None, n_heads=4):
 # =============================================================================
 # Row E -- convolution module.  reference src/convolution.py:34-49
 # =============================================================================
-def conv_module(P, prefix, x, valid_mask, bn_eps=1e-5, train=False, bn_out=None, momentum=0.1):
+def conv_module(P, prefix, x, valid_mask, bn_eps=1e-5, train=False, bn_out=None, momentum=0.1, causal=False, conv_cache=None, cache_out=None):
     """x (B,T,D) time-major.  train=True: BatchNorm1d in training mode (convolution.py:44 under module.train()) -- batch mean and
     BIASED variance over ALL B*T positions of each channel, padded frames included (quirk Q6); the running statistics it would
     leave behind (momentum 0.1, UNBIASED variance, torch's rule) are returned through bn_out[prefix] = (mean, var).
+    causal=True is NOT the reference (which has no causal mode, convolution.py:34-39): it restates the build's opt-in extension -- the
+    depthwise taps reach back K-1 frames, conv_cache (B,K-1,D) is the left context (zeros when None), cache_out[prefix] receives the next one.
     Channels-last restatement of
     mask -> pointwise(D->2D) -> GLU -> depthwise k (zero pad only at the tensor edges) -> BatchNorm(eval) -> SiLU
     -> pointwise(D->D) -> mask.   Quirk Q5: masking precedes pw1, so padded frames carry GLU(bias) into the halo.
@@ -231,8 +233,14 @@ def conv_module(P, prefix, x, valid_mask, bn_eps=1e-5, train=False, bn_out=None,
     wd = _w(P, prefix, "depthwise_conv.weight")[:, 0, :]                    # (D, K)
     K = wd.size(1)
     half = (K - 1) // 2
-    ypad = torch.zeros(B, T + 2 * half, D, dtype=y.dtype)
-    ypad[:, half:half + T] = y
+    if causal:
+        ctx = torch.zeros(B, K - 1, D, dtype=y.dtype) if conv_cache is None else conv_cache.to(y.dtype)
+        ypad = torch.cat([ctx, y], dim=1)
+        if cache_out is not None:
+            cache_out[prefix] = ypad[:, -(K - 1):].clone()
+    else:
+        ypad = torch.zeros(B, T + 2 * half, D, dtype=y.dtype)
+        ypad[:, half:half + T] = y
     z = torch.zeros_like(y)
     for tap in range(K):                                                    # cross-correlation, like nn.Conv1d
         z = z + ypad[:, tap:tap + T] * wd[:, tap]

@@ -625,6 +625,121 @@ def test_two_encoders_two_streams_two_precisions(pkg):
     pkg.cfm.set_precision("bf16")
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("graph", [False, True])
+def test_streaming_batch_per_stream_offsets(pkg, mode, graph):
+    """encoder.StreamingBatch: streams that started at DIFFERENT times (so different offsets and cache fills) advance in one batched
+    step over per-layer K/V rings; every stream's output equals the batch-1 forward_chunk loop on that stream alone (the path the
+    reference's goldens pin) within the mode's tolerance."""
+    g, meta = load_golden("enc_cfg1_stream")
+    pkg.cfm.set_precision(mode)
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    B, chunk, left, steps = 5, 4, 2, 11
+    hop, window, need = 4 * chunk, (chunk - 1) * 4 + 7, chunk * left
+    feats = dev(synth.fbank(95, B, window + hop * steps))
+    start = [0, 0, 2, 3, 5]                                           # stream b begins its utterance at global step start[b]
+    sb = pkg.encoder.StreamingBatch(enc, B, chunk, left, graph=graph)
+    empty = torch.zeros((0, 0, 0, 0), device=DEV)
+    ref_cache, ref_off = [empty] * B, [0] * B
+    worst = 0.0
+    with torch.no_grad():
+        for s in range(steps):
+            restart = [b for b in range(B) if start[b] == s and s > 0]
+            if restart:
+                sb.reset(restart)
+            wins = []
+            for b in range(B):
+                k = max(s - start[b], 0)                              # the stream's own step counter (idle streams replay window 0: ignored below)
+                wins.append(feats[b, k * hop: k * hop + window])
+            y = sb.step(torch.stack(wins).contiguous()).clone()
+            for b in range(B):
+                if s < start[b]:
+                    continue
+                y_ref, ref_cache[b], _ = enc.forward_chunk(wins[b].unsqueeze(0).contiguous(), ref_off[b], need, ref_cache[b], empty)
+                ref_off[b] += y_ref.size(1)
+                worst = max(worst, relerr(y[b:b + 1], y_ref))
+        assert sb.offsets.tolist() == [(steps - st) * chunk for st in start]
+        assert (sb.graph is not None) == graph
+    print("  [%s] StreamingBatch (graph=%s), staggered streams vs batch-1 forward_chunk: %.3e" % (mode, graph, worst))
+    assert worst < TOL[mode] * 2.0, worst
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_config5_64_streams_against_oracle(pkg, mode):
+    """BASELINE config 5 at its real size: 64 streams x chunk 16 (67-frame windows) x 4 cached chunks on the 12-layer d=256 model, one
+    captured step; streams checked against the CPU oracle's batch-1 forward_chunk loop (reference semantics, encoder.py:78-123)."""
+    from oracle import conformer_oracle as O
+    pkg.cfm.set_precision(mode)
+    enc = build_encoder(pkg, CFG2, 12)
+    B, chunk, left, steps = 64, 16, 4, 7
+    hop, window, need = 4 * chunk, (chunk - 1) * 4 + 7, chunk * left
+    feats = dev(synth.fbank(96, B, window + hop * steps))
+    sb = pkg.encoder.StreamingBatch(enc, B, chunk, left)
+    outs = []
+    with torch.no_grad():
+        for s in range(steps):
+            outs.append(sb.step(feats[:, s * hop: s * hop + window].contiguous()).clone())
+    assert sb.graph is not None and sb.offsets.tolist() == [steps * chunk] * B
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    cfg = O.Config(**CFG2)
+    worst = 0.0
+    for b in (0, 17, 63):
+        cache, off = None, 0
+        for s in range(steps):
+            y_ref, cache = O.encoder_forward_chunk(P, cfg, feats[b:b + 1, s * hop: s * hop + window].cpu(), off, need, cache)
+            off += y_ref.size(1)
+            worst = max(worst, relerr(outs[s][b:b + 1], y_ref))
+    print("  [%s] config 5 (64 streams x chunk 16 x left 4, 12 layers) vs oracle per stream: %.3e" % (mode, worst))
+    assert worst < TOL[mode] * 2.0, worst
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_causal_conv_extension(pkg, mode):
+    """The OPT-IN causal depthwise convolution (not in the reference): (a) the module against the oracle's restatement of the extension,
+    (b) chunk-by-chunk with the conv cache equals the whole sequence at once, (c) off by default -- the reference's arithmetic untouched,
+    (d) StreamingBatch(causal_conv=True) carries the per-stream conv context."""
+    from oracle import conformer_oracle as O
+    from test_oracle_golden import conv_shapes, table
+    g, meta = load_golden("mods_d144")
+    D, FF, K, B, T = meta["D"], meta["FF"], meta["K"], 3, 48
+    pkg.cfm.set_precision(mode)
+    m = synth.load_synth_(pkg.convolution.ConvolutionModule(D, K, FF).eval(), 33).to(DEV)
+    x = dev(synth.normal(97, (B, T, D)))
+    nomask = torch.ones((0, 0, 0), dtype=torch.bool, device=DEV)
+    P = table(conv_shapes(D, K), 33)
+    with torch.no_grad():
+        y_plain, _ = m(x, nomask)
+        m.causal = True
+        y_full, c_full = m(x, nomask)
+        y_ref = O.conv_module(P, "", x.cpu(), None, causal=True)
+        check("causal conv module vs oracle restatement", y_full, y_ref, mode)
+        assert relerr(y_full, y_plain) > 1e-2                           # it really is another convolution
+        pieces, cache = [], torch.zeros((0, 0, 0), device=DEV)
+        for t0 in range(0, T, 16):
+            yc, cache = m(x[:, t0:t0 + 16].contiguous(), nomask, cache)
+            pieces.append(yc)
+        assert relerr(torch.cat(pieces, 1), y_full) < (1e-6 if mode == "fp32" else TOL[mode])
+        assert torch.equal(cache, c_full)
+        m.causal = False
+        assert torch.equal(m(x, nomask)[0], y_plain)
+    # (d) through the batched streaming step
+    g2, meta2 = load_golden("enc_cfg1_stream")
+    enc = build_encoder(pkg, meta2["cfg"], meta2["wseed"])
+    Bs, chunk, left, steps = 3, 4, 2, 6
+    hop, window = 4 * chunk, (chunk - 1) * 4 + 7
+    feats = dev(synth.fbank(98, Bs, window + hop * steps))
+    sc, sn = pkg.encoder.StreamingBatch(enc, Bs, chunk, left, causal_conv=True), pkg.encoder.StreamingBatch(enc, Bs, chunk, left)
+    Penc = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    cfg = O.Config(**meta2["cfg"])
+    with torch.no_grad():
+        for s in range(steps):
+            w = feats[:, s * hop: s * hop + window].contiguous()
+            yc, yn = sc.step(w).clone(), sn.step(w).clone()
+            assert relerr(yc, yn) > 1e-3
+    assert all(not blk.conv_module.causal for blk in enc.encoders)      # the opt-in does not leak into the modules
+    assert float(sc.conv.abs().max()) > 0 and sn.conv is None
+
+
 def test_general_path_matches_chain_path_including_after_norm(pkg):
     """cfm_encoder_layer_forward picks the row chains when every fragment-major pack is present; with those packs withheld the same
     block runs on the general path (separate GEMMs, LayerNorm and depthwise kernels).  Both must agree, including the encoder's
