@@ -427,7 +427,12 @@ def gemm_tn(a, b, out=None, want_colsum=False, row_mask=None, alpha=1.0, conv=No
     if out is None:
         if accumulate:
             raise ValueError("cfm.gemm_tn: accumulate needs an existing out")
-        out = torch.empty((N, K), dtype=torch.float32, device=a.device)
+        if want_colsum and colsum is None and not _deterministic[0]:
+            # weight and bias gradient in ONE zero-filled buffer (one fill launch instead of the library's two memsets), then accumulate
+            buf = torch.zeros((N * K + N,), dtype=torch.float32, device=a.device)
+            out, colsum, accumulate = buf[:N * K].view(N, K), buf[N * K:], True
+        else:
+            out = torch.empty((N, K), dtype=torch.float32, device=a.device)
     elif out.dtype != torch.float32 or tuple(out.shape) != (N, K) or out.stride(1) != 1:
         raise ValueError("cfm.gemm_tn: out must be float32 (%d,%d)" % (N, K))
     if want_colsum and colsum is None:

@@ -41,14 +41,12 @@ __global__ void cfm_attn_delta_kernel(const AttnBwdArgs a) {
     const int b = (int)(id / ((int64_t)a.Tq * a.H));
     const int64_t o = ((int64_t)b * a.Tq + i) * ((int64_t)a.H * a.dk) + (int64_t)h * a.dk;
     float s = 0.f;
-    for (int d = 0; d < a.dk; d += 4) {
-        float x[4], y[4];
+    for (int d = 0; d < a.dk; d += 8) {
+        float x[8], y[8];
+        load8f(a.out, a.io_dt, o + d, a.dk - d, x);            // 16-byte loads when aligned
+        load8f(a.dout, a.do_dt, o + d, a.dk - d, y);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x[e] = load_as_f32(a.out, o + d + e, a.io_dt);
-            y[e] = load_as_f32(a.dout, o + d + e, a.do_dt);
-        }
-        s += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+        for (int e = 0; e < 8; ++e) s = fmaf(x[e], y[e], s);
     }
     a.delta[id] = s;
 }

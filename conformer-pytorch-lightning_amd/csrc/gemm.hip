@@ -604,6 +604,10 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
         const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
         const long t64x128 = (long)((a.M - a.m_begin + 63) / 64) * ((a.N + 127) / 128);
         tile = t128 >= 224 ? 1 : (t64x128 >= 224 ? 2 : 3);
+        if constexpr (!SPLIT) {                   // narrow outputs (N = D) at training batch sizes: 64 x 64 tiles fill under half the CUs
+            const long t64 = (long)((a.M - a.m_begin + 63) / 64) * ((a.N + 63) / 64), t32x64 = (long)((a.M - a.m_begin + 31) / 32) * ((a.N + 63) / 64);
+            if (tile == 3 && t64 < 192 && t32x64 >= 96) tile = 5;
+        }
     }
     switch (tile) {
         case 1: return launch<HT, 128, 128, BK, A_F32, SPLIT, CONV>(a, s, base);

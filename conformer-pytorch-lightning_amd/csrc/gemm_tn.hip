@@ -8,9 +8,12 @@
 // one column, two of them make the 8-element MFMA fragment.  Both operands use the same (permuted) m order inside a 32-row
 // step -- {4g..4g+3, 16+4g..16+4g+3} for lane group g -- which is all the contraction needs.
 //
-//   tile   128 (n) x 128 (k) outputs per workgroup, 256 threads = 2 x 2 wavefronts of 64 x 64, 16 accumulator fragments each
+//   tile   128 x 128 or 64 x 64 outputs per workgroup (template TILE), 256 threads = 2 x 2 wavefronts of TILE/2 x TILE/2
 //   M      split over `splits` workgroups per tile (training batches are M = 2-8 k rows against N x K <= 2048 x 256 outputs: a
-//          single pass over M would leave most CUs idle); partial products meet in C through f32 atomics (global_atomic_add_f32)
+//          single pass over M would leave most CUs idle); partial products meet in C through f32 atomics (global_atomic_add_f32).
+//          Every split costs N x K atomics, and those -- not the MFMAs -- set the time of a small product (measured, config 3:
+//          66 us average with 128 x 128 tiles and 8-64 splits, 4 M atomics per feed-forward weight): small outputs therefore take the
+//          64 x 64 tile (4 x the tiles, so 4 x fewer splits for the same number of workgroups)
 //   bias   the column sums of A (d loss / d bias) ride along in the k-tile-0 workgroups: the A tile is in LDS anyway
 //   conv   B rows may be the implicit im2col rows of a channels-last image (3x3 stride 2): the front-end's conv2 weight gradient
 //   SPLIT  f32 operands split into bf16 hi/lo planes while staging, 3 MFMAs per fragment pair (the f32-accurate mode)
@@ -35,12 +38,11 @@ struct TnArgs {
     int chunks_per_split, atomic;
 };
 
-constexpr int TN_BN = 128, TN_BK = 128;
-constexpr int TN_STR = 128 + 16;   // LDS row stride in 16-bit elements: 288 B = 72 words = 8 (mod 64): the 4 rows of a transposed read hit disjoint banks
-
-template <typename HT, bool SPLIT>
+// LDS row stride in 16-bit elements: TILE + 16 -> 288 B = 72 words = 8 (mod 64) for TILE 128, 160 B = 40 words for TILE 64: the 4 rows of a
+// transposed read hit disjoint banks either way
+template <typename HT, bool SPLIT, int STR>
 __device__ __forceinline__ void stage_store(u16* tile, int plane_elems, int row, int col, const u32x4& raw, const f32x4& f0, const f32x4& f1, bool is_f32) {
-    u16* p = tile + row * TN_STR + col;
+    u16* p = tile + row * STR + col;
     if constexpr (SPLIT) {
         u32x4 hi, lo;
         split8(f0, f1, hi, lo);
@@ -52,20 +54,25 @@ __device__ __forceinline__ void stage_store(u16* tile, int plane_elems, int row,
 }
 
 // one MFMA operand fragment (16 columns starting at c0, the 32 rows of m-step ms) from a [m][col] tile
+template <int STR>
 __device__ __forceinline__ u32x4 tr_frag(const u16* tile, int ms, int c0, int g, int l15) {
-    const u16* pa = tile + (ms * 32 + 4 * g + (l15 >> 2)) * TN_STR + c0 + (l15 & 3) * 4;
+    const u16* pa = tile + (ms * 32 + 4 * g + (l15 >> 2)) * STR + c0 + (l15 & 3) * 4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 16 * TN_STR));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 16 * STR));
     const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
     return (u32x4){lo2.x, lo2.y, hi2.x, hi2.y};
 }
 
-template <typename HT, bool SPLIT, bool A32, bool B32, bool CONV>
+template <typename HT, bool SPLIT, bool A32, bool B32, bool CONV, int TILE>
 __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
+    constexpr int TN_BN = TILE, TN_BK = TILE, TN_STR = TILE + 16;
+    constexpr int FR = TILE / 32;                    // 16-wide fragments per wavefront and operand (4 or 2)
+    constexpr int PPR = TILE / 8;                    // 16-byte pieces per tile row
     constexpr int MCH = SPLIT ? 32 : 64;             // rows of M per staged chunk
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int PLANE = MCH * TN_STR;              // 16-bit elements per operand plane
-    constexpr int PASSES = MCH / 16;                 // 16-byte pieces per thread and operand: MCH rows x 16 pieces / 256 threads
+    constexpr int PASSES = MCH * PPR / 256;          // 16-byte pieces per thread and operand
+    constexpr int RPP = 256 / PPR;                   // tile rows staged per pass
     __shared__ __attribute__((aligned(16))) u16 smem[2 * 2 * NPL * PLANE];   // [buffer][A | B][plane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
     if (chunk_begin >= chunk_end) return;            // uniform, before any barrier
 
     // ---- staging: thread -> (row = pass*16 + tid/16, 8 columns at (tid & 15) * 8) of both operand tiles -------------------------
-    const int prow = tid >> 4, pcol = (tid & 15) * 8;
+    const int prow = tid / PPR, pcol = (tid % PPR) * 8;
     const bool a_col_ok = n0 + pcol < g.N;           // N % 8 == 0: a piece is entirely inside or outside
     const bool b_col_ok = k0 + pcol < g.K;
     int64_t b_koff = k0 + pcol;                      // element offset of this thread's B columns inside a row
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
     auto gload = [&](int chunk) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int m = chunk * MCH + p * 16 + prow;
+            const int m = chunk * MCH + p * RPP + prow;
             const bool row_ok = m < g.M;
             const bool a_ok = row_ok && a_col_ok && (!g.mask || g.mask[m] != 0);
             const bool b_ok = row_ok && b_col_ok;
@@ -134,19 +141,19 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
         u16* Bt = At + NPL * PLANE;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int row = p * 16 + prow;
-            if constexpr (A32) stage_store<HT, SPLIT>(At, PLANE, row, pcol, z4, fa[p][0], fa[p][1], true);
-            else stage_store<HT, SPLIT>(At, PLANE, row, pcol, ra[p], zf, zf, false);
-            if constexpr (B32) stage_store<HT, SPLIT>(Bt, PLANE, row, pcol, z4, fb[p][0], fb[p][1], true);
-            else stage_store<HT, SPLIT>(Bt, PLANE, row, pcol, rb[p], zf, zf, false);
+            const int row = p * RPP + prow;
+            if constexpr (A32) stage_store<HT, SPLIT, TN_STR>(At, PLANE, row, pcol, z4, fa[p][0], fa[p][1], true);
+            else stage_store<HT, SPLIT, TN_STR>(At, PLANE, row, pcol, ra[p], zf, zf, false);
+            if constexpr (B32) stage_store<HT, SPLIT, TN_STR>(Bt, PLANE, row, pcol, z4, fb[p][0], fb[p][1], true);
+            else stage_store<HT, SPLIT, TN_STR>(Bt, PLANE, row, pcol, rb[p], zf, zf, false);
         }
     };
 
-    f32x4 acc[4][4];                                 // [n fragment][k fragment]: lane holds C[n = .. + l15][k = .. + 4*g4 + r]
+    f32x4 acc[FR][FR];                               // [n fragment][k fragment]: lane holds C[n = .. + l15][k = .. + 4*g4 + r]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = zf;
+        for (int j = 0; j < FR; ++j) acc[i][j] = zf;
     float csum = 0.f;                                // bias gradient: thread t < 128 owns column n0 + t (k-tile 0 workgroups only)
     const bool do_colsum = g.colsum != nullptr && tile_k == 0 && tid < TN_BN;
 
@@ -160,21 +167,21 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
         const u16* Bt = At + NPL * PLANE;
 #pragma unroll
         for (int ms = 0; ms < MCH / 32; ++ms) {
-            u32x4 af[4], bf[4], afl[SPLIT ? 4 : 1], bfl[SPLIT ? 4 : 1];
+            u32x4 af[FR], bf[FR], afl[SPLIT ? FR : 1], bfl[SPLIT ? FR : 1];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = tr_frag(At, ms, wr * 64 + i * 16, g4, l15);
-                if constexpr (SPLIT) afl[i] = tr_frag(At + PLANE, ms, wr * 64 + i * 16, g4, l15);
+            for (int i = 0; i < FR; ++i) {
+                af[i] = tr_frag<TN_STR>(At, ms, wr * (TILE / 2) + i * 16, g4, l15);
+                if constexpr (SPLIT) afl[i] = tr_frag<TN_STR>(At + PLANE, ms, wr * (TILE / 2) + i * 16, g4, l15);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bf[j] = tr_frag(Bt, ms, wc * 64 + j * 16, g4, l15);
-                if constexpr (SPLIT) bfl[j] = tr_frag(Bt + PLANE, ms, wc * 64 + j * 16, g4, l15);
+            for (int j = 0; j < FR; ++j) {
+                bf[j] = tr_frag<TN_STR>(Bt, ms, wc * (TILE / 2) + j * 16, g4, l15);
+                if constexpr (SPLIT) bfl[j] = tr_frag<TN_STR>(Bt + PLANE, ms, wc * (TILE / 2) + j * 16, g4, l15);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FR; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < FR; ++j) {
                     if constexpr (SPLIT) {
                         acc[i][j] = HT::mfma(bf[j], afl[i], acc[i][j]);
                         acc[i][j] = HT::mfma(bfl[j], af[i], acc[i][j]);
@@ -196,12 +203,12 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
 
     // ---- epilogue: C[n][k..k+3] -----------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wr * 64 + i * 16 + l15;
+    for (int i = 0; i < FR; ++i) {
+        const int n = n0 + wr * (TILE / 2) + i * 16 + l15;
         if (n >= g.N) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + wc * 64 + j * 16 + 4 * g4;
+        for (int j = 0; j < FR; ++j) {
+            const int k = k0 + wc * (TILE / 2) + j * 16 + 4 * g4;
             if (k >= g.K) continue;                  // K % 4 == 0: the 4 columns are valid together
             float* c = g.C + (int64_t)n * g.ldc + k;
             const f32x4 v = acc[i][j] * g.alpha;
@@ -217,12 +224,17 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
 }
 
 template <typename HT, bool SPLIT, bool A32, bool B32>
-int launch_tn(const TnArgs& a, bool conv, int splits, hipStream_t s, const char* name) {
-    const int tiles = ((a.N + TN_BN - 1) / TN_BN) * ((a.K + TN_BK - 1) / TN_BK);
+int launch_tn(const TnArgs& a, bool conv, int tile, int splits, hipStream_t s, const char* name) {
+    const int tiles = ((a.N + tile - 1) / tile) * ((a.K + tile - 1) / tile);
     CfmProfScope prof(name, s, 2.0 * a.M * (double)a.N * a.K, (double)a.M * (a.N * (A32 ? 4 : 2) + a.K * (B32 ? 4 : 2)) + 4.0 * a.N * a.K);
     const dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
-    if (conv) CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, true>), grid, block, 0, s, a);
-    else CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, false>), grid, block, 0, s, a);
+    if (tile == 128) {
+        if (conv) CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, true, 128>), grid, block, 0, s, a);
+        else CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, false, 128>), grid, block, 0, s, a);
+    } else {
+        if (conv) CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, true, 64>), grid, block, 0, s, a);
+        else CFM_LAUNCH((cfm_gemm_tn_kernel<HT, SPLIT, A32, B32, false, 64>), grid, block, 0, s, a);
+    }
     return cfm_launch_status(name);
 }
 
@@ -251,11 +263,15 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const int mch = d->split ? 32 : 64;
     const int chunks = (d->M + mch - 1) / mch;
-    const int tiles = ((d->N + TN_BN - 1) / TN_BN) * ((d->K + TN_BK - 1) / TN_BK);
+    // 64 x 64 tiles while the output is small (fewer than 128 tiles of 128 x 128: every weight of the d = 256 / 512 blocks), 128 x 128 for
+    // the big ones (the CTC head's 5008 x 256, the front-end convolutions): then about one workgroup per CU
+    const int t128 = ((d->N + 127) / 128) * ((d->K + 127) / 128);
+    const int tile = (t128 >= 128 || chunks >= 128) ? 128 : 64;        // M >= 8 k rows: enough splits of >= 4 chunks even with few big tiles
+    const int tiles = ((d->N + tile - 1) / tile) * ((d->K + tile - 1) / tile);
     int splits = d->splits;
-    if (splits <= 0) {                                      // ~2 workgroups per CU, at least 2 chunks per split
-        splits = (512 + tiles - 1) / tiles;
-        const int max_s = (chunks + 1) / 2;
+    if (splits <= 0) {
+        splits = (256 + tiles - 1) / tiles;
+        const int max_s = (chunks + 3) / 4;                 // at least 4 chunks (256 rows) per split
         splits = splits > max_s ? max_s : splits;
     }
     splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
@@ -273,13 +289,13 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
             return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of colsum failed");
     }
     const bool a32 = d->a_dtype == CFM_F32, b32 = d->b_dtype == CFM_F32;
-    if (d->split) return launch_tn<BF16, true, true, true>(a, conv, splits, s, "gemm_tn_bf16x3");
-#define CFM_TN(HT, NAME)                                                                        \
-    do {                                                                                        \
-        if (a32 && b32) return launch_tn<HT, false, true, true>(a, conv, splits, s, NAME);      \
-        if (a32) return launch_tn<HT, false, true, false>(a, conv, splits, s, NAME);            \
-        if (b32) return launch_tn<HT, false, false, true>(a, conv, splits, s, NAME);            \
-        return launch_tn<HT, false, false, false>(a, conv, splits, s, NAME);                    \
+    if (d->split) return launch_tn<BF16, true, true, true>(a, conv, tile, splits, s, "gemm_tn_bf16x3");
+#define CFM_TN(HT, NAME)                                                                              \
+    do {                                                                                              \
+        if (a32 && b32) return launch_tn<HT, false, true, true>(a, conv, tile, splits, s, NAME);      \
+        if (a32) return launch_tn<HT, false, true, false>(a, conv, tile, splits, s, NAME);            \
+        if (b32) return launch_tn<HT, false, false, true>(a, conv, tile, splits, s, NAME);            \
+        return launch_tn<HT, false, false, false>(a, conv, tile, splits, s, NAME);                    \
     } while (0)
     if (d->mma_dtype == CFM_BF16) CFM_TN(BF16, "gemm_tn_bf16");
     CFM_TN(F16, "gemm_tn_f16");

@@ -38,24 +38,37 @@ __device__ __forceinline__ float dsilu_(float z) {
 }
 
 // out_a[j] = alpha * sum_b part[b*J + j] for j < J1, out_b[j - J1] for the rest: the fixed-order second stage of every reduction here
-__global__ void cfm_reduce_partials_kernel(const float* __restrict__ part, int nblk, int J, int J1, float alpha, float* out_a, float* out_b) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= J) return;
-    float s0 = 0.f, s1 = 0.f;                            // two chains: the loop is latency-bound otherwise
-    int b = 0;
-    for (; b + 1 < nblk; b += 2) {
-        s0 += part[(int64_t)b * J + j];
-        s1 += part[(int64_t)(b + 1) * J + j];
+// 64 columns per workgroup, 4 threads per column each summing every 4th partial (fixed order), combined through LDS: the serial chain is
+// nblk/4 loads long instead of nblk (latency-bound: ~0.1 us per dependent load)
+constexpr int RP_Q = 16;
+__global__ __launch_bounds__(1024) void cfm_reduce_partials_kernel(const float* __restrict__ part, int nblk, int J, int J1, float alpha, float* out_a, float* out_b) {
+    __shared__ float red[RP_Q][64];
+    const int jc = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jc;
+    float s0 = 0.f, s1 = 0.f;
+    if (j < J) {
+        int b = q;
+        for (; b + RP_Q < nblk; b += 2 * RP_Q) {
+            s0 += part[(int64_t)b * J + j];
+            s1 += part[(int64_t)(b + RP_Q) * J + j];
+        }
+        if (b < nblk) s0 += part[(int64_t)b * J + j];
     }
-    if (b < nblk) s0 += part[(int64_t)b * J + j];
-    const float s = (s0 + s1) * alpha;
-    if (j < J1) out_a[j] = s;
-    else out_b[j - J1] = s;
+    red[q][jc] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && j < J) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < RP_Q; ++i) s += red[i][jc];              // fixed order
+        s *= alpha;
+        if (j < J1) out_a[j] = s;
+        else out_b[j - J1] = s;
+    }
 }
 
 int reduce_partials(const float* part, int nblk, int J, int J1, float alpha, float* out_a, float* out_b, hipStream_t s, const char* what) {
     CfmProfScope prof("reduce_partials", s, 0.0, (double)nblk * J * 4);
-    CFM_LAUNCH(cfm_reduce_partials_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, s, part, nblk, J, J1, alpha, out_a, out_b);
+    CFM_LAUNCH(cfm_reduce_partials_kernel, dim3((unsigned)((J + 63) / 64)), dim3(64 * RP_Q), 0, s, part, nblk, J, J1, alpha, out_a, out_b);
     return cfm_launch_status(what);
 }
 
@@ -64,7 +77,7 @@ int reduce_partials(const float* part, int nblk, int J, int J1, float alpha, flo
 //   xhat = (x - mean) * rstd;  gy = gamma * dy;   dx = dres + rstd * (gy - mean_D(gy) - xhat * mean_D(gy * xhat))
 //   dgamma = sum_rows dy * xhat;  dbeta = sum_rows dy          (per-workgroup partials -> ws[blk][2][D])
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr int LNB_ROWS = 32;
+constexpr int LNB_ROWS = 8;       // 2 rows per wavefront: at M = 2 k rows a 32-row workgroup left three quarters of the CUs idle (12 us -> ~4 us)
 
 template <int ITERS>
 __global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy, int dy_dt,
@@ -216,22 +229,49 @@ __global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __res
 }
 
 // stats[0..3][D] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running statistics updated (torch: unbiased variance)
-__global__ void cfm_bn_finalize_kernel(const float* __restrict__ ws, int nblk_t, int B, int T, int D, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
-                                       float* __restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= D) return;
-    double n = 0.0, mean = 0.0, m2 = 0.0;                   // Chan's pairwise combination, fixed order
-    for (int b = 0; b < B; ++b)
-        for (int tb = 0; tb < nblk_t; ++tb) {
-            const int64_t blk = (int64_t)b * nblk_t + tb;
-            const double nb = (double)min(DWT, T - tb * DWT);
-            const double mb = ws[(blk * 2 + 0) * D + c], qb = ws[(blk * 2 + 1) * D + c];
-            const double d = mb - mean, nn = n + nb;
-            mean += d * nb / nn;
-            m2 += qb + d * d * n * nb / nn;
-            n = nn;
+// one wavefront per channel: lane l combines partials l, l+64, ... (Chan's pairwise rule, fp64), then the 64 lane results are merged by a
+// butterfly -- the serial chain is (B * nblk_t)/64 + 6 combinations instead of B * nblk_t (36 us at config 3 as one thread per channel)
+__device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, double nb, double mb, double qb) {
+    if (nb <= 0.0) return;
+    const double d = mb - mean, nn = n + nb;
+    mean += d * nb / nn;
+    m2 += qb + d * d * n * nb / nn;
+    n = nn;
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int o) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __shfl_xor(lo, o, 64);
+    hi = __shfl_xor(hi, o, 64);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__global__ __launch_bounds__(256) void cfm_bn_finalize_kernel(const float* __restrict__ ws, int nblk_t, int B, int T, int D, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+                                                              float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= D) return;                                     // wave-uniform
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    const int total = B * nblk_t;
+    for (int blk = lane; blk < total; blk += 64) {
+        const int tb = blk % nblk_t;
+        chan_merge(n, mean, m2, (double)min(DWT, T - tb * DWT), ws[((int64_t)blk * 2 + 0) * D + c], ws[((int64_t)blk * 2 + 1) * D + c]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double on = shfl_xor_f64(n, o), om = shfl_xor_f64(mean, o), oq = shfl_xor_f64(m2, o);
+        // merge the partner's triple; both lanes of a pair compute the same symmetric result
+        const double nn = n + on;
+        if (nn > 0.0) {
+            const double d = om - mean;
+            m2 = m2 + oq + d * d * n * on / nn;
+            mean = (n * mean + on * om) / nn;
         }
+        n = nn;
+    }
+    if (lane != 0) return;
+    {
+    }
     const double var = m2 / n;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * rstd;
@@ -257,7 +297,7 @@ __global__ void cfm_bn_silu_apply_kernel(const float* __restrict__ c, const floa
 }
 
 // dy = ds * silu'(c*scale + shift) -> dy_out (f32); per-workgroup sums over 64 rows of dy and dy * chat -> ws[blk][2][D]
-constexpr int BNB_ROWS = 64;
+constexpr int BNB_ROWS = 16;
 __global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __restrict__ ds, int ds_dt, const float* __restrict__ c, const float* __restrict__ stats,
                                                               float* __restrict__ dy_out, float* __restrict__ ws, int64_t M, int D) {
     const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
@@ -327,14 +367,21 @@ __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __rest
 }
 
 // second stage of the BatchNorm backward sums: dbeta = S1, dgamma = S2, coef = (S1/N, S2/N)
-__global__ void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, double inv_n, float* dgamma, float* dbeta, float* coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, double inv_n, float* dgamma, float* dbeta, float* coef) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wavefront per channel
     if (c >= D) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s1 += ws[((int64_t)b * 2 + 0) * D + c];
         s2 += ws[((int64_t)b * 2 + 1) * D + c];
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        s1 += shfl_xor_f64(s1, o);
+        s2 += shfl_xor_f64(s2, o);
+    }
+    if (lane != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     coef[c] = (float)(s1 * inv_n);
@@ -342,19 +389,23 @@ __global__ void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, int nbl
 }
 
 // second stage of the depthwise gradients: dw_w[c][k] (the layout of depthwise_conv.weight (D,1,K)) and dw_b[c]
-__global__ void cfm_dwconv_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, float* dw_w, float* dw_b) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= 16 * D) return;
+__global__ __launch_bounds__(1024) void cfm_dwconv_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, float* dw_w, float* dw_b) {
+    __shared__ float red[RP_Q][64];
+    const int jc = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int id = blockIdx.x * 64 + jc;                                // output (slot, c), 16 threads each (fixed-order partial sums)
     const int slot = id / D, c = id - slot * D;
-    float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 1 < nblk; b += 2) {
-        s0 += ws[((int64_t)b * 16 + slot) * D + c];
-        s1 += ws[((int64_t)(b + 1) * 16 + slot) * D + c];
+    float s0 = 0.f;
+    if (id < 16 * D)
+        for (int b = q; b < nblk; b += RP_Q) s0 += ws[((int64_t)b * 16 + slot) * D + c];
+    red[q][jc] = s0;
+    __syncthreads();
+    if (q == 0 && id < 16 * D) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < RP_Q; ++i) s += red[i][jc];
+        if (slot < DWK) dw_w[c * DWK + slot] = s;
+        else dw_b[c] = s;
     }
-    if (b < nblk) s0 += ws[((int64_t)b * 16 + slot) * D + c];
-    if (slot < DWK) dw_w[c * DWK + slot] = s0 + s1;
-    else dw_b[c] = s0 + s1;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -573,7 +624,7 @@ extern "C" int cfm_dwconv_bn_train(const void* g, int32_t g_dtype, const float* 
     }
     {
         CfmProfScope prof("bn_finalize", s, 0.0, (double)B * nblk_t * 2 * D * 4);
-        CFM_LAUNCH(cfm_bn_finalize_kernel, dim3((unsigned)((D + 63) / 64)), dim3(64), 0, s, (const float*)ws, nblk_t, B, T, D, gamma, beta, running_mean,
+        CFM_LAUNCH(cfm_bn_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, nblk_t, B, T, D, gamma, beta, running_mean,
                    running_var, momentum, eps, stats);
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train (finalize)")) return rc;
     }
@@ -599,7 +650,7 @@ extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const f
     }
     {
         CfmProfScope prof("bn_bwd_finalize", s, 0.0, (double)nb * 2 * D * 4);
-        CFM_LAUNCH(cfm_bn_bwd_finalize_kernel, dim3((unsigned)((D + 63) / 64)), dim3(64), 0, s, (const float*)ws, nb, D, 1.0 / (double)M, dgamma, dbeta, coef);
+        CFM_LAUNCH(cfm_bn_bwd_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, nb, D, 1.0 / (double)M, dgamma, dbeta, coef);
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (finalize)")) return rc;
     }
     const int nblk_t = (T + DWT - 1) / DWT;
@@ -611,7 +662,7 @@ extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const f
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (conv)")) return rc;
     }
     CfmProfScope prof("dwconv_bwd_finalize", s, 0.0, (double)B * nblk_t * 16 * D * 4);
-    CFM_LAUNCH(cfm_dwconv_bwd_finalize_kernel, dim3((unsigned)((16 * D + 255) / 256)), dim3(256), 0, s, (const float*)part, B * nblk_t, D, dw_w, dw_b);
+    CFM_LAUNCH(cfm_dwconv_bwd_finalize_kernel, dim3((unsigned)((16 * D + 63) / 64)), dim3(64 * RP_Q), 0, s, (const float*)part, B * nblk_t, D, dw_w, dw_b);
     return cfm_launch_status("cfm_dwconv_bn_train_bwd (reduce)");
 }
 

@@ -40,3 +40,17 @@ steady = sorted(times[12:])
 ms = 1e3 * steady[len(steady) // 2]
 print("streams %d  graph session: %.3f ms per step (median of replayed steps) = %.0f input frames/s over all streams (%.1f x real time per stream)"
       % (B, ms, B * hop / (ms * 1e-3), hop * 10.0 / ms))
+
+# ---- round 2: encoder.StreamingBatch -- per-stream offsets on the device, K/V ring buffers (no cat + trim), the whole step one graph
+sb = enc_mod.StreamingBatch(enc, B, chunk, left)
+times = []
+with torch.no_grad():
+    for step in range(40):
+        win = x[:, step * hop: step * hop + window].contiguous()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y = sb.step(win)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+steady = sorted(times[12:])
+ms = 1e3 * steady[len(steady) // 2]
+print("streams %d  StreamingBatch (ring KV, per-stream offsets, one graph): %.3f ms per step = %.0f input frames/s over all streams (%.1f x real time per stream)"
+      % (B, ms, B * hop / (ms * 1e-3), hop * 10.0 / ms))

@@ -20,6 +20,7 @@ from conftest import check_joint_case, joint_case_inputs, load_golden
 pytestmark = pytest.mark.gpu
 
 TOL = {"fp32": 5e-5, "fp16": 1e-3, "bf16": 1.2e-2}
+JOINT_TOL = {"fp32": 3e-5, "fp16": 1e-3, "bf16": 6e-3}      # measured 7e-6 / 4e-4 / 3.4e-3
 MODES = ["bf16", "fp16", "fp32"]
 DEV = "cuda"
 
@@ -320,6 +321,48 @@ def test_config4_encoder_shape_against_oracle(pkg, mode):
     y_ref, m_ref = O.encoder_forward(P, O.Config(**cfg), x.cpu(), lens)
     assert np.array_equal(m.cpu().numpy(), np.asarray(m_ref))                                   # bit-exact
     check("config-4 encoder shape (d=512, h=8, 3 layers)", y, y_ref, mode)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_config4_real_size_encoder_and_joint(pkg, mode):
+    """BASELINE config 4 at its REAL size: 17-layer d=512 h=8 ff=2048 encoder on B=16 x (80 x 1000), then the transducer joint on its output
+    (U+1 = 41, join 512, V = 5002: 817 M logits).  Two utterances against the CPU oracle, size-independent properties for the rest."""
+    from oracle import conformer_oracle as O
+    import joint as joint_mod
+    pkg.cfm.set_precision(mode)
+    cfg = dict(input_dim=80, kernel_size=15, encoder_dim=512, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+               hidden_dim=2048, num_heads=8, encoder_num_layers=17, max_len=5000, use_relative=True)
+    enc = build_encoder(pkg, cfg, 43)
+    B, T, U = 16, 1000, 41
+    x = dev(synth.fbank(4343, B, T))
+    lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        y, m = enc(x, lens)
+        y_again, _ = enc(x, lens)
+        y_shard, _ = enc(x[0:2].contiguous(), lens[0:2])
+    assert y.shape == (B, 249, 512) and bool(m.all()) and bool(torch.isfinite(y).all())
+    assert torch.equal(y, y_again) and torch.equal(y[0:2], y_shard)
+    z = (y - enc.after_norm.bias) / enc.after_norm.weight
+    assert float(z.mean(-1).abs().max()) < 1e-3 and float((z.var(-1, unbiased=False) - 1).abs().max()) < 1e-2
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    y_ref, _ = O.encoder_forward(P, O.Config(**cfg), x[:2].cpu(), [T, T])
+    check("config 4 encoder, full size (17 layers, d=512), 2 utts vs oracle", y[:2], y_ref, mode, 1.5)
+    # joint on the encoder's output: sampled (b,t,u) rows of the 817 M logits against the oracle's logits of that triple alone
+    jn = synth.load_synth_(joint_mod.TransducerJoint(5002, 512, 256, 512).eval(), 44).to(DEV)
+    pred = dev(synth.normal(4545, (B, U, 256)))
+    with torch.no_grad():
+        logits = jn(y, pred)
+    assert logits.shape == (B, 249, U, 5002)
+    Pj = {k: v.detach().cpu() for k, v in jn.state_dict().items()}
+    rs = np.random.RandomState(46)
+    worst = 0.0
+    for _ in range(16):
+        b, t, u = int(rs.randint(0, B)), int(rs.randint(0, 249)), int(rs.randint(0, U))
+        ref = O.joint_forward(Pj, "", y[b:b + 1, t:t + 1].cpu(), pred[b:b + 1, u:u + 1].cpu())
+        worst = max(worst, relerr(logits[b, t, u].float(), ref.reshape(-1)))
+    print("  [%s] config 4 joint at full size, 16 sampled rows vs oracle: %.3e" % (mode, worst))
+    assert worst < JOINT_TOL[mode] * 1.5
+    del logits
 
 
 @pytest.mark.parametrize("D,H,FF,K,L,B,T,lens", [
@@ -789,9 +832,6 @@ def test_cpu_tensors_fail_loudly(pkg):
     layer = pkg.encoder_layer.ConformerEncoderLayer(16, 15, 0.0, 0.0, 32, 2, True).to(DEV).train()
     with pytest.raises(NotImplementedError):                       # a KV cache in train mode: streaming is inference-only
         layer(torch.zeros(1, 4, 16, device=DEV), torch.ones((0, 0, 0)), torch.zeros(1, 1, 16, device=DEV), attn_cache=torch.zeros(1, 2, 3, 16, device=DEV))
-
-
-JOINT_TOL = {"fp32": 3e-5, "fp16": 1e-3, "bf16": 6e-3}      # measured 7e-6 / 4e-4 / 3.4e-3
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -63,7 +63,19 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
         params_r = list(enc_r.parameters()) + list(dec_r.parameters())
         opt = torch.optim.Adam(params_r, lr=lr)
         loss_r = make_loss(enc_r, dec_r)
+        named = list(enc.named_parameters()) + list(dec.named_parameters())
+        bufs, bufs_r = dict(enc.named_buffers()), dict(enc_r.named_buffers())
+        worst = (0.0, "")
         for s in range(steps):
+            # both models start every step from the SAME weights / BatchNorm statistics / Adam moments-by-construction: the trajectories of
+            # two separately rounded Adam runs drift apart at the noise level (structurally-zero gradients, ReLU mask flips), which says
+            # nothing about the harness.  What is compared is ONE step: accumulate 2 micro-batches, clip, Adam, WarmupLR.
+            with torch.no_grad():
+                for (k, a), b in zip(named, params_r):
+                    b.copy_(a)
+                for k in bufs:
+                    bufs_r[k].copy_(bufs[k])
+            before = [a.detach().clone() for _, a in named]
             loss = tr.step(data[s])
             assert tr.reduce_log == list(range(len(tr.buckets))), "every bucket launched once, in gradient-ready order"
             opt.zero_grad()
@@ -76,28 +88,17 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
             for gp in opt.param_groups:
                 gp["lr"] = T.warmup_lr(lr, warmup, s + 1)
             opt.step()
-            assert abs(float(loss) - tot / accum) < 1e-4 * abs(tot / accum)
-            assert abs(float(tr.last_grad_norm) - float(norm)) < 1e-3 * float(norm)
-        assert float(norm) > clip or True
-        # Parameters whose gradient is zero in exact arithmetic (keys' bias, pos_bias_v / linear_pos in the batch path, the depthwise bias
-        # under BatchNorm) receive pure rounding noise, and Adam turns the SIGN of that noise into a full +-lr update: after the first step
-        # the two models differ in the last bits, the noise decorrelates, and these parameters random-walk apart by O(lr) -- in ANY
-        # implementation, the reference included.  They are bounded by the total step length instead of compared digit by digit.
-        noise = ("linear_k.bias", "pos_bias_v", "linear_pos.weight", "depthwise_conv.bias")
-        travelled = sum(T.warmup_lr(lr, warmup, s + 1) for s in range(steps))
-        worst = (0.0, "")
-        for (k, a), b in zip(list(enc.named_parameters()) + list(dec.named_parameters()), params_r):
-            d = float((a - b).abs().max())
-            if k.endswith(noise):
-                assert d <= 2.0 * travelled * 1.01, (k, d, travelled)
-                continue
-            worst = max(worst, (d / max(float(b.abs().max()), 1e-3), k))
-        print("  trainer vs plain autograd + torch Adam after %d steps: worst parameter difference %.3e (%s)" % (steps, worst[0], worst[1]))
-        assert worst[0] < 1e-3, worst      # measured 3e-4: Adam's 1/sqrt(v) amplifies last-bit differences of small gradients in the first steps            # weight-gradient atomics are order-dependent in the last bits; Adam's 1/sqrt(v) amplifies them early on
-        # BatchNorm running statistics advanced identically
-        for (k, a), (_, b) in zip(enc.named_buffers(), enc_r.named_buffers()):
-            if "running" in k:
-                assert float((a - b).abs().max()) < 1e-5, k
+            assert abs(float(loss) - tot / accum) < 1e-5 * abs(tot / accum)
+            assert abs(float(tr.last_grad_norm) - float(norm)) < 1e-4 * float(norm)
+            for ((k, a), b), a0 in zip(zip(named, params_r), before):
+                upd = float((b - a0).abs().max())                       # how far torch's step moved this parameter
+                worst = max(worst, (float((a - b).abs().max()) / max(upd, 1e-12), k))
+            for k in bufs:
+                if "running" in k:
+                    assert float((bufs[k] - bufs_r[k]).abs().max()) < 1e-6, k
+        print("  trainer step vs plain autograd + clip_grad_norm_ + torch Adam: worst |difference| / |update| = %.3e (%s)" % worst)
+        # torch keeps the Adam moments of ITS trajectory, the trainer of its own: identical by construction here (same gradients every step)
+        assert worst[0] < 2e-3, worst
     finally:
         if use_pg:
             dist.destroy_process_group()
