@@ -1,4 +1,4 @@
-// encoder.cpp -- composite: one conformer block enqueued from C++ (6 launches with the row-local chains of rowchain.hip, no host sync).
+// encoder.cpp -- composite: one conformer block enqueued from C++ (5 launches with the row-local chains of rowchain.hip, 17 on the general path; no host sync).
 //
 // Mirrors reference src/encoder_layer.py:49-71:
 //   x = x + 1/2 FFNm(LN(x)); x = x + MHSA(LN(x)); x = x + Conv(LN(x)); x = x + 1/2 FFN(LN(x)); out = LN(x)

@@ -5,7 +5,7 @@ Drop-in for the reference's ``src/encoder_layer.py`` (constructor arguments, chi
 ``(out, inputs_attn_mask, new_attn_cache, new_cnn_cache)`` contract of encoder_layer.py:11-71).
 
 The whole block -- LN, 1/2 macaron FFN, LN, MHSA, LN, convolution module, LN, 1/2 FFN, final LN with every residual -- is
-ONE call into libconformer_gfx950 (``cfm_encoder_layer_forward``): 17 kernel launches enqueued from C++ with no host
+ONE call into libconformer_gfx950 (``cfm_encoder_layer_forward``): 5 kernel launches (row chains; 17 on the general path) enqueued from C++ with no host
 synchronisation, the residual stream in f32, every bias / activation / GLU / mask / residual add fused into a GEMM
 epilogue, and LayerNorm writing the next GEMM's operand dtype directly.  The child modules (feedforward / attention /
 convolution) only own the parameters here; called on their own they run the same kernels op by op.
