@@ -42,7 +42,8 @@ class GemmTnDesc(ctypes.Structure):
                 ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("a_dtype", c_i32), ("b_dtype", c_i32), ("mma_dtype", c_i32), ("split", c_i32), ("accumulate", c_i32), ("splits", c_i32),
                 ("alpha", ctypes.c_float),
-                ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32)]
+                ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
+                ("row_off", c_p), ("colsum_off", c_p)]
 
 
 class AttnBwdDesc(ctypes.Structure):
@@ -86,6 +87,44 @@ _LAYER_W_FIELDS = [
     "ff_w1", "ff_w1_lo", "ff_w2", "ff_w2_lo", "ff_b1", "ff_b2", "ffm_w1f", "ffm_w2f", "ff_w1f", "ff_w2f", "ffm_w2n", "ff_w2n", "qkv_wf", "out_wf", "pw1_wf", "pw2_wf",
     "qkv_w", "qkv_w_lo", "pos_w", "pos_w_lo", "out_w", "out_w_lo", "qkv_b", "out_b", "bias_u", "bias_v",
     "pw1_w", "pw1_w_lo", "pw2_w", "pw2_w_lo", "pw1_b", "pw2_b", "dw_w", "dw_b", "bn_scale", "bn_shift"]
+
+
+_TRAIN_W_PTRS = ["ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "ln_conv_b", "ln_ff_g", "ln_ff_b", "ln_final_g", "ln_final_b",
+                 "ffm_w1", "ffm_w1_lo", "ffm_w2", "ffm_w2_lo", "ffm_w1t", "ffm_w1t_lo", "ffm_w2t", "ffm_w2t_lo", "ffm_b1", "ffm_b2",
+                 "ff_w1", "ff_w1_lo", "ff_w2", "ff_w2_lo", "ff_w1t", "ff_w1t_lo", "ff_w2t", "ff_w2t_lo", "ff_b1", "ff_b2",
+                 "qkv_w", "qkv_w_lo", "qkv_t", "qkv_t_lo", "out_w", "out_w_lo", "out_t", "out_t_lo", "qkv_b", "out_b",
+                 "pw1_w", "pw1_w_lo", "pw1_t", "pw1_t_lo", "pw2_w", "pw2_w_lo", "pw2_t", "pw2_t_lo", "pw1_b", "pw2_b", "dw_w", "dw_b", "bn_gamma", "bn_beta",
+                 "bn_running_mean", "bn_running_var"]
+
+
+class LayerTrainWeights(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in _TRAIN_W_PTRS] + [("bn_momentum", ctypes.c_float), ("bn_eps", ctypes.c_float)]
+
+
+class LayerTrainIO(ctypes.Structure):
+    _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("FF", c_i32), ("ktaps", c_i32), ("act_dtype", c_i32), ("w_dtype", c_i32),
+                ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64), ("pad_valid", c_p),
+                ("p_hidden_m", ctypes.c_float), ("p_hidden", ctypes.c_float), ("p_branch", ctypes.c_float), ("p_attn", ctypes.c_float),
+                ("p_attn_out", ctypes.c_float), ("seed", ctypes.c_uint32), ("deterministic", c_i32)]
+
+
+_TRAIN_SAVED = ["xn1", "z1", "h1", "xn2", "qkv", "ctx", "xn3", "u", "glu", "s", "xn4", "z2", "h2", "x1", "x2", "x3", "x4", "c", "lse", "stats"]
+_TRAIN_SCRATCH = ["dxn", "dz", "dyb", "ds", "dglu", "du", "dctx", "dqkv", "delta", "ln_ws", "dwbn_ws", "dy_ws"]
+_TRAIN_GRADS = ["slab", "ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "ln_conv_b", "ln_ff_g", "ln_ff_b", "ln_final_g", "ln_final_b",
+                "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "ff_w1", "ff_b1", "ff_w2", "ff_b2", "out_w", "out_b", "pw2_w", "pw2_b", "dw_w", "dw_b", "bn_g", "bn_b",
+                "pos_bias_u", "q_bias", "qkv_row_off", "qkv_bias_off", "pw1_row_off", "pw1_bias_off"]
+
+
+class LayerTrainSaved(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in _TRAIN_SAVED]
+
+
+class LayerTrainScratch(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in _TRAIN_SCRATCH]
+
+
+class LayerTrainGrads(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in _TRAIN_GRADS]
 
 
 class LayerWeights(ctypes.Structure):
@@ -163,6 +202,10 @@ def lib():
         L.cfm_sumsq.argtypes = [c_p, c_i64, c_p, c_i32, c_p, c_p]
         L.cfm_dropout_rows.argtypes = [c_p, c_i32, c_p, c_i32, c_p, c_f, c_f, ctypes.c_uint32, c_f, ctypes.c_uint32, c_i64, c_i32, c_p]
         L.cfm_dropout_mask.argtypes = [c_p, c_i64, c_f, ctypes.c_uint32, c_p]
+        L.cfm_encoder_layer_train_forward.argtypes = [ctypes.POINTER(LayerTrainWeights), ctypes.POINTER(LayerTrainIO), ctypes.POINTER(LayerTrainSaved),
+                                                      ctypes.POINTER(LayerTrainScratch), c_p, c_p, c_p]
+        L.cfm_encoder_layer_train_backward.argtypes = [ctypes.POINTER(LayerTrainWeights), ctypes.POINTER(LayerTrainIO), ctypes.POINTER(LayerTrainSaved),
+                                                       ctypes.POINTER(LayerTrainScratch), ctypes.POINTER(LayerTrainGrads), c_p, c_p, c_p, c_p]
         L.cfm_stream_prep.argtypes = [c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]
         L.cfm_kv_ring_write.argtypes = [c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_stream_advance.argtypes = [c_p, c_p, c_i32, c_i32, c_p]
@@ -181,7 +224,7 @@ def lib():
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
                      "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask",
-                     "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
+                     "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib

@@ -13,6 +13,8 @@ What train mode means here (reference: encoder_layer.py:49-71, convolution.py:34
   * the batch path's positional score term is constant along each softmax row, so linear_pos / pos_bias_v receive an exact
     zero gradient (the reference's is rounding noise ~1e-8) and the term is not evaluated; pos_bias_u rides in linear_q's bias.
 """
+import ctypes
+
 import torch
 
 import cfm
@@ -340,6 +342,151 @@ def subsampling_params(mod):
     return [p for n, p in mod.named_parameters() if n.startswith("conv.") or n.startswith("out.")]
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# the block as TWO host calls (csrc/train_layer.cpp): the same launches as the op-by-op composition above, enqueued from C++
+# ----------------------------------------------------------------------------------------------------------------------
+USE_COMPOSITE = True          # False: EncoderLayerFn runs the op-by-op composition (tests compare the two)
+
+_GRAD_FIELDS = {"norm_ff_macaron.weight": "ln_ffm_g", "norm_ff_macaron.bias": "ln_ffm_b", "norm_mha.weight": "ln_mha_g", "norm_mha.bias": "ln_mha_b",
+                "norm_conv.weight": "ln_conv_g", "norm_conv.bias": "ln_conv_b", "norm_ff.weight": "ln_ff_g", "norm_ff.bias": "ln_ff_b",
+                "norm_final.weight": "ln_final_g", "norm_final.bias": "ln_final_b",
+                "feed_forward_macaron.w_1.weight": "ffm_w1", "feed_forward_macaron.w_1.bias": "ffm_b1", "feed_forward_macaron.w_2.weight": "ffm_w2",
+                "feed_forward_macaron.w_2.bias": "ffm_b2", "feed_forward.w_1.weight": "ff_w1", "feed_forward.w_1.bias": "ff_b1",
+                "feed_forward.w_2.weight": "ff_w2", "feed_forward.w_2.bias": "ff_b2", "self_attn.linear_out.weight": "out_w", "self_attn.linear_out.bias": "out_b",
+                "conv_module.pointwise_conv2.weight": "pw2_w", "conv_module.pointwise_conv2.bias": "pw2_b", "conv_module.depthwise_conv.weight": "dw_w",
+                "conv_module.depthwise_conv.bias": "dw_b", "conv_module.norm.weight": "bn_g", "conv_module.norm.bias": "bn_b", "self_attn.pos_bias_u": "pos_bias_u"}
+
+
+def layer_grad_layout(layer, offsets=None):
+    """Where each parameter's gradient lives in the block's flat gradient slab: {name: (offset, numel)} in floats (16-byte aligned), the slab
+    length, and the device row-offset maps of the two fused products.  offsets: a ready-made {name: offset} (the data-parallel trainer's
+    bucket layout) or None for a private slab in named_parameters order.  Cached on the layer per layout."""
+    key = None if offsets is None else tuple(sorted(offsets.items()))
+    cache = layer.__dict__.setdefault("_grad_layout", {})
+    hit = cache.get(key)
+    dev = next(layer.parameters()).device
+    if hit is not None and hit["device"] == dev:
+        return hit
+    lay, n = {}, 0
+    for name, p in layer.named_parameters():
+        if offsets is None:
+            lay[name] = (n, p.numel())
+            n += (p.numel() + 3) // 4 * 4
+        else:
+            lay[name] = (offsets[name], p.numel())
+            n = max(n, offsets[name] + p.numel())
+    D = layer.encoder_dim
+    ar = torch.arange(D, dtype=torch.int64)
+    qo, ko, vo = (lay["self_attn.linear_%s.weight" % c][0] for c in "qkv")
+    qb, kb, vb = (lay["self_attn.linear_%s.bias" % c][0] for c in "qkv")
+    qkv_row = torch.cat([qo + ar * D, ko + ar * D, vo + ar * D])
+    qkv_bias = torch.cat([qb + ar, kb + ar, vb + ar])
+    idx = packing.glu_interleave_index(D, torch.device("cpu"))            # GEMM row j of the interleaved pack = reference row idx[j]
+    pw1_row = lay["conv_module.pointwise_conv1.weight"][0] + idx * D
+    pw1_bias = lay["conv_module.pointwise_conv1.bias"][0] + idx
+    hit = dict(device=dev, layout=lay, numel=n, qkv_row=qkv_row.to(dev), qkv_bias=qkv_bias.to(dev), pw1_row=pw1_row.to(dev), pw1_bias=pw1_bias.to(dev))
+    cache[key] = hit
+    return hit
+
+
+def _train_weights_struct(layer, pks):
+    ffm, att, cv, ff = pks
+    w = cfm.LayerTrainWeights()
+    for short, name in (("ffm", "norm_ff_macaron"), ("mha", "norm_mha"), ("conv", "norm_conv"), ("ff", "norm_ff"), ("final", "norm_final")):
+        ln = getattr(layer, name)
+        setattr(w, "ln_%s_g" % short, ln.weight.data_ptr())
+        setattr(w, "ln_%s_b" % short, ln.bias.data_ptr())
+    for pre, pk in (("ffm", ffm), ("ff", ff)):
+        for f in ("w1", "w1_lo", "w2", "w2_lo", "w1t", "w1t_lo", "w2t", "w2t_lo", "b1", "b2"):
+            setattr(w, pre + "_" + f, cfm.ptr(getattr(pk, f)))
+    for f in ("qkv_w", "qkv_w_lo", "qkv_t", "qkv_t_lo", "out_w", "out_w_lo", "out_t", "out_t_lo", "qkv_b", "out_b"):
+        setattr(w, f, cfm.ptr(getattr(att, f)))
+    for f in ("pw1_w", "pw1_w_lo", "pw1_t", "pw1_t_lo", "pw2_w", "pw2_w_lo", "pw2_t", "pw2_t_lo", "pw1_b", "pw2_b", "dw_w", "dw_b"):
+        setattr(w, f, cfm.ptr(getattr(cv, f)))
+    w.bn_gamma, w.bn_beta = cv.gamma.data_ptr(), cv.beta.data_ptr()
+    bn = layer.conv_module.norm
+    if bn.track_running_stats:
+        w.bn_running_mean, w.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    w.bn_momentum = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+    w.bn_eps = bn.eps
+    return w
+
+
+def _composite_ok(layer, x):
+    bn = layer.conv_module.norm
+    return (USE_COMPOSITE and layer.kernel_size == 15 and bn.weight is not None and bn.bias is not None and
+            layer.conv_module.pointwise_conv1.bias is not None and layer.conv_module.depthwise_conv.bias is not None and
+            all(p.dtype == torch.float32 and p.is_contiguous() for p in layer.parameters()))
+
+
+def _layer_composite_forward(ctx, x0, layer, prec, mask8, m_str, keep, pks, B, T, D):
+    dev, adt = x0.device, prec.act_dtype
+    M, FF, H = B * T, layer.hidden_dim, layer.num_heads
+    esz = 4 if adt == torch.float32 else 2
+    # everything the backward needs, in two allocations: act-dtype rows and f32 rows
+    widths = dict(xn1=D, z1=FF, h1=FF, xn2=D, qkv=3 * D, ctx=D, xn3=D, u=2 * D, glu=D, s=D, xn4=D, z2=FF, h2=FF)
+    act = torch.empty((M * sum(widths.values()),), dtype=adt, device=dev)
+    f32 = torch.empty((5 * M * D + B * H * T + 4 * D,), dtype=torch.float32, device=dev)
+    sv = cfm.LayerTrainSaved()
+    o = 0
+    for name, wd in widths.items():
+        setattr(sv, name, act.data_ptr() + o * esz)
+        o += M * wd
+    o = 0
+    for name, n in (("x1", M * D), ("x2", M * D), ("x3", M * D), ("x4", M * D), ("c", M * D), ("lse", B * H * T), ("stats", 4 * D)):
+        setattr(sv, name, f32.data_ptr() + o * 4)
+        o += n
+    sc = cfm.LayerTrainScratch()
+    sc.dwbn_ws = cfm.scratch("dwbn", cfm.lib().cfm_dwconv_bn_ws(B, T, D), torch.float32, dev).data_ptr()
+    io = cfm.LayerTrainIO()
+    io.B, io.T, io.D, io.H, io.FF, io.ktaps, io.act_dtype, io.w_dtype = B, T, D, H, FF, layer.kernel_size, prec.act_code, prec.w_code
+    io.attn_mask, io.am_sb, io.am_sq, io.pad_valid = cfm.ptr(mask8), m_str[0], m_str[1], cfm.ptr(keep)
+    p_br, p_a = layer.dropout.p, layer.self_attn.dropout.p
+    io.p_hidden_m, io.p_hidden, io.p_branch, io.p_attn = layer.feed_forward_macaron.dropout.p, layer.feed_forward.dropout.p, p_br, p_a
+    io.p_attn_out = 0.0 if layer.use_relative else p_a
+    io.seed = draw_seed() if max(io.p_hidden_m, io.p_hidden, p_br, p_a) > 0 else 0
+    io.deterministic = 1 if cfm.ops._deterministic[0] else 0
+    w = _train_weights_struct(layer, pks)
+    y = torch.empty((M, D), dtype=torch.float32, device=dev)
+    cfm.check(cfm.lib().cfm_encoder_layer_train_forward(ctypes.byref(w), ctypes.byref(io), ctypes.byref(sv), ctypes.byref(sc), x0.data_ptr(), y.data_ptr(),
+                                                        cfm.stream()), "cfm_encoder_layer_train_forward")
+    bn = layer.conv_module.norm
+    if bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    ctx.comp = (layer, prec, mask8, keep, pks, w, io, sv, (act, f32, x0), B, T, D)
+    return y
+
+
+def _layer_composite_backward(ctx, dy):
+    layer, prec, mask8, keep, pks, w, io, sv, (act, f32, x0), B, T, D = ctx.comp
+    dev, adt = x0.device, prec.act_dtype
+    M, FF, H = B * T, layer.hidden_dim, layer.num_heads
+    lay = layer_grad_layout(layer, getattr(layer, "_flat_grad_offsets", None))
+    target = getattr(layer, "_flat_grad_target", None)              # the trainer's gradient memory for this block (accumulated into), or a private slab
+    slab = target if target is not None else torch.zeros((lay["numel"],), dtype=torch.float32, device=dev)
+    g = cfm.LayerTrainGrads()
+    g.slab = slab.data_ptr()
+    for name, field in _GRAD_FIELDS.items():
+        if name in lay["layout"]:
+            setattr(g, field, slab.data_ptr() + 4 * lay["layout"][name][0])
+    g.q_bias = slab.data_ptr() + 4 * lay["layout"]["self_attn.linear_q.bias"][0]
+    g.qkv_row_off, g.qkv_bias_off, g.pw1_row_off, g.pw1_bias_off = (lay[k].data_ptr() for k in ("qkv_row", "qkv_bias", "pw1_row", "pw1_bias"))
+    esz = 4 if adt == torch.float32 else 2
+    sc = cfm.LayerTrainScratch()
+    sc.dxn = cfm.scratch("t_dxn", M * D, torch.float32, dev).data_ptr()
+    for name, wd in (("dz", FF), ("dyb", D), ("ds", D), ("dglu", D), ("du", 2 * D), ("dctx", D), ("dqkv", 3 * D)):
+        setattr(sc, name, cfm.scratch("t_" + name, M * wd, adt, dev).data_ptr())
+    sc.delta = cfm.scratch("attn_delta", B * H * T, torch.float32, dev).data_ptr()
+    sc.ln_ws = cfm.scratch("ln_bwd", cfm.lib().cfm_layernorm_bwd_ws(M, D), torch.float32, dev).data_ptr()
+    sc.dwbn_ws = cfm.scratch("dwbn", cfm.lib().cfm_dwconv_bn_ws(B, T, D), torch.float32, dev).data_ptr()
+    sc.dy_ws = cfm.scratch("dwbn_dy", M * D, torch.float32, dev).data_ptr()
+    dyc = _f32c(dy.reshape(M, D))
+    dx = torch.empty((M, D), dtype=torch.float32, device=dev)
+    cfm.check(cfm.lib().cfm_encoder_layer_train_backward(ctypes.byref(w), ctypes.byref(io), ctypes.byref(sv), ctypes.byref(sc), ctypes.byref(g), x0.data_ptr(),
+                                                         dyc.data_ptr(), dx.data_ptr(), cfm.stream()), "cfm_encoder_layer_train_backward")
+    return dx, slab, lay
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """One conformer block in train mode (encoder_layer.py:49-71): four residual sub-blocks + norm_final, one autograd node."""
 
@@ -347,6 +494,11 @@ class EncoderLayerFn(torch.autograd.Function):
     def forward(ctx, x, layer, prec, mask8, m_str, keep, *params):
         B, T, D = x.shape
         rel = layer.use_relative
+        ctx.comp = None
+        if _composite_ok(layer, x):
+            pks = (packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
+                   packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
+            return _layer_composite_forward(ctx, _f32c(x.reshape(B * T, D)), layer, prec, mask8, m_str, keep, pks, B, T, D).view(B, T, D)
         pks = (packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
                packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
         ln = lambda m: (m.weight.detach(), m.bias.detach())
@@ -368,6 +520,14 @@ class EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.comp is not None:
+            layer, B, T, D = ctx.comp[0], ctx.comp[-3], ctx.comp[-2], ctx.comp[-1]
+            dx, slab, lay = _layer_composite_backward(ctx, dy)
+            grads = []
+            for name, p in layer.named_parameters():
+                off, n = lay["layout"][name]
+                grads.append(slab[off:off + n].view(p.shape) if p.requires_grad else None)
+            return (dx.view(B, T, D), None, None, None, None, None) + tuple(grads)
         layer, prec, mask8, m_str, keep, pks, (s1, s2, s3, s4, x4), B, T, D, dr = ctx.args
         rel = layer.use_relative
         ln = lambda m: (m.weight.detach(), m.bias.detach())

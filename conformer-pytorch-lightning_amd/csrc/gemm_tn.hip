@@ -36,6 +36,8 @@ struct TnArgs {
     float alpha;
     int convC, T1, F1, T2, F2;
     int chunks_per_split, atomic;
+    const int64_t* row_off;
+    const int64_t* colsum_off;
 };
 
 // LDS row stride in 16-bit elements: TILE + 16 -> 288 B = 72 words = 8 (mod 64) for TILE 128, 160 B = 40 words for TILE 64: the 4 rows of a
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
         for (int j = 0; j < FR; ++j) {
             const int k = k0 + wc * (TILE / 2) + j * 16 + 4 * g4;
             if (k >= g.K) continue;                  // K % 4 == 0: the 4 columns are valid together
-            float* c = g.C + (int64_t)n * g.ldc + k;
+            float* c = g.C + (g.row_off ? g.row_off[n] : (int64_t)n * g.ldc) + k;
             const f32x4 v = acc[i][j] * g.alpha;
             if (g.atomic) {
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
             }
         }
     }
-    if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum + n0 + tid, csum * g.alpha);
+    if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n0 + tid] : (int64_t)(n0 + tid)), csum * g.alpha);
 }
 
 template <typename HT, bool SPLIT, bool A32, bool B32>
@@ -279,6 +281,8 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum; a.mask = d->row_mask; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.M = d->M; a.N = d->N; a.K = d->K; a.alpha = d->alpha;
     a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
+    CFM_CHECK_ARG((!d->row_off && !d->colsum_off) || d->accumulate, "cfm_gemm_tn: row_off / colsum_off need accumulate = 1 (zero-filled by the caller)");
+    a.row_off = d->row_off; a.colsum_off = d->colsum_off;
     a.chunks_per_split = (chunks + splits - 1) / splits;
     splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;   // no empty split
     a.atomic = (splits > 1 || d->accumulate) ? 1 : 0;

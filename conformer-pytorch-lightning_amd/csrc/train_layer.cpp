@@ -1,0 +1,205 @@
+// train_layer.cpp -- one conformer block in TRAIN mode, forward and backward, enqueued from C++ (no host synchronisation, no allocation).
+//
+// reference: src/encoder_layer.py:49-71 under module.train() -- four residual sub-blocks (1/2 FFN, MHSA, convolution module with BatchNorm
+// batch statistics, 1/2 FFN) + norm_final, dropout on every branch output / FFN hidden activation / attention probabilities -- and what
+// autograd derives from it.  The same launches, in the same order, as the op-by-op composition in cfm/autograd.py (which remains for the
+// bare modules and as the readable specification; tests run both and compare): ~17 launches forward, ~60 backward per block, issued from
+// ONE host call each instead of ~60 Python -> ctypes round trips (~18 us apiece: the step was host-bound at 40 ms with 27 ms of kernels).
+//
+// Parameter gradients are written (accumulated: the caller zero-fills) straight into a caller-provided flat buffer through per-parameter
+// pointers / row-offset maps -- in the data-parallel trainer that buffer IS the gradient bucket memory the RCCL all-reduce runs on.
+#include <math.h>
+
+#include "cfm_common.h"
+
+namespace {
+
+struct TCtx {
+    const cfm_layer_train_weights* w;
+    const cfm_layer_train_io* io;
+    int M, D, FF, H, dk, adt, wdt;
+    bool split;
+    cfm_stream_t st;
+};
+
+#define CFM_TRY(expr)                    \
+    do {                                 \
+        int rc__ = (expr);               \
+        if (rc__ != CFM_OK) return rc__; \
+    } while (0)
+
+inline const void* eoff(const void* p, int64_t elems, int dt) { return (const char*)p + elems * cfm_elt_size(dt); }
+inline void* eoffw(void* p, int64_t elems, int dt) { return (char*)p + elems * cfm_elt_size(dt); }
+
+inline uint32_t site_seed(uint32_t seed, int site) { return seed + 0x9E3779B1u * (uint32_t)site; }
+
+// C = epilogue(A . W^T) with the training options
+int gemm(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* W, const void* Wlo, const float* bias, void* C, int c_dt, int64_t ldc, int M, int N,
+         int K, int act, const float* res, float alpha, const uint8_t* row_mask, int mask_mode, void* pre, const void* aux, float drop_p, uint32_t drop_seed,
+         float drop2_p = 0.f, uint32_t drop2_seed = 0) {
+    cfm_gemm_desc d = {};
+    d.A = A; d.W = W; d.W_lo = c.split ? Wlo : nullptr; d.bias = bias; d.residual = res; d.row_mask = row_mask; d.C = C;
+    d.lda = lda; d.ldc = ldc; d.ldr = ldc; d.M = M; d.N = N; d.K = K;
+    d.a_dtype = a_dt; d.w_dtype = c.wdt; d.c_dtype = c_dt; d.act = act; d.alpha = alpha; d.mask_mode = mask_mode;
+    if (pre) { d.C_pre = pre; d.ld_pre = N; d.pre_dtype = c.adt; }
+    if (aux) { d.aux = aux; d.ld_aux = N; d.aux_dtype = c.adt; }
+    d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop2_p = drop2_p; d.drop2_seed = drop2_seed;
+    if (c.split && !Wlo) return cfm_fail(CFM_ERR_ARG, "train layer: split mode needs the *_lo weight planes");
+    return cfm_gemm(&d, c.st);
+}
+
+// dW (+)= alpha * A^T . B, db (+)= alpha * colsum(A), accumulated into caller memory
+int wgrad(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* B, int b_dt, int64_t ldb, float* dW, float* db, int M, int N, int K, float alpha,
+          const uint8_t* row_mask, const int64_t* row_off, const int64_t* colsum_off) {
+    cfm_gemm_tn_desc d = {};
+    d.A = A; d.B = B; d.C = dW; d.colsum = db; d.row_mask = row_mask; d.lda = lda; d.ldb = ldb; d.ldc = K; d.M = M; d.N = N; d.K = K;
+    d.a_dtype = a_dt; d.b_dtype = b_dt; d.mma_dtype = c.wdt; d.split = c.split ? 1 : 0; d.accumulate = 1; d.splits = c.io->deterministic ? 1 : 0;
+    d.alpha = alpha; d.row_off = row_off; d.colsum_off = colsum_off;
+    return cfm_gemm_tn(&d, c.st);
+}
+
+int ln_fwd(const TCtx& c, const float* x, const float* g, const float* b, void* out, int out_dt, const uint8_t* mask) {
+    // masked variant goes through the second output (out2 = mask ? LN : 0)
+    if (mask) return cfm_layernorm(x, g, b, nullptr, 0, nullptr, nullptr, out, out_dt, mask, 1e-5f, c.M, c.D, c.st);
+    return cfm_layernorm(x, g, b, out, out_dt, nullptr, nullptr, nullptr, 0, nullptr, 1e-5f, c.M, c.D, c.st);
+}
+
+// ---- feed-forward sub-block: x_out = x + 1/2 drop_o(W2 drop_h(silu(W1 LN(x) + b1)) + b2) -------------------------------------------------
+int ffn_fwd(const TCtx& c, const float* x, const float* lg, const float* lb, const void* w1, const void* w1l, const float* b1, const void* w2, const void* w2l,
+            const float* b2, void* xn, void* z, void* h, float* x_out, float p_h, uint32_t s_h, float p_o, uint32_t s_o) {
+    CFM_TRY(ln_fwd(c, x, lg, lb, xn, c.adt, nullptr));
+    CFM_TRY(gemm(c, xn, c.adt, c.D, w1, w1l, b1, h, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_SILU, nullptr, 0.f, nullptr, 0, z, nullptr, p_h, s_h));
+    return gemm(c, h, c.adt, c.FF, w2, w2l, b2, x_out, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, x, 0.5f, nullptr, 0, nullptr, nullptr, p_o, s_o);
+}
+
+// d (f32 [M,D], the gradient of the sub-block's output) is updated in place to the gradient of its input
+int ffn_bwd(const TCtx& c, const cfm_layer_train_scratch* t, float* d, const float* x, const float* lg, const void* xn, const void* z, const void* h,
+            const void* w1t, const void* w1tl, const void* w2t, const void* w2tl, float* gW1, float* gb1, float* gW2, float* gb2, float* glg, float* glb,
+            float p_h, uint32_t s_h, float p_o, uint32_t s_o) {
+    const void* dyb = d;
+    int dyb_dt = CFM_F32;
+    float alpha = 0.5f;
+    if (p_o > 0.f) {   // the branch gradient through the output dropout, as a GEMM operand
+        CFM_TRY(cfm_dropout_rows(d, CFM_F32, t->dyb, c.adt, nullptr, 0.5f, p_o, s_o, 0.f, 0, c.M, c.D, c.st));
+        dyb = t->dyb; dyb_dt = c.adt; alpha = 1.0f;
+    }
+    CFM_TRY(wgrad(c, dyb, dyb_dt, c.D, h, c.adt, c.FF, gW2, gb2, c.M, c.D, c.FF, alpha, nullptr, nullptr, nullptr));
+    CFM_TRY(gemm(c, dyb, dyb_dt, c.D, w2t, w2tl, nullptr, t->dz, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_DSILU, nullptr, alpha, nullptr, 0, nullptr, z, p_h, s_h));
+    CFM_TRY(wgrad(c, t->dz, c.adt, c.FF, xn, c.adt, c.D, gW1, gb1, c.M, c.FF, c.D, 1.0f, nullptr, nullptr, nullptr));
+    CFM_TRY(gemm(c, t->dz, c.adt, c.FF, w1t, w1tl, nullptr, t->dxn, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
+    return cfm_layernorm_bwd(x, t->dxn, CFM_F32, lg, nullptr, d, d, glg, glb, t->ln_ws, 1e-5f, c.M, c.D, c.st);
+}
+
+}  // namespace
+
+extern "C" int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                               const cfm_layer_train_scratch* t, const float* x_in, float* y_out, cfm_stream_t stream) {
+    CFM_CHECK_ARG(w && io && sv && t && x_in && y_out, "cfm_encoder_layer_train_forward: null pointer");
+    CFM_CHECK_ARG(io->B > 0 && io->T > 0 && io->D > 0 && io->H > 0 && io->D % io->H == 0 && io->FF > 0 && io->D % 16 == 0,
+                  "cfm_encoder_layer_train_forward: bad dims B=%d T=%d D=%d H=%d FF=%d", io->B, io->T, io->D, io->H, io->FF);
+    TCtx c;
+    c.w = w; c.io = io; c.M = io->B * io->T; c.D = io->D; c.FF = io->FF; c.H = io->H; c.dk = io->D / io->H; c.adt = io->act_dtype; c.wdt = io->w_dtype;
+    c.split = io->act_dtype == CFM_F32; c.st = stream;
+    const int M = c.M, D = c.D, adt = c.adt;
+    const uint32_t sd = io->seed;
+    // (1) macaron feed-forward
+    CFM_TRY(ffn_fwd(c, x_in, w->ln_ffm_g, w->ln_ffm_b, w->ffm_w1, w->ffm_w1_lo, w->ffm_b1, w->ffm_w2, w->ffm_w2_lo, w->ffm_b2, sv->xn1, sv->z1, sv->h1, sv->x1,
+                    io->p_hidden_m, site_seed(sd, 1), io->p_branch, site_seed(sd, 2)));
+    // (2) self-attention: q + pos_bias_u rides in the projection's bias; the batch path's positional term is softmax-invariant
+    CFM_TRY(ln_fwd(c, sv->x1, w->ln_mha_g, w->ln_mha_b, sv->xn2, adt, nullptr));
+    CFM_TRY(gemm(c, sv->xn2, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, sv->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
+    {
+        cfm_attn_desc a = {};
+        const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
+        a.q = sv->qkv; a.k = eoff(sv->qkv, D, adt); a.v = eoff(sv->qkv, 2 * D, adt);
+        a.q_sb = a.k_sb = a.v_sb = sb; a.q_st = a.k_st = a.v_st = stt; a.k_sh = a.v_sh = c.dk;
+        a.q_dtype = a.kv_dtype = adt; a.out = sv->ctx; a.out_dtype = adt;
+        a.mask = io->attn_mask; a.m_sb = io->am_sb; a.m_sq = io->am_sq;
+        a.B = io->B; a.H = c.H; a.Tq = a.Tk = io->T; a.dk = c.dk; a.mma_dtype = c.wdt; a.split = c.split ? 1 : 0; a.scale = 1.0f / sqrtf((float)c.dk);
+        a.lse = sv->lse; a.drop_p = io->p_attn; a.drop_seed = site_seed(sd, 3);
+        CFM_TRY(cfm_attention(&a, stream));
+    }
+    {
+        float p1 = io->p_branch, p2 = io->p_attn_out;
+        uint32_t s1 = site_seed(sd, 4), s2 = site_seed(sd, 5);
+        if (p1 <= 0.f && p2 > 0.f) { p1 = p2; s1 = s2; p2 = 0.f; }
+        CFM_TRY(gemm(c, sv->ctx, adt, D, w->out_w, w->out_w_lo, w->out_b, sv->x2, CFM_F32, D, M, D, D, CFM_ACT_NONE, sv->x1, 1.0f, nullptr, 0, nullptr, nullptr, p1, s1, p2, s2));
+    }
+    // (3) convolution module, BatchNorm in training mode
+    CFM_TRY(ln_fwd(c, sv->x2, w->ln_conv_g, w->ln_conv_b, sv->xn3, adt, io->pad_valid));
+    CFM_TRY(gemm(c, sv->xn3, adt, D, w->pw1_w, w->pw1_w_lo, w->pw1_b, sv->glu, adt, D, M, 2 * D, D, CFM_ACT_GLU, nullptr, 0.f, nullptr, 0, sv->u, nullptr, 0.f, 0));
+    CFM_TRY(cfm_dwconv_bn_train(sv->glu, adt, w->dw_w, w->dw_b, w->bn_gamma, w->bn_beta, w->bn_running_mean, w->bn_running_var, w->bn_momentum, w->bn_eps, sv->c,
+                                sv->stats, sv->s, adt, t->dwbn_ws, io->B, io->T, D, io->ktaps, stream));
+    CFM_TRY(gemm(c, sv->s, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, sv->x3, CFM_F32, D, M, D, D, CFM_ACT_NONE, sv->x2, 1.0f, io->pad_valid, 0, nullptr, nullptr,
+                 io->p_branch, site_seed(sd, 6)));
+    // (4) feed-forward, (5) norm_final
+    CFM_TRY(ffn_fwd(c, sv->x3, w->ln_ff_g, w->ln_ff_b, w->ff_w1, w->ff_w1_lo, w->ff_b1, w->ff_w2, w->ff_w2_lo, w->ff_b2, sv->xn4, sv->z2, sv->h2, sv->x4, io->p_hidden,
+                    site_seed(sd, 7), io->p_branch, site_seed(sd, 8)));
+    return cfm_layernorm(sv->x4, w->ln_final_g, w->ln_final_b, y_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, 1e-5f, M, D, stream);
+}
+
+extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                                const cfm_layer_train_scratch* t, const cfm_layer_train_grads* g, const float* x_in, const float* dy,
+                                                float* dx, cfm_stream_t stream) {
+    CFM_CHECK_ARG(w && io && sv && t && g && x_in && dy && dx && dx != dy, "cfm_encoder_layer_train_backward: null pointer (dx must not alias dy)");
+    TCtx c;
+    c.w = w; c.io = io; c.M = io->B * io->T; c.D = io->D; c.FF = io->FF; c.H = io->H; c.dk = io->D / io->H; c.adt = io->act_dtype; c.wdt = io->w_dtype;
+    c.split = io->act_dtype == CFM_F32; c.st = stream;
+    const int M = c.M, D = c.D, adt = c.adt;
+    const uint32_t sd = io->seed;
+    float* d = dx;                                        // the residual stream's gradient, updated in place from the block's output to its input
+    // (5) norm_final
+    CFM_TRY(cfm_layernorm_bwd(sv->x4, dy, CFM_F32, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, t->ln_ws, 1e-5f, M, D, stream));
+    // (4) feed-forward
+    CFM_TRY(ffn_bwd(c, t, d, sv->x3, w->ln_ff_g, sv->xn4, sv->z2, sv->h2, w->ff_w1t, w->ff_w1t_lo, w->ff_w2t, w->ff_w2t_lo, g->ff_w1, g->ff_b1, g->ff_w2, g->ff_b2,
+                    g->ln_ff_g, g->ln_ff_b, io->p_hidden, site_seed(sd, 7), io->p_branch, site_seed(sd, 8)));
+    // (3) convolution module: x3 = x2 + mask * drop(s . Wpw2^T + b)
+    {
+        const void* dyb = d;
+        int dyb_dt = CFM_F32;
+        if (io->p_branch > 0.f) {
+            CFM_TRY(cfm_dropout_rows(d, CFM_F32, t->dyb, adt, nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0, M, D, stream));
+            dyb = t->dyb; dyb_dt = adt;
+        }
+        CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, io->pad_valid, nullptr, nullptr));
+        CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, io->pad_valid, 1, nullptr, nullptr, 0.f, 0));
+        CFM_TRY(cfm_dwconv_bn_train_bwd(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
+                                        io->B, io->T, D, io->ktaps, stream));
+        CFM_TRY(cfm_glu_bwd(sv->u, adt, t->dglu, adt, t->du, adt, M, D, stream));
+        CFM_TRY(wgrad(c, t->du, adt, 2 * D, sv->xn3, adt, D, g->slab, g->slab, M, 2 * D, D, 1.0f, nullptr, g->pw1_row_off, g->pw1_bias_off));
+        CFM_TRY(gemm(c, t->du, adt, 2 * D, w->pw1_t, w->pw1_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 2 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
+        CFM_TRY(cfm_layernorm_bwd(sv->x2, t->dxn, CFM_F32, w->ln_conv_g, io->pad_valid, d, d, g->ln_conv_g, g->ln_conv_b, t->ln_ws, 1e-5f, M, D, stream));
+    }
+    // (2) self-attention: x2 = x1 + drop(ctx . Wo^T + bo)
+    {
+        float p1 = io->p_branch, p2 = io->p_attn_out;
+        uint32_t s1 = site_seed(sd, 4), s2 = site_seed(sd, 5);
+        if (p1 <= 0.f && p2 > 0.f) { p1 = p2; s1 = s2; p2 = 0.f; }
+        const void* dyb = d;
+        int dyb_dt = CFM_F32;
+        if (p1 > 0.f) {
+            CFM_TRY(cfm_dropout_rows(d, CFM_F32, t->dyb, adt, nullptr, 1.0f, p1, s1, p2, s2, M, D, stream));
+            dyb = t->dyb; dyb_dt = adt;
+        }
+        CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->ctx, adt, D, g->out_w, g->out_b, M, D, D, 1.0f, nullptr, nullptr, nullptr));
+        CFM_TRY(gemm(c, dyb, dyb_dt, D, w->out_t, w->out_t_lo, nullptr, t->dctx, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
+        cfm_attn_bwd_desc b = {};
+        const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
+        b.q = sv->qkv; b.k = eoff(sv->qkv, D, adt); b.v = eoff(sv->qkv, 2 * D, adt);
+        b.mask = io->attn_mask; b.out = sv->ctx; b.dout = t->dctx; b.lse = sv->lse;
+        b.grad_q = t->dqkv; b.grad_k = eoffw(t->dqkv, D, adt); b.grad_v = eoffw(t->dqkv, 2 * D, adt); b.delta = t->delta;
+        b.q_sb = b.k_sb = b.v_sb = sb; b.q_st = b.k_st = b.v_st = stt; b.m_sb = io->am_sb; b.m_sq = io->am_sq;
+        b.B = io->B; b.H = c.H; b.Tq = b.Tk = io->T; b.dk = c.dk; b.io_dtype = adt; b.dout_dtype = adt; b.mma_dtype = c.wdt; b.split = c.split ? 1 : 0;
+        b.scale = 1.0f / sqrtf((float)c.dk); b.drop_p = io->p_attn; b.drop_seed = site_seed(sd, 3);
+        CFM_TRY(cfm_attention_bwd(&b, stream));
+        CFM_TRY(wgrad(c, t->dqkv, adt, 3 * D, sv->xn2, adt, D, g->slab, g->slab, M, 3 * D, D, 1.0f, nullptr, g->qkv_row_off, g->qkv_bias_off));
+        if (g->pos_bias_u && g->q_bias &&              // d/du of (q + u) . k^T = d/d(linear_q.bias): the column sums of dq
+            hipMemcpyAsync(g->pos_bias_u, g->q_bias, (size_t)D * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return cfm_fail(CFM_ERR_LAUNCH, "train layer: copy of the pos_bias_u gradient failed");
+        CFM_TRY(gemm(c, t->dqkv, adt, 3 * D, w->qkv_t, w->qkv_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 3 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
+        CFM_TRY(cfm_layernorm_bwd(sv->x1, t->dxn, CFM_F32, w->ln_mha_g, nullptr, d, d, g->ln_mha_g, g->ln_mha_b, t->ln_ws, 1e-5f, M, D, stream));
+    }
+    // (1) macaron feed-forward
+    return ffn_bwd(c, t, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t, w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2,
+                   g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), io->p_branch, site_seed(sd, 2));
+}

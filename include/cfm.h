@@ -139,6 +139,11 @@ typedef struct {
     int32_t split, accumulate, splits;
     float alpha;
     int32_t conv_C, conv_T1, conv_F1, conv_T2, conv_F2;
+    /* optional scatter of the output (needs accumulate = 1: the caller has zero-filled the destination): row n of C starts at C + row_off[n]
+     * (elements) instead of C + n*ldc, column sum n goes to colsum[colsum_off[n]] -- lets one fused product (q|k|v, the interleaved
+     * pointwise-conv-1 pack) write each reference parameter's gradient where it lives in a flat gradient buffer.  int64 [N], device. */
+    const int64_t* row_off;
+    const int64_t* colsum_off;
 } cfm_gemm_tn_desc;
 
 int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream);
@@ -521,6 +526,70 @@ int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t 
 int cfm_dropout_rows(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, const uint8_t* row_mask, float alpha, float p, uint32_t seed,
                      float p2, uint32_t seed2, int64_t M, int32_t N, cfm_stream_t stream);
 int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One conformer block in TRAIN mode as two host calls (csrc/train_layer.cpp): encoder_layer.py:49-71 under module.train() and its
+ * backward, the same launches in the same order as the op-by-op composition of cfm/autograd.py.  All buffers are the caller's:
+ *   weights  the train packs (forward [N,K] and transposed [K,N] 16-bit matrices, + lo planes in the f32-accurate mode; cfm/packing.py)
+ *   saved    activations the backward needs, act dtype unless typed: xn1..4 [M,D], z1,z2,h1,h2 [M,FF], qkv [M,3D], ctx [M,D], u [M,2D], glu/s [M,D],
+ *            f32 x1..x4 / c [M,D], lse [B,H,T], stats [4,D]
+ *   scratch  backward work buffers (dxn f32 [M,D], dz [M,FF], dyb/ds/dglu/dctx [M,D], du [M,2D], dqkv [M,3D], delta f32 [B,H,T],
+ *            ln_ws cfm_layernorm_bwd_ws floats, dwbn_ws cfm_dwconv_bn_ws floats, dy_ws f32 [M,D]); the forward uses dwbn_ws only
+ *   grads    where each parameter's gradient goes: plain pointers, and for the two fused products (q|k|v, the interleaved pointwise-conv-1
+ *            pack) per-row element offsets relative to `slab` (cfm_gemm_tn_desc.row_off).  Weight / bias gradients are ACCUMULATED: the
+ *            caller zero-fills; LayerNorm / BatchNorm / depthwise gradients are overwritten.  pos_bias_u receives a copy of q_bias' gradient.
+ * Dropout: probabilities per site and one seed (site s uses seed + 0x9E3779B1*s); 0 disables.  deterministic = 1: weight-gradient products
+ * run unsplit (no atomics).  Returns like every entry point; nothing is synchronised. */
+typedef struct {
+    const float *ln_ffm_g, *ln_ffm_b, *ln_mha_g, *ln_mha_b, *ln_conv_g, *ln_conv_b, *ln_ff_g, *ln_ff_b, *ln_final_g, *ln_final_b;
+    const void *ffm_w1, *ffm_w1_lo, *ffm_w2, *ffm_w2_lo, *ffm_w1t, *ffm_w1t_lo, *ffm_w2t, *ffm_w2t_lo;
+    const float *ffm_b1, *ffm_b2;
+    const void *ff_w1, *ff_w1_lo, *ff_w2, *ff_w2_lo, *ff_w1t, *ff_w1t_lo, *ff_w2t, *ff_w2t_lo;
+    const float *ff_b1, *ff_b2;
+    const void *qkv_w, *qkv_w_lo, *qkv_t, *qkv_t_lo, *out_w, *out_w_lo, *out_t, *out_t_lo;
+    const float *qkv_b, *out_b;
+    const void *pw1_w, *pw1_w_lo, *pw1_t, *pw1_t_lo, *pw2_w, *pw2_w_lo, *pw2_t, *pw2_t_lo;
+    const float *pw1_b, *pw2_b, *dw_w, *dw_b, *bn_gamma, *bn_beta;
+    float *bn_running_mean, *bn_running_var;
+    float bn_momentum, bn_eps;
+} cfm_layer_train_weights;
+
+typedef struct {
+    int32_t B, T, D, H, FF, ktaps, act_dtype, w_dtype;
+    const uint8_t* attn_mask;
+    int64_t am_sb, am_sq;
+    const uint8_t* pad_valid;
+    float p_hidden_m, p_hidden, p_branch, p_attn, p_attn_out;
+    uint32_t seed;
+    int32_t deterministic;
+} cfm_layer_train_io;
+
+typedef struct {
+    void *xn1, *z1, *h1, *xn2, *qkv, *ctx, *xn3, *u, *glu, *s, *xn4, *z2, *h2;
+    float *x1, *x2, *x3, *x4, *c, *lse, *stats;
+} cfm_layer_train_saved;
+
+typedef struct {
+    float* dxn;
+    void *dz, *dyb, *ds, *dglu, *du, *dctx, *dqkv;
+    float *delta, *ln_ws, *dwbn_ws, *dy_ws;
+} cfm_layer_train_scratch;
+
+typedef struct {
+    float* slab;
+    float *ln_ffm_g, *ln_ffm_b, *ln_mha_g, *ln_mha_b, *ln_conv_g, *ln_conv_b, *ln_ff_g, *ln_ff_b, *ln_final_g, *ln_final_b;
+    float *ffm_w1, *ffm_b1, *ffm_w2, *ffm_b2, *ff_w1, *ff_b1, *ff_w2, *ff_b2;
+    float *out_w, *out_b, *pw2_w, *pw2_b, *dw_w, *dw_b, *bn_g, *bn_b;
+    float* pos_bias_u;
+    const float* q_bias;
+    const int64_t *qkv_row_off, *qkv_bias_off, *pw1_row_off, *pw1_bias_off;
+} cfm_layer_train_grads;
+
+int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                    const cfm_layer_train_scratch* t, const float* x_in, float* y_out, cfm_stream_t stream);
+int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                     const cfm_layer_train_scratch* t, const cfm_layer_train_grads* g, const float* x_in, const float* dy, float* dx,
+                                     cfm_stream_t stream);
 
 /* Optimizer step over flat f32 buffers (module.py:140-143 Adam; executor.py:150 gradient_clip_val):  g' = g * (*grad_scale) + wd * p;
  * m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)   (torch.optim.Adam).

@@ -43,7 +43,9 @@ def test_library_exports_every_declared_symbol(cfm):
 def test_ctypes_structs_match_c_sizes(cfm, tmp_path):
     structs = {"cfm_gemm_desc": cfm.GemmDesc, "cfm_attn_desc": cfm.AttnDesc, "cfm_ffn_desc": cfm.FfnDesc,
                "cfm_layer_weights": cfm.LayerWeights, "cfm_layer_scratch": cfm.LayerScratch, "cfm_layer_io": cfm.LayerIO,
-               "cfm_gemm_tn_desc": cfm.GemmTnDesc, "cfm_attn_bwd_desc": cfm.AttnBwdDesc, "cfm_rowchain_desc": cfm.RowChainDesc}
+               "cfm_gemm_tn_desc": cfm.GemmTnDesc, "cfm_attn_bwd_desc": cfm.AttnBwdDesc, "cfm_rowchain_desc": cfm.RowChainDesc,
+               "cfm_layer_train_weights": cfm.LayerTrainWeights, "cfm_layer_train_io": cfm.LayerTrainIO, "cfm_layer_train_saved": cfm.LayerTrainSaved,
+               "cfm_layer_train_scratch": cfm.LayerTrainScratch, "cfm_layer_train_grads": cfm.LayerTrainGrads}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "cfm.h"\nint main(){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in structs) + "return 0;}\n")

@@ -339,6 +339,42 @@ def test_dropout_gradients_by_finite_differences(pkg, rel):
     pkg.cfm.set_precision("bf16")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+@pytest.mark.parametrize("rel", [True, False])
+def test_composite_block_equals_op_by_op(pkg, mode, rel):
+    """The block enqueued from C++ (csrc/train_layer.cpp, two host calls) against the op-by-op composition of cfm/autograd.py (one C-ABI call
+    per kernel): the same launches in the same order, so with the weight-gradient products unsplit (no atomics) output, input gradient and
+    every parameter gradient are BIT-identical -- with dropout 0.1 active (same seed) and a ragged batch."""
+    from cfm import autograd as ag
+    pkg.cfm.set_precision(mode)
+    pkg.cfm.set_deterministic(True)
+    try:
+        D, H, FF, K, B, T = 144, 4, 576, 15, 3, 37
+        layer = synth.load_synth_(pkg.encoder_layer.ConformerEncoderLayer(D, K, 0.1, 0.1, FF, H, rel), 35).to(DEV).train()
+        pad = pad_valid([37, 30, 19], T)
+        pos_b = pkg.attention.RelativePositionalEncoding(D, 0.0).pe[0:B].to(DEV) if rel else None
+        x = dev(synth.normal(45, (B, T, D)))
+        G = dev(synth.normal(46, (B, T, D)))
+        res = {}
+        for comp in (True, False):
+            ag.USE_COMPOSITE = comp
+            layer.zero_grad()
+            layer.conv_module.norm.reset_running_stats()
+            xr = x.clone().requires_grad_(True)
+            torch.manual_seed(99)
+            out = layer(xr, pad, pos_b, pad)[0]
+            (out * G).sum().backward()
+            res[comp] = (out.detach().clone(), xr.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()},
+                         layer.conv_module.norm.running_var.clone())
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][3], res[False][3])
+        for k in res[True][2]:
+            assert torch.equal(res[True][2][k], res[False][2][k]), k
+    finally:
+        ag.USE_COMPOSITE = True
+        pkg.cfm.set_deterministic(False)
+        pkg.cfm.set_precision("bf16")
+
+
 def test_train_mode_refuses_what_is_not_built(pkg):
     D = 144
     enc = pkg.encoder.ConformerEncoder(80, 15, D, 0.0, 0.0, 0.0, 576, 4, 1, use_relative=True).to(DEV).train()
