@@ -461,9 +461,11 @@ def _layer_composite_backward(ctx, dy):
     layer, prec, mask8, keep, pks, w, io, sv, (act, f32, x0), B, T, D = ctx.comp
     dev, adt = x0.device, prec.act_dtype
     M, FF, H = B * T, layer.hidden_dim, layer.num_heads
-    lay = layer_grad_layout(layer, getattr(layer, "_flat_grad_offsets", None))
-    target = getattr(layer, "_flat_grad_target", None)              # the trainer's gradient memory for this block (accumulated into), or a private slab
-    slab = target if target is not None else torch.zeros((lay["numel"],), dtype=torch.float32, device=dev)
+    # the slab mirrors the trainer's flat layout of this block when the block takes part as one autograd leaf (trainer.py), else a private
+    # named_parameters-order layout; zero-filled: weight / bias gradients are accumulated into it by the split-M products
+    leaf = layer.__dict__.get("_flat_leaf") if ctx.flat else None
+    lay = layer_grad_layout(layer, layer.__dict__.get("_flat_grad_offsets") if ctx.flat else None)
+    slab = torch.zeros((leaf.numel() if leaf is not None else lay["numel"],), dtype=torch.float32, device=dev)
     g = cfm.LayerTrainGrads()
     g.slab = slab.data_ptr()
     for name, field in _GRAD_FIELDS.items():
@@ -495,6 +497,9 @@ class EncoderLayerFn(torch.autograd.Function):
         B, T, D = x.shape
         rel = layer.use_relative
         ctx.comp = None
+        ctx.flat = len(params) == 1 and params[0] is getattr(layer, "_flat_leaf", None)
+        if ctx.flat and not _composite_ok(layer, x):
+            raise RuntimeError("a block registered with a flat parameter leaf (trainer.py) needs the composite train path")
         if _composite_ok(layer, x):
             pks = (packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
                    packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
@@ -523,6 +528,8 @@ class EncoderLayerFn(torch.autograd.Function):
         if ctx.comp is not None:
             layer, B, T, D = ctx.comp[0], ctx.comp[-3], ctx.comp[-2], ctx.comp[-1]
             dx, slab, lay = _layer_composite_backward(ctx, dy)
+            if ctx.flat:                                              # one gradient for the block's flat parameter leaf (trainer.py)
+                return (dx.view(B, T, D), None, None, None, None, None, slab)
             grads = []
             for name, p in layer.named_parameters():
                 off, n = lay["layout"][name]

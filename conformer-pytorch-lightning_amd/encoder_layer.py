@@ -161,7 +161,9 @@ class ConformerEncoderLayer(nn.Module):
             keep = cfm.as_u8_mask(inputs_pad_mask).reshape(-1)
             if keep.numel() != B * T:
                 raise RuntimeError("pad mask %s does not match inputs %s" % (tuple(inputs_pad_mask.shape), tuple(inputs.shape)))
-        return ag.EncoderLayerFn.apply(inputs, self, cfm.resolve_precision(self), m8, m_str, keep, *self.parameters())
+        leaf = self.__dict__.get("_flat_leaf")         # set by trainer.DataParallelTrainer: the block's parameters as ONE autograd leaf
+        params = (leaf,) if leaf is not None else tuple(self.parameters())
+        return ag.EncoderLayerFn.apply(inputs, self, cfm.resolve_precision(self), m8, m_str, keep, *params)
 
     def forward(self, inputs, inputs_attn_mask, pos_embed, inputs_pad_mask=_ABSENT, attn_cache=_ABSENT, cnn_cache=_ABSENT):
         if cfm.check_mode(self, "ConformerEncoderLayer"):

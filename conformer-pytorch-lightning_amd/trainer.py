@@ -96,25 +96,58 @@ class DataParallelTrainer:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
         self.kernels.weights_changed()
 
-        # buckets: contiguous runs of parameters (ready order) of at least bucket_mb
+        # Autograd UNITS.  A conformer block whose backward writes all its parameter gradients into one contiguous slab (cfm/autograd.py
+        # EncoderLayerFn on the composite path) takes part as ONE leaf -- a view of the flat parameter buffer over the block's range, its
+        # .grad the same range of the flat gradient buffer: one AccumulateGrad (one add over the slab) and one hook per block instead of
+        # ~33.  Every other parameter is its own unit.
+        off_of = {id(p): o for p, o in zip(self.params, offs)}
+        in_block = {}
+        self.leaves = []
+        for m in self.modules:
+            for blk in m.modules():
+                if not (hasattr(blk, "train_forward") and hasattr(blk, "_weights")):
+                    continue
+                ps = [p for p in blk.parameters() if p.requires_grad]
+                if not ps or any(id(p) not in off_of for p in ps) or len(ps) != len(list(blk.parameters())):
+                    continue
+                lo = min(off_of[id(p)] for p in ps)
+                hi = max(off_of[id(p)] + (p.numel() + 3) // 4 * 4 for p in ps)
+                if sum((p.numel() + 3) // 4 * 4 for p in ps) != hi - lo:
+                    continue                                                # not contiguous in the flat order (shared parameters): stay per-parameter
+                leaf = self.flat_p[lo:hi].detach().requires_grad_(True)
+                leaf.grad = self.flat_g[lo:hi]
+                blk.__dict__["_flat_leaf"] = leaf
+                blk.__dict__["_flat_grad_offsets"] = {n: off_of[id(p)] - lo for n, p in blk.named_parameters()}
+                self.leaves.append(leaf)
+                for p in ps:
+                    in_block[id(p)] = leaf
+        units, seen_leaf = [], set()                                        # (tensor to hook, start, end) in ready order
+        for p, o in zip(self.params, offs):
+            leaf = in_block.get(id(p))
+            if leaf is None:
+                units.append((p, o, o + (p.numel() + 3) // 4 * 4))
+            elif id(leaf) not in seen_leaf:
+                seen_leaf.add(id(leaf))
+                lo = leaf.data_ptr() - self.flat_p.data_ptr()
+                units.append((leaf, lo // 4, lo // 4 + leaf.numel()))
+        # buckets: contiguous runs of units (ready order) of at least bucket_mb
         limit = int(bucket_mb * (1 << 20) / 4)
-        self.buckets = []                                                   # (start, end, n_params)
+        self.buckets = []                                                   # (start, end, n_units)
         start, count = 0, 0
         self._bucket_of = {}
-        for i, (p, o) in enumerate(zip(self.params, offs)):
-            self._bucket_of[id(p)] = len(self.buckets)
+        for i, (t, lo, hi) in enumerate(units):
+            self._bucket_of[id(t)] = len(self.buckets)
             count += 1
-            end = o + (p.numel() + 3) // 4 * 4
-            if end - start >= limit or i == len(self.params) - 1:
-                self.buckets.append((start, end, count))
-                start, count = end, 0
+            if hi - start >= limit or i == len(units) - 1:
+                self.buckets.append((start, hi, count))
+                start, count = hi, 0
         self._ready = [0] * len(self.buckets)
         self._next = 0
         self._works = []
         self._sync = False
         self.reduce_log = []                                                # bucket indices in launch order of the last step (tests)
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+        for t, _, _ in units:
+            t.register_post_accumulate_grad_hook(self._on_grad)
 
     # ------------------------------------------------------------------------------------------------------------
     def _on_grad(self, p):
