@@ -105,11 +105,11 @@ class LayerTrainIO(ctypes.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("FF", c_i32), ("ktaps", c_i32), ("act_dtype", c_i32), ("w_dtype", c_i32),
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64), ("pad_valid", c_p),
                 ("p_hidden_m", ctypes.c_float), ("p_hidden", ctypes.c_float), ("p_branch", ctypes.c_float), ("p_attn", ctypes.c_float),
-                ("p_attn_out", ctypes.c_float), ("seed", ctypes.c_uint32), ("deterministic", c_i32)]
+                ("p_attn_out", ctypes.c_float), ("seed", ctypes.c_uint32), ("deterministic", c_i32), ("side_stream", c_p)]
 
 
 _TRAIN_SAVED = ["xn1", "z1", "h1", "xn2", "qkv", "ctx", "xn3", "u", "glu", "s", "xn4", "z2", "h2", "x1", "x2", "x3", "x4", "c", "lse", "stats"]
-_TRAIN_SCRATCH = ["dxn", "dz", "dyb", "ds", "dglu", "du", "dctx", "dqkv", "delta", "ln_ws", "dwbn_ws", "dy_ws"]
+_TRAIN_SCRATCH = ["dxn", "dz", "dyb", "ds", "dglu", "du", "dctx", "dqkv", "delta", "ln_ws", "dwbn_ws", "dy_ws", "dz2", "dyb2", "dyb3", "dyb4"]
 _TRAIN_GRADS = ["slab", "ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "ln_conv_b", "ln_ff_g", "ln_ff_b", "ln_final_g", "ln_final_b",
                 "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "ff_w1", "ff_b1", "ff_w2", "ff_b2", "out_w", "out_b", "pw2_w", "pw2_b", "dw_w", "dw_b", "bn_g", "bn_b",
                 "pos_bias_u", "q_bias", "qkv_row_off", "qkv_bias_off", "pw1_row_off", "pw1_bias_off"]

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
     constexpr int TN_BN = TILE, TN_BK = TILE, TN_STR = TILE + 16;
     constexpr int FR = TILE / 32;                    // 16-wide fragments per wavefront and operand (4 or 2)
     constexpr int PPR = TILE / 8;                    // 16-byte pieces per tile row
-    constexpr int MCH = SPLIT ? 32 : 64;             // rows of M per staged chunk
+    constexpr int MCH = (SPLIT ? 32 : 64) * (TILE == 64 ? 2 : 1);   // rows of M per staged chunk (per barrier): 64-wide tiles do only 8 MFMAs
+                                                                     // per wavefront and 32-row step, so they take twice the rows per barrier
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int PLANE = MCH * TN_STR;              // 16-bit elements per operand plane
     constexpr int PASSES = MCH * PPR / 256;          // 16-byte pieces per thread and operand
@@ -263,17 +264,19 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
         CFM_CHECK_ARG(d->ldb % (d->b_dtype == CFM_F32 ? 4 : 8) == 0 && d->ldb >= d->K, "cfm_gemm_tn: bad ldb=%lld", (long long)d->ldb);
     }
     hipStream_t s = (hipStream_t)stream;
-    const int mch = d->split ? 32 : 64;
-    const int chunks = (d->M + mch - 1) / mch;
+    const int mch128 = d->split ? 32 : 64;                  // chunk rows of the 128-wide tile; the 64-wide tile stages twice as many per barrier
+    const int chunks128 = (d->M + mch128 - 1) / mch128;
     // 64 x 64 tiles while the output is small (fewer than 128 tiles of 128 x 128: every weight of the d = 256 / 512 blocks), 128 x 128 for
     // the big ones (the CTC head's 5008 x 256, the front-end convolutions): then about one workgroup per CU
     const int t128 = ((d->N + 127) / 128) * ((d->K + 127) / 128);
-    const int tile = (t128 >= 128 || chunks >= 128) ? 128 : 64;        // M >= 8 k rows: enough splits of >= 4 chunks even with few big tiles
+    const int tile = (t128 >= 128 || chunks128 >= 128) ? 128 : 64;     // M >= 8 k rows: enough splits of >= 4 chunks even with few big tiles
+    const int mch = tile == 64 ? 2 * mch128 : mch128;
+    const int chunks = (d->M + mch - 1) / mch;
     const int tiles = ((d->N + tile - 1) / tile) * ((d->K + tile - 1) / tile);
     int splits = d->splits;
     if (splits <= 0) {
         splits = (256 + tiles - 1) / tiles;
-        const int max_s = (chunks + 3) / 4;                 // at least 4 chunks (256 rows) per split
+        const int max_s = (chunks * mch + 255) / 256;       // at least 256 rows per split
         splits = splits > max_s ? max_s : splits;
     }
     splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);

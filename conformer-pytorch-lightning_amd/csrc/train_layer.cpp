@@ -20,7 +20,33 @@ struct TCtx {
     int M, D, FF, H, dk, adt, wdt;
     bool split;
     cfm_stream_t st;
+    cfm_stream_t side;      // weight-gradient products go here when set (backward)
 };
+
+// A small pool of timing-free events for the main -> side stream hand-offs (created once per process; events are recorded and waited on
+// in stream order, so one event can be reused as soon as its wait has been enqueued).
+struct EventPool {
+    hipEvent_t ev[32];
+    int n = 0, next = 0;
+    hipEvent_t get() {
+        if (n < 32) {
+            if (hipEventCreateWithFlags(&ev[n], hipEventDisableTiming) != hipSuccess) return nullptr;
+            return ev[n++];
+        }
+        hipEvent_t e = ev[next];
+        next = (next + 1) % 32;
+        return e;
+    }
+};
+thread_local EventPool g_events;
+
+// make `to` wait for everything enqueued on `from` so far
+int stream_after(cfm_stream_t from, cfm_stream_t to) {
+    hipEvent_t e = g_events.get();
+    if (!e || hipEventRecord(e, (hipStream_t)from) != hipSuccess || hipStreamWaitEvent((hipStream_t)to, e, 0) != hipSuccess)
+        return cfm_fail(CFM_ERR_LAUNCH, "train layer: stream hand-off failed");
+    return CFM_OK;
+}
 
 #define CFM_TRY(expr)                    \
     do {                                 \
@@ -48,14 +74,20 @@ int gemm(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* W, con
     return cfm_gemm(&d, c.st);
 }
 
-// dW (+)= alpha * A^T . B, db (+)= alpha * colsum(A), accumulated into caller memory
+// dW (+)= alpha * A^T . B, db (+)= alpha * colsum(A), accumulated into caller memory.  With a side stream: issued there, after everything the
+// main stream has enqueued so far (its operands); the operands must then stay untouched until the streams are joined (end of the backward)
 int wgrad(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* B, int b_dt, int64_t ldb, float* dW, float* db, int M, int N, int K, float alpha,
           const uint8_t* row_mask, const int64_t* row_off, const int64_t* colsum_off) {
+    cfm_stream_t st = c.st;
+    if (c.side) {
+        if (int rc = stream_after(c.st, c.side)) return rc;
+        st = c.side;
+    }
     cfm_gemm_tn_desc d = {};
     d.A = A; d.B = B; d.C = dW; d.colsum = db; d.row_mask = row_mask; d.lda = lda; d.ldb = ldb; d.ldc = K; d.M = M; d.N = N; d.K = K;
     d.a_dtype = a_dt; d.b_dtype = b_dt; d.mma_dtype = c.wdt; d.split = c.split ? 1 : 0; d.accumulate = 1; d.splits = c.io->deterministic ? 1 : 0;
     d.alpha = alpha; d.row_off = row_off; d.colsum_off = colsum_off;
-    return cfm_gemm_tn(&d, c.st);
+    return cfm_gemm_tn(&d, st);
 }
 
 int ln_fwd(const TCtx& c, const float* x, const float* g, const float* b, void* out, int out_dt, const uint8_t* mask) {
@@ -73,20 +105,21 @@ int ffn_fwd(const TCtx& c, const float* x, const float* lg, const float* lb, con
 }
 
 // d (f32 [M,D], the gradient of the sub-block's output) is updated in place to the gradient of its input
-int ffn_bwd(const TCtx& c, const cfm_layer_train_scratch* t, float* d, const float* x, const float* lg, const void* xn, const void* z, const void* h,
-            const void* w1t, const void* w1tl, const void* w2t, const void* w2tl, float* gW1, float* gb1, float* gW2, float* gb2, float* glg, float* glb,
-            float p_h, uint32_t s_h, float p_o, uint32_t s_o) {
+int ffn_bwd(const TCtx& c, const cfm_layer_train_scratch* t, void* dyb_buf, void* dz_buf, float* d, const float* x, const float* lg, const void* xn, const void* z,
+            const void* h, const void* w1t, const void* w1tl, const void* w2t, const void* w2tl, float* gW1, float* gb1, float* gW2, float* gb2, float* glg,
+            float* glb, float p_h, uint32_t s_h, float p_o, uint32_t s_o) {
     const void* dyb = d;
     int dyb_dt = CFM_F32;
     float alpha = 0.5f;
-    if (p_o > 0.f) {   // the branch gradient through the output dropout, as a GEMM operand
-        CFM_TRY(cfm_dropout_rows(d, CFM_F32, t->dyb, c.adt, nullptr, 0.5f, p_o, s_o, 0.f, 0, c.M, c.D, c.st));
-        dyb = t->dyb; dyb_dt = c.adt; alpha = 1.0f;
+    if (p_o > 0.f || c.side) {   // the branch gradient through the output dropout, as a GEMM operand (with a side stream: always its own buffer --
+                                 // d is overwritten by this sub-block's LayerNorm backward while the weight-gradient product may still read it)
+        CFM_TRY(cfm_dropout_rows(d, CFM_F32, dyb_buf, c.adt, nullptr, 0.5f, p_o, s_o, 0.f, 0, c.M, c.D, c.st));
+        dyb = dyb_buf; dyb_dt = c.adt; alpha = 1.0f;
     }
     CFM_TRY(wgrad(c, dyb, dyb_dt, c.D, h, c.adt, c.FF, gW2, gb2, c.M, c.D, c.FF, alpha, nullptr, nullptr, nullptr));
-    CFM_TRY(gemm(c, dyb, dyb_dt, c.D, w2t, w2tl, nullptr, t->dz, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_DSILU, nullptr, alpha, nullptr, 0, nullptr, z, p_h, s_h));
-    CFM_TRY(wgrad(c, t->dz, c.adt, c.FF, xn, c.adt, c.D, gW1, gb1, c.M, c.FF, c.D, 1.0f, nullptr, nullptr, nullptr));
-    CFM_TRY(gemm(c, t->dz, c.adt, c.FF, w1t, w1tl, nullptr, t->dxn, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
+    CFM_TRY(gemm(c, dyb, dyb_dt, c.D, w2t, w2tl, nullptr, dz_buf, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_DSILU, nullptr, alpha, nullptr, 0, nullptr, z, p_h, s_h));
+    CFM_TRY(wgrad(c, dz_buf, c.adt, c.FF, xn, c.adt, c.D, gW1, gb1, c.M, c.FF, c.D, 1.0f, nullptr, nullptr, nullptr));
+    CFM_TRY(gemm(c, dz_buf, c.adt, c.FF, w1t, w1tl, nullptr, t->dxn, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
     return cfm_layernorm_bwd(x, t->dxn, CFM_F32, lg, nullptr, d, d, glg, glb, t->ln_ws, 1e-5f, c.M, c.D, c.st);
 }
 
@@ -99,7 +132,7 @@ extern "C" int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w,
                   "cfm_encoder_layer_train_forward: bad dims B=%d T=%d D=%d H=%d FF=%d", io->B, io->T, io->D, io->H, io->FF);
     TCtx c;
     c.w = w; c.io = io; c.M = io->B * io->T; c.D = io->D; c.FF = io->FF; c.H = io->H; c.dk = io->D / io->H; c.adt = io->act_dtype; c.wdt = io->w_dtype;
-    c.split = io->act_dtype == CFM_F32; c.st = stream;
+    c.split = io->act_dtype == CFM_F32; c.st = stream; c.side = nullptr;
     const int M = c.M, D = c.D, adt = c.adt;
     const uint32_t sd = io->seed;
     // (1) macaron feed-forward
@@ -145,21 +178,24 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
     TCtx c;
     c.w = w; c.io = io; c.M = io->B * io->T; c.D = io->D; c.FF = io->FF; c.H = io->H; c.dk = io->D / io->H; c.adt = io->act_dtype; c.wdt = io->w_dtype;
     c.split = io->act_dtype == CFM_F32; c.st = stream;
+    c.side = io->side_stream && io->side_stream != stream ? io->side_stream : nullptr;
+    CFM_CHECK_ARG(!c.side || (t->dz2 && t->dyb2 && t->dyb3 && t->dyb4), "cfm_encoder_layer_train_backward: a side stream needs the dz2 / dyb2..4 scratch buffers");
     const int M = c.M, D = c.D, adt = c.adt;
     const uint32_t sd = io->seed;
     float* d = dx;                                        // the residual stream's gradient, updated in place from the block's output to its input
     // (5) norm_final
     CFM_TRY(cfm_layernorm_bwd(sv->x4, dy, CFM_F32, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, t->ln_ws, 1e-5f, M, D, stream));
     // (4) feed-forward
-    CFM_TRY(ffn_bwd(c, t, d, sv->x3, w->ln_ff_g, sv->xn4, sv->z2, sv->h2, w->ff_w1t, w->ff_w1t_lo, w->ff_w2t, w->ff_w2t_lo, g->ff_w1, g->ff_b1, g->ff_w2, g->ff_b2,
+    CFM_TRY(ffn_bwd(c, t, t->dyb, t->dz, d, sv->x3, w->ln_ff_g, sv->xn4, sv->z2, sv->h2, w->ff_w1t, w->ff_w1t_lo, w->ff_w2t, w->ff_w2t_lo, g->ff_w1, g->ff_b1, g->ff_w2, g->ff_b2,
                     g->ln_ff_g, g->ln_ff_b, io->p_hidden, site_seed(sd, 7), io->p_branch, site_seed(sd, 8)));
     // (3) convolution module: x3 = x2 + mask * drop(s . Wpw2^T + b)
     {
         const void* dyb = d;
         int dyb_dt = CFM_F32;
-        if (io->p_branch > 0.f) {
-            CFM_TRY(cfm_dropout_rows(d, CFM_F32, t->dyb, adt, nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0, M, D, stream));
-            dyb = t->dyb; dyb_dt = adt;
+        void* buf = c.side ? t->dyb2 : t->dyb;
+        if (io->p_branch > 0.f || c.side) {
+            CFM_TRY(cfm_dropout_rows(d, CFM_F32, buf, adt, nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0, M, D, stream));
+            dyb = buf; dyb_dt = adt;
         }
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, io->pad_valid, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, io->pad_valid, 1, nullptr, nullptr, 0.f, 0));
@@ -177,9 +213,10 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
         if (p1 <= 0.f && p2 > 0.f) { p1 = p2; s1 = s2; p2 = 0.f; }
         const void* dyb = d;
         int dyb_dt = CFM_F32;
-        if (p1 > 0.f) {
-            CFM_TRY(cfm_dropout_rows(d, CFM_F32, t->dyb, adt, nullptr, 1.0f, p1, s1, p2, s2, M, D, stream));
-            dyb = t->dyb; dyb_dt = adt;
+        void* buf = c.side ? t->dyb3 : t->dyb;
+        if (p1 > 0.f || c.side) {
+            CFM_TRY(cfm_dropout_rows(d, CFM_F32, buf, adt, nullptr, 1.0f, p1, s1, p2, s2, M, D, stream));
+            dyb = buf; dyb_dt = adt;
         }
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->ctx, adt, D, g->out_w, g->out_b, M, D, D, 1.0f, nullptr, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->out_t, w->out_t_lo, nullptr, t->dctx, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
@@ -193,13 +230,16 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
         b.scale = 1.0f / sqrtf((float)c.dk); b.drop_p = io->p_attn; b.drop_seed = site_seed(sd, 3);
         CFM_TRY(cfm_attention_bwd(&b, stream));
         CFM_TRY(wgrad(c, t->dqkv, adt, 3 * D, sv->xn2, adt, D, g->slab, g->slab, M, 3 * D, D, 1.0f, nullptr, g->qkv_row_off, g->qkv_bias_off));
-        if (g->pos_bias_u && g->q_bias &&              // d/du of (q + u) . k^T = d/d(linear_q.bias): the column sums of dq
-            hipMemcpyAsync(g->pos_bias_u, g->q_bias, (size_t)D * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        if (g->pos_bias_u && g->q_bias &&              // d/du of (q + u) . k^T = d/d(linear_q.bias): the column sums of dq (same stream as that product)
+            hipMemcpyAsync(g->pos_bias_u, g->q_bias, (size_t)D * 4, hipMemcpyDeviceToDevice, (hipStream_t)(c.side ? c.side : stream)) != hipSuccess)
             return cfm_fail(CFM_ERR_LAUNCH, "train layer: copy of the pos_bias_u gradient failed");
         CFM_TRY(gemm(c, t->dqkv, adt, 3 * D, w->qkv_t, w->qkv_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 3 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
         CFM_TRY(cfm_layernorm_bwd(sv->x1, t->dxn, CFM_F32, w->ln_mha_g, nullptr, d, d, g->ln_mha_g, g->ln_mha_b, t->ln_ws, 1e-5f, M, D, stream));
     }
     // (1) macaron feed-forward
-    return ffn_bwd(c, t, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t, w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2,
-                   g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), io->p_branch, site_seed(sd, 2));
+    CFM_TRY(ffn_bwd(c, t, c.side ? t->dyb4 : t->dyb, c.side ? t->dz2 : t->dz, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t,
+                    w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2, g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), io->p_branch,
+                    site_seed(sd, 2)));
+    if (c.side) return stream_after(c.side, c.st);       // join: the block's gradients are complete when the main stream gets past this point
+    return CFM_OK;
 }

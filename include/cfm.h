@@ -534,7 +534,8 @@ int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream
  *   saved    activations the backward needs, act dtype unless typed: xn1..4 [M,D], z1,z2,h1,h2 [M,FF], qkv [M,3D], ctx [M,D], u [M,2D], glu/s [M,D],
  *            f32 x1..x4 / c [M,D], lse [B,H,T], stats [4,D]
  *   scratch  backward work buffers (dxn f32 [M,D], dz [M,FF], dyb/ds/dglu/dctx [M,D], du [M,2D], dqkv [M,3D], delta f32 [B,H,T],
- *            ln_ws cfm_layernorm_bwd_ws floats, dwbn_ws cfm_dwconv_bn_ws floats, dy_ws f32 [M,D]); the forward uses dwbn_ws only
+ *            ln_ws cfm_layernorm_bwd_ws floats, dwbn_ws cfm_dwconv_bn_ws floats, dy_ws f32 [M,D]; dz2 / dyb2..4 with a side stream);
+ *            the forward uses dwbn_ws only
  *   grads    where each parameter's gradient goes: plain pointers, and for the two fused products (q|k|v, the interleaved pointwise-conv-1
  *            pack) per-row element offsets relative to `slab` (cfm_gemm_tn_desc.row_off).  Weight / bias gradients are ACCUMULATED: the
  *            caller zero-fills; LayerNorm / BatchNorm / depthwise gradients are overwritten.  pos_bias_u receives a copy of q_bias' gradient.
@@ -562,6 +563,11 @@ typedef struct {
     float p_hidden_m, p_hidden, p_branch, p_attn, p_attn_out;
     uint32_t seed;
     int32_t deterministic;
+    /* backward only, optional: a second HIP stream of the same device.  The weight-gradient products do not feed the chain of input
+     * gradients, so they are issued there (each after an event on its operands) and overlap with the chain on the main stream -- at
+     * training batch sizes no single kernel fills the chip; the main stream waits for the side stream before the call's work is
+     * complete from its point of view (an event wait, not a host synchronisation).  NULL: everything on `stream`. */
+    cfm_stream_t side_stream;
 } cfm_layer_train_io;
 
 typedef struct {
@@ -573,6 +579,8 @@ typedef struct {
     float* dxn;
     void *dz, *dyb, *ds, *dglu, *du, *dctx, *dqkv;
     float *delta, *ln_ws, *dwbn_ws, *dy_ws;
+    void *dz2, *dyb2, *dyb3, *dyb4; /* with a side stream: the operands of overlapped weight-gradient products must outlive the sub-block that
+                                       made them: second feed-forward's dz, one branch-gradient buffer per sub-block (act dtype, [M,FF] / [M,D]) */
 } cfm_layer_train_scratch;
 
 typedef struct {
