@@ -175,6 +175,8 @@ def lib():
         L.cfm_dwconv_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_conv1_relu.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_conv1_relu_mma.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
+        L.cfm_conv12_supported.argtypes = [c_i32, c_i32]
+        L.cfm_conv12_relu.argtypes = [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_valid_mask.argtypes = [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_chunk_mask.argtypes = [c_p, c_i32, c_i32, c_i32, c_p]
         L.cfm_attn_mask.argtypes = [c_p, c_p, c_p, c_i32, c_i32, c_p]
@@ -219,7 +221,7 @@ def lib():
         L.cfm_prof_collect.restype = ctypes.c_int
         L.cfm_prof_entry.argtypes = [c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma",
+        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma", "cfm_conv12_relu", "cfm_conv12_supported",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",

@@ -8,7 +8,7 @@ import cfm as _c
 
 __all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
            "ctc_nll_train", "ctc_grad", "adam_step", "sumsq", "scratch_stats",
-           "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
+           "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "conv12_relu", "conv12_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -285,6 +285,35 @@ def conv1_relu(x, w9c, bias, out_dtype, cmvn=None, mma=False):
     fn = _c.lib().cfm_conv1_relu_mma if mma else _c.lib().cfm_conv1_relu
     _c.check(fn(_c.ptr(x), _c.ptr(w9c), _c.ptr(bias), _c.ptr(out), _c.dt_code(out), B, T, F, C, _c.ptr(mean), _c.ptr(istd), _c.stream()),
              "cfm_conv1_relu_mma" if mma else "cfm_conv1_relu")
+    return out
+
+
+def conv12_supported(C, out_dtype):
+    return out_dtype in (torch.bfloat16, torch.float16) and bool(_c.lib().cfm_conv12_supported(C, _c.dt_code(out_dtype)))
+
+
+def conv12_relu(x, w9c, b1, w2, b2, cmvn=None):
+    """x [B,T,F] f32 -> relu(conv3x3 s2(relu(conv3x3 s2(x)))) as [B*T2*F2, C] in w2's 16-bit dtype, the first convolution recomputed inside
+    the second one's operand producer (include/cfm.h cfm_conv12_relu; bit-identical to conv1_relu(mma=True) + gemm(conv=...))."""
+    _c.require_hip(x, w9c, b1, w2, b2)
+    mean = istd = None
+    if cmvn is not None:
+        mean, istd = cmvn
+        _c.require_hip(mean, istd)
+        for t in (mean, istd):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != x.shape[2] or not t.is_contiguous()):
+                raise ValueError("cfm.conv12_relu: cmvn statistics must be contiguous float32 [F]")
+    if x.dim() != 3 or x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("cfm.conv12_relu: x must be contiguous float32 [B,T,F]")
+    B, T, F = x.shape
+    C = w9c.shape[1]
+    if w2.shape != (C, 9 * C) or not w2.is_contiguous() or w2.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("cfm.conv12_relu: w2 must be a contiguous 16-bit [C, 9C] matrix")
+    T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    out = torch.empty((B * T2 * F2, C), dtype=w2.dtype, device=x.device)
+    _c.check(_c.lib().cfm_conv12_relu(_c.ptr(x), _c.ptr(w9c), _c.ptr(b1), _c.ptr(w2), _c.ptr(b2), _c.ptr(out), _c.dt_code(out), B, T, F, C,
+                                      _c.ptr(mean), _c.ptr(istd), _c.stream()), "cfm_conv12_relu")
     return out
 
 

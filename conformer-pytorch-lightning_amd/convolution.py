@@ -85,6 +85,9 @@ class ConvolutionModule(nn.Module):
         return out.view(B, T, D).to(inputs.dtype), new_cache
 
 
+FUSE_CONVS = True     # tests switch it off to compare with the two-kernel path
+
+
 class ConvolutionSubSampling(nn.Module):
 
     def __init__(self, input_dim, output_dim, pos_enc):
@@ -115,11 +118,15 @@ class ConvolutionSubSampling(nn.Module):
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
         if T2 < 1 or F2 != pk.Fp:
             raise RuntimeError("input of shape %s is too short / has the wrong feature size for this front-end" % (tuple(inputs.shape),))
-        # 16-bit modes: the 9 taps on the matrix pipe (operands rounded to the mode's type, as every other contraction of the mode)
-        h1 = cfm.conv1_relu(x, pk.w1, pk.b1, prec.act_dtype, cmvn=cmvn,
-                            mma=cfm.conv1_relu_mma_supported(C, prec.act_dtype))                 # [B,T1,F1,C]
-        h2 = cfm.gemm(h1, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2),
-                      out_dtype=prec.act_dtype)                                                  # [B*T2*F2, C]
+        if FUSE_CONVS and pk.w2_lo is None and cfm.conv12_supported(C, prec.act_dtype):
+            # 16-bit modes: both convolutions in one kernel, the first one recomputed in the second one's operand producer (bit-identical)
+            h2 = cfm.conv12_relu(x, pk.w1, pk.b1, pk.w2, pk.b2, cmvn=cmvn)                         # [B*T2*F2, C]
+        else:
+            # the 9 taps on the matrix pipe in the 16-bit modes (operands rounded to the mode's type, as every other contraction of the mode)
+            h1 = cfm.conv1_relu(x, pk.w1, pk.b1, prec.act_dtype, cmvn=cmvn,
+                                mma=cfm.conv1_relu_mma_supported(C, prec.act_dtype))             # [B,T1,F1,C]
+            h2 = cfm.gemm(h1, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2),
+                          out_dtype=prec.act_dtype)                                              # [B*T2*F2, C]
         y = cfm.gemm(h2.view(B * T2, F2 * C), pk.wl, bias=pk.bl, w_lo=pk.wl_lo, out_dtype=torch.float32)
         return y.view(B, T2, -1)
 

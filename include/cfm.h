@@ -306,6 +306,15 @@ int cfm_conv1_relu(const float* x, const float* w, const float* bias, void* y, i
 int cfm_conv1_relu_mma(const float* x, const float* w, const float* bias, void* y, int y_dtype, int32_t B, int32_t T, int32_t F,
                        int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream);
 
+/* Both front-end convolutions in one kernel (csrc/frontend.hip): relu(conv3x3 s2 (relu(conv3x3 s2 (x)))) -> y [B,T2,F2,C] channels-last in
+ * the 16-bit type y_dtype.  replaces convolution.py:60-63 in eval mode.  The first convolution is recomputed inside the second one's
+ * A-operand producer with the operands of cfm_conv1_relu_mma, so its [B,T1,F1,C] output never exists in memory; the result is
+ * bit-identical to cfm_conv1_relu_mma followed by cfm_gemm(conv_*, ReLU) on the same packed weights.
+ * w1 [9,C] f32 tap-major, b1 [C], w2 [C, 9*C] 16-bit (y_dtype) in K order (kt, kf, ci), b2 [C] f32.  C in {64,128,192,256}.  CMVN as cfm_conv1_relu. */
+int cfm_conv12_supported(int32_t C, int32_t y_dtype);
+int cfm_conv12_relu(const float* x, const float* w1, const float* b1, const void* w2, const float* b2, void* y, int32_t y_dtype, int32_t B,
+                    int32_t T, int32_t F, int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Masks -- integer/bool, bit-exact with the reference.
  *  cfm_valid_mask     out[b,t] = (t*stride + first) < len[b]     (uint8 0/1), t in [0,T)
