@@ -78,7 +78,10 @@ class RowChainDesc(ctypes.Structure):
                 ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p), ("ln2_b", c_p), ("out_f32", c_p), ("out16", c_p),
                 ("tail_w", c_p), ("tail_b", c_p), ("tail_out", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32),
                 ("tail_N", c_i32), ("tail_glu", c_i32), ("w_dtype", c_i32), ("alpha", ctypes.c_float), ("eps", ctypes.c_float),
-                ("out2_f32", c_p), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32)]
+                ("out2_f32", c_p), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32),
+                ("tail_vt", c_p), ("vt_T", c_i32), ("vt_ld", c_i32),
+                ("att_qkv", c_p), ("att_vt", c_p), ("att_p", c_p), ("att_bias_u", c_p), ("att_bias_v", c_p), ("att_mask", c_p),
+                ("att_p_sb", c_i64), ("att_m_sb", c_i64), ("att_T", c_i32), ("att_H", c_i32), ("att_vt_ld", c_i32), ("att_scale", ctypes.c_float)]
 
 
 _LAYER_W_FIELDS = [
@@ -132,7 +135,7 @@ class LayerWeights(ctypes.Structure):
 
 
 class LayerScratch(ctypes.Structure):
-    _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw")]
+    _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw", "vt")] + [("vt_ld", c_i32)]
 
 
 class LayerIO(ctypes.Structure):

@@ -27,7 +27,8 @@ _arena = {}
 _retired = []
 
 
-def scratch(tag, numel, dtype, device):
+def scratch(tag, numel, dtype, device, zero=False):
+    """zero=True: the block is zero-filled when it is (re)allocated -- for buffers whose never-written parts are read (and must be finite)."""
     device = torch.device(device)
     key = (tag, dtype, device, torch.cuda.current_stream(device).cuda_stream)
     buf = _arena.get(key)
@@ -35,7 +36,7 @@ def scratch(tag, numel, dtype, device):
         want = max(int(numel), 1) if buf is None else max(int(numel), buf.numel() * 3 // 2)
         if buf is not None:
             _retired.append(buf)
-        buf = torch.empty(want, dtype=dtype, device=device)
+        buf = (torch.zeros if zero else torch.empty)(want, dtype=dtype, device=device)
         _arena[key] = buf
     return buf[:numel]
 

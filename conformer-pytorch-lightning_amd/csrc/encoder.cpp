@@ -1,4 +1,5 @@
-// encoder.cpp -- composite: one conformer block enqueued from C++ (5 launches with the row-local chains of rowchain.hip, 17 on the general path; no host sync).
+// encoder.cpp -- composite: one conformer block enqueued from C++ (3 launches with the row-local chains of rowchain.hip when the attention rides in the
+// conv-in chain, 4 otherwise, 17 on the general path; no host sync).
 //
 // Mirrors reference src/encoder_layer.py:49-71:
 //   x = x + 1/2 FFNm(LN(x)); x = x + MHSA(LN(x)); x = x + Conv(LN(x)); x = x + 1/2 FFN(LN(x)); out = LN(x)
@@ -87,8 +88,13 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         if (!io->after_out) return CFM_OK;
         return cfm_layernorm(x_out, io->after_g, io->after_b, io->after_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, eps, M, D, stream);
     };
+    // 3-launch path: the attention runs as the input stage of the conv-in chain (batch path only: no cache / ring, key-validity mask, at most
+    // one positional row per item, T <= 256, 4 heads x 64) on values the macaron chain's tail wrote transposed
+    const bool merged = chains && s->vt && s->vt_ld >= 256 && s->vt_ld % 4 == 0 && D == 256 && H == 4 && !ring && Tc == 0 && !io->new_cache &&
+                        io->T <= 256 && (!has_pos || P == 1) && (!io->attn_mask || io->am_sq == 0);
     if (chains) {
         cfm_rowchain_desc m = {};
+        if (merged) { m.tail_vt = s->vt; m.vt_T = io->T; m.vt_ld = s->vt_ld; }
         m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2n = w->ffm_w2n; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
         m.ln2_g = w->ln_mha_g; m.ln2_b = w->ln_mha_b; m.out_f32 = x_out; m.tail_w = w->qkv_wf; m.tail_b = w->qkv_b; m.tail_out = s->qkv;
         m.M = M; m.D = D; m.FF = FF; m.tail_N = 3 * D; m.tail_glu = 0; m.w_dtype = c.w_dt; m.alpha = 0.5f; m.eps = eps;
@@ -117,6 +123,21 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     if (has_pos && !io->pos_proj)
         CFM_TRY(gemm(c, io->pos_embed, CFM_F32, D, w->pos_w, w->pos_w_lo, nullptr, s->pos, adt, D, io->pos_rows, D, D, CFM_ACT_NONE,
                      nullptr, 0.f, nullptr));
+    if (merged) {
+        // attention + conv-in chain in one launch: context -> out-proj + residual -> LN_conv (pad mask) -> pointwise-conv-1 + GLU
+        cfm_rowchain_desc ci = {};
+        ci.att_qkv = s->qkv; ci.att_vt = s->vt; ci.att_vt_ld = s->vt_ld; ci.att_T = io->T; ci.att_H = H; ci.att_scale = 1.0f / sqrtf((float)dk);
+        ci.att_mask = io->attn_mask; ci.att_m_sb = io->am_sb;
+        if (has_pos) {
+            const int64_t pld = io->pos_proj ? io->pos_proj_ld : D;
+            ci.att_p = io->pos_proj ? io->pos_proj : s->pos; ci.att_p_sb = io->pos_shared ? 0 : pld;
+            ci.att_bias_u = w->bias_u; ci.att_bias_v = w->bias_v;
+        }
+        ci.head_w = w->out_wf; ci.head_b = w->out_b; ci.head_res = x_out; ci.ln_g = w->ln_conv_g; ci.ln_b = w->ln_conv_b;
+        ci.ln_mask = io->pad_valid; ci.out_f32 = x_out; ci.tail_w = w->pw1_wf; ci.tail_b = w->pw1_b; ci.tail_out = s->glu;
+        ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
+        CFM_TRY(cfm_rowchain(&ci, stream));
+    }
     const void* kq = eoff(s->qkv, D, adt);
     const void* vq = eoff(s->qkv, 2 * D, adt);
     const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
@@ -146,14 +167,14 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     a.B = io->B; a.H = H; a.Tq = io->T; a.Tk = Tk; a.dk = dk;
     a.mma_dtype = c.w_dt; a.split = c.split ? 1 : 0;
     a.scale = 1.0f / sqrtf((float)dk);
-    CFM_TRY(cfm_attention(&a, stream));
+    if (!merged) CFM_TRY(cfm_attention(&a, stream));
     if (chains) {
         // conv-in chain: out-proj + residual -> LN_conv (pad mask) -> pointwise-conv-1 + GLU
         cfm_rowchain_desc ci = {};
         ci.head_a = s->ctx; ci.head_w = w->out_wf; ci.head_b = w->out_b; ci.head_res = x_out; ci.ln_g = w->ln_conv_g; ci.ln_b = w->ln_conv_b;
         ci.ln_mask = io->pad_valid; ci.out_f32 = x_out; ci.tail_w = w->pw1_wf; ci.tail_b = w->pw1_b; ci.tail_out = s->glu;
         ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
-        CFM_TRY(cfm_rowchain(&ci, stream));
+        if (!merged) CFM_TRY(cfm_rowchain(&ci, stream));
         // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own
         const bool dw_fused = io->ktaps == 15 && !io->causal_conv;
         if (io->causal_conv) {

@@ -39,6 +39,7 @@
 //    (a 4-word step, the "+8 halfs" habit, makes every fragment read 2-way conflicted);
 //  * everything a phase needs from global memory is requested a phase early (row data, norm parameters, epilogue
 //    operands, the next phase's first weights).
+#include <stdlib.h>
 #include <string>
 #include <type_traits>
 
@@ -68,6 +69,18 @@ struct ChainArgs {
     int tail_N;
     int out16_dtype;
     float alpha, eps;
+    // TVT: the value columns [2D, 3D) of the (fused QKV) tail go out transposed per head, vt[((b*H + h)*64 + d) * vt_ld + t], instead of as rows
+    u16* tail_vt;
+    int vt_T, vt_ld;
+    // HATT: the head input is the attention context of this tile's 32 frames, computed here (see the attention stage in the kernel)
+    const u16* att_qkv;       // [B*T, 3D]: q | k | (values are read from att_vt)
+    const u16* att_vt;        // [B, H, 64, att_vt_ld] transposed values, key columns >= T finite (zero-filled once)
+    const u16* att_p;         // projected positional row per batch item (stride att_p_sb; 0: one shared row), or null (plain MHSA)
+    const float *att_bias_u, *att_bias_v;
+    const uint8_t* att_mask;  // key validity [B, >= T] bytes (stride att_m_sb), or null
+    int64_t att_p_sb, att_m_sb;
+    int att_T, att_vt_ld;
+    float att_scale;
 };
 
 // Phase stamps for scripts/probe_chain.hip (built with -DCFM_CHAIN_STAMPS; never defined in the product build): thread 0 of each
@@ -150,9 +163,11 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
             if ((lane + 64 * it) * 4 < D) v[rr][it] = (v[rr][it] - mean[rr]) * rstd[rr] * gam[it] + bet[it];
 }
 
-template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU>
+template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU, bool HATT = false, bool TVT = false>
 __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr bool HEAD = HSTEPS > 0, TAIL = TSTEPS > 0;
+    static_assert(!HATT || (HEAD && !HDW && !MID && D == 256), "the attention input stage: conv-in chain, 4 heads x 64");
+    static_assert(!TVT || (TAIL && !TGLU && D == 256), "transposed values: a fused-QKV tail with 64-wide heads");
     constexpr int DWK = 15, DWH = (DWK - 1) / 2, DWROWS = RBM + DWK - 1;     // depthwise taps, halo, rows of the halo tile
     constexpr int KS1 = (D + 31) / 32;                     // 32-wide K slices of a D-long row
     constexpr int KP = KS1 * 32;
@@ -168,7 +183,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     // region A: the f32 x tile between HEAD and LN_in, then the 16-bit hidden tile, then the f32 y tile of the FFN
     constexpr int A_MAIN = MID && RBM * HS * 2 > RBM * XS_STRIDE * 4 ? RBM * HS * 2 : RBM * XS_STRIDE * 4;
     constexpr int A_DW = HDW ? DWROWS * D * 2 + DWK * D * 4 : 0;          // 16-bit halo tile + the f32 taps of the depthwise input stage
-    constexpr int A_BYTES = A_MAIN > A_DW ? A_MAIN : A_DW;
+    constexpr int A_ATT = HATT ? 4 * RBM * XS_STRIDE * 4 : 0;             // four partial context tiles (one per key quarter), f32
+    constexpr int A_BYTES = A_MAIN > A_DW ? (A_MAIN > A_ATT ? A_MAIN : A_ATT) : (A_DW > A_ATT ? A_DW : A_ATT);
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[A_BYTES];
     __shared__ __attribute__((aligned(16))) u16 xn[RBM * XN_STRIDE];
     float* const xs = (float*)lds_a;
@@ -177,7 +193,18 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * RBM;
+    // HATT tiles never cross an utterance (the attention stage reads one utterance's keys): tile = (b, 32 frames), rows past the
+    // utterance's end are treated like rows past M everywhere below (clamped loads, no stores)
+    // XCD-aware order: workgroups go round-robin over the 8 XCDs, so the tiles of ONE utterance get ids 8 apart -- they share an L2 and its
+    // keys / values are fetched from memory once, not once per XCD (groups of 8 utterances; padding workgroups of the last group exit)
+    const int att_tiles = HATT ? (a.att_T + RBM - 1) / RBM : 1;
+    const int att_j = blockIdx.x >> 3;
+    const int att_b = HATT ? (att_j / att_tiles) * 8 + (blockIdx.x & 7) : 0, att_t0 = HATT ? (att_j % att_tiles) * RBM : 0;
+    if constexpr (HATT) {
+        if ((int64_t)att_b * a.att_T >= a.M) return;     // uniform, before any barrier
+    }
+    const int64_t row0 = HATT ? (int64_t)att_b * a.att_T + att_t0 : (int64_t)blockIdx.x * RBM;
+    const int64_t Mlim = HATT ? (int64_t)(att_b + 1) * a.att_T : a.M;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     CFM_STAMP(0);
 
@@ -204,7 +231,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int64_t gr = row0 + wave * RPW + rr;
-        ln_rows[rr] = gr < a.M ? gr : a.M - 1;
+        ln_rows[rr] = gr < Mlim ? gr : Mlim - 1;
         ln_keep[rr] = true;
         if constexpr (!HEAD) {
 #pragma unroll
@@ -233,7 +260,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         auto frag0 = [&](int s) { return s * NW + wave; };
         auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
         u32x4 wr[KS1];
-        if constexpr (!HDW) {
+        if constexpr (!HDW && !HATT) {
 #pragma unroll
             for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];   // weights first
         }
@@ -253,7 +280,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 const int id = tid + i * NT;
                 const int64_t grow = row0 - DWH + id / C8;
                 hv[i] = (u32x4){0u, 0u, 0u, 0u};
-                if (id < DWROWS * C8 && grow >= 0 && grow < a.M) hv[i] = *(const u32x4*)(a.head_a + grow * D + (id % C8) * 8);
+                if (id < DWROWS * C8 && grow >= 0 && grow < Mlim) hv[i] = *(const u32x4*)(a.head_a + grow * D + (id % C8) * 8);
             }
             const bool worker = tid < CP * RG;
             const int cp = worker ? tid % CP : 0, rg = worker ? tid / CP : 0;   // channel pair, frame group (wave-uniform: CP % 64 == 0 or idle tail)
@@ -315,16 +342,204 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                         for (int k = 0; k < DWK; ++k) acc = (f32x2){fmaf(tw[k].x, win[i + k].x, acc.x), fmaf(tw[k].y, win[i + k].y, acc.y)};
                     }
                     const f32x2 y = (f32x2){fmaf(acc.x + pb.x, ps.x, ph.x), fmaf(acc.y + pb.y, ps.y, ph.y)};   // as the scalar kernel contracts it
-                    const unsigned o = g0 + i < a.M ? pack2<HT>(siluf_(y.x), siluf_(y.y)) : 0u;
+                    const unsigned o = g0 + i < Mlim ? pack2<HT>(siluf_(y.x), siluf_(y.y)) : 0u;
                     *(unsigned*)(xn + (rg * 4 + i) * XN_STRIDE + 2 * cp) = o;
                 }
             }
+        } else if constexpr (HATT) {
+            // ================= attention input stage ==================================================================
+            // The head input IS the attention context of this tile's 32 frames (attention.py:81-96; the stand-alone kernel is
+            // attention.hip cfm_attn2_kernel): no launch of its own, no [M, D] context round trip.  16 wavefronts = 4 heads x 4 KEY
+            // QUARTERS (64 keys each, T <= 256).  Swapped MFMA roles as there: S^T[key, q] = K~ . Q~^T with the key fragment as the
+            // A operand -- loaded straight from the qkv rows in memory, one 16-byte piece per lane, and shared by BOTH 16-query fragments
+            // of the tile from registers -- and O^T[d, q] = V^T . P^T with V^T fragments read from the transposed copy the macaron
+            // chain's tail wrote (one 16-byte piece per lane).  Nothing is staged in LDS;
+            // what crosses wavefronts is the softmax: per-query maxima of the four quarters (one barrier), then the partial row
+            // sums and the four partial context tiles, added in a fixed order by all 1 024 threads while they normalise, round and
+            // write the 16-bit context tile the head GEMM reads (two more barriers).  Same arithmetic per element as cfm_attn2_kernel
+            // up to the order of the f32 sums over keys.
+            // MEASURED (config 2, 12 launches per step, profiles/r02_merged_attention.txt): 27.7 us per launch against 9.7 (cfm_attn2_kernel) +
+            // 13.1 (conv-in chain) = 22.8 us for the two launches it replaces -- SLOWER, so the encoder does not use it by default
+            // (encoder_layer.MERGE_ATTENTION).  Knock-outs: without any of the stage's global loads the launch takes 18.2 us (13.1 + ~5 of
+            // MFMA / softmax / three barriers / the partial-tile exchange); the loads add 10 us -- values 6.1, keys 3.4, mask bytes 2.3,
+            // queries 1.7 when removed one at a time -- because a 32-frame tile needs ALL FOUR heads' keys and values of its utterance (255 KB
+            // per workgroup, twice the bytes per CU of the 64-query stand-alone kernel), nothing else in the chain can run before them, and at
+            // kernel entry they come from memory, not L2 (the L2s are written back and invalidated between dependent launches).  The launch
+            // it saves is worth ~5 us; the exposed fill costs more.
+            __shared__ float att_mx[16 * RBM], att_ls[16 * RBM];
+            __shared__ __attribute__((aligned(16))) uint8_t att_mk[256];
+            const int T = a.att_T;
+            const int h = wave >> 2, kq = wave & 3;
+            if (tid < 256) {                                  // key validity of the utterance, one byte per key (read back as 4-byte words)
+                bool ok = tid < T;
+                if (ok && a.att_mask) ok = a.att_mask[(int64_t)att_b * a.att_m_sb + tid] != 0;
+                att_mk[tid] = ok ? 1 : 0;
+            }
+            const bool pos = a.att_p != nullptr;
+            u32x4 qu[2][2], qv[2][2];
+            float bd[2] = {0.f, 0.f};
+            {
+                u32x4 qraw[2][2], praw[2];
+                f32x4 bu[2][2], bv[2][2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int d0 = h * 64 + kk * 32 + g * 8;
+#pragma unroll
+                    for (int qf = 0; qf < 2; ++qf) {
+                        int qr = att_t0 + qf * 16 + l15;
+                        qr = qr < T ? qr : T - 1;
+                        qraw[qf][kk] = *(const u32x4*)(a.att_qkv + ((int64_t)att_b * T + qr) * (3 * D) + d0);
+                    }
+                    if (pos) {
+                        bu[kk][0] = *(const f32x4*)(a.att_bias_u + d0); bu[kk][1] = *(const f32x4*)(a.att_bias_u + d0 + 4);
+                        bv[kk][0] = *(const f32x4*)(a.att_bias_v + d0); bv[kk][1] = *(const f32x4*)(a.att_bias_v + d0 + 4);
+                        praw[kk] = *(const u32x4*)(a.att_p + (int64_t)att_b * a.att_p_sb + d0);
+                    }
+                }
+#pragma unroll
+                for (int qf = 0; qf < 2; ++qf)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const u32x4 raw = qraw[qf][kk];
+                        if (!pos) {
+                            qu[qf][kk] = raw;
+                            qv[qf][kk] = raw;
+                        } else {
+                            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+                            float f[8];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                f[2 * i] = HT::to_f32((u16)(w[i] & 0xffffu));
+                                f[2 * i + 1] = HT::to_f32((u16)(w[i] >> 16));
+                            }
+                            const f32x4 fa = {f[0], f[1], f[2], f[3]}, fb = {f[4], f[5], f[6], f[7]};
+                            qu[qf][kk] = pack8<HT>(fa + bu[kk][0], fb + bu[kk][1]);
+                            qv[qf][kk] = pack8<HT>(fa + bv[kk][0], fb + bv[kk][1]);
+                            // bd_i = (q_i + v) . p_b : this lane's 8 d-values of the slice (the positional term of the batch path is one value per query)
+                            const unsigned pw[4] = {praw[kk].x, praw[kk].y, praw[kk].z, praw[kk].w};
+                            const unsigned qw[4] = {qv[qf][kk].x, qv[qf][kk].y, qv[qf][kk].z, qv[qf][kk].w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                bd[qf] = fmaf(HT::to_f32((u16)(qw[i] & 0xffffu)), HT::to_f32((u16)(pw[i] & 0xffffu)), bd[qf]);
+                                bd[qf] = fmaf(HT::to_f32((u16)(qw[i] >> 16)), HT::to_f32((u16)(pw[i] >> 16)), bd[qf]);
+                            }
+                        }
+                    }
+                if (pos) {
+#pragma unroll
+                    for (int qf = 0; qf < 2; ++qf) {
+                        bd[qf] += __shfl_xor(bd[qf], 16, 64);
+                        bd[qf] += __shfl_xor(bd[qf], 32, 64);
+                    }
+                }
+            }
+            // ---- S^T for this wavefront's 64 keys x 32 queries.  Row i of key fragment f stands for key 32 (f >> 1) + 8 (i >> 2) + 4 (f & 1) + (i & 3)
+            //      of the quarter (a row permutation of the K~ loads, free): the 8 probabilities a lane packs for one 32-key MFMA step are then
+            //      8 CONSECUTIVE keys, and the matching V^T fragment is one 16-byte piece per lane.
+            f32x4 s[2][4];
+            u32x4 vf[2][4];
+            {
+                u32x4 kf[4][2];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    int key = kq * 64 + 32 * (f >> 1) + 8 * (l15 >> 2) + 4 * (f & 1) + (l15 & 3);
+                    key = key < T ? key : T - 1;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        kf[f][kk] = *(const u32x4*)(a.att_qkv + ((int64_t)att_b * T + key) * (3 * D) + D + h * 64 + kk * 32 + g * 8);
+                }
+                // V^T fragments of these keys: requested behind the keys, used after the softmax
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd)
+                        vf[k2][fd] = *(const u32x4*)(a.att_vt + ((int64_t)(att_b * 4 + h) * 64 + fd * 16 + l15) * a.att_vt_ld + kq * 64 + k2 * 32 + 8 * g);
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int qf = 0; qf < 2; ++qf) {
+                        s[qf][f] = zero4;
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) s[qf][f] = HT::mfma(kf[f][kk], qu[qf][kk], s[qf][f]);
+                    }
+            }
+            __syncthreads();                                  // the validity bytes
+            // ---- key validity, scale, the positional constant; per-query maximum of this quarter
+            unsigned okbits = 0u;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const unsigned mb = *(const unsigned*)(att_mk + kq * 64 + 32 * (f >> 1) + 8 * g + 4 * (f & 1));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) okbits |= ((mb >> (8 * r)) & 0xffu) ? 1u << (f * 4 + r) : 0u;
+            }
+            float tmax[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+            for (int qf = 0; qf < 2; ++qf) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = (okbits >> (f * 4 + r)) & 1u ? (s[qf][f][r] + bd[qf]) * a.att_scale : -INFINITY;
+                        s[qf][f][r] = x;
+                        tmax[qf] = fmaxf(tmax[qf], x);
+                    }
+                tmax[qf] = fmaxf(tmax[qf], __shfl_xor(tmax[qf], 16, 64));
+                tmax[qf] = fmaxf(tmax[qf], __shfl_xor(tmax[qf], 32, 64));
+                if (g == 0) att_mx[wave * RBM + qf * 16 + l15] = tmax[qf];
+            }
+            __syncthreads();
+            float* const opart = (float*)lds_a;
+#pragma unroll
+            for (int qf = 0; qf < 2; ++qf) {
+                const int q = qf * 16 + l15;
+                const float m = fmaxf(fmaxf(att_mx[(h * 4 + 0) * RBM + q], att_mx[(h * 4 + 1) * RBM + q]),
+                                      fmaxf(att_mx[(h * 4 + 2) * RBM + q], att_mx[(h * 4 + 3) * RBM + q]));
+                float psum = 0.f;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = (m == -INFINITY) ? 0.f : __expf(s[qf][f][r] - m);
+                        s[qf][f][r] = pv;
+                        psum += pv;
+                    }
+                psum += __shfl_xor(psum, 16, 64);
+                psum += __shfl_xor(psum, 32, 64);
+                if (g == 0) att_ls[wave * RBM + q] = psum;
+                // ---- O^T partial of this quarter
+                f32x4 acc_o[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const u32x4 ph = pack8<HT>(s[qf][2 * k2], s[qf][2 * k2 + 1]);
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd) acc_o[fd] = HT::mfma(vf[k2][fd], ph, acc_o[fd]);
+                }
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) *(f32x4*)(opart + (kq * RBM + q) * XS_STRIDE + h * 64 + fd * 16 + 4 * g) = acc_o[fd];
+            }
+            __syncthreads();
+            {   // all threads: context[r][c8 .. c8+7] = (sum of the four quarters) / l, rounded to the operand type, into the head GEMM's input tile
+                const int r = tid >> 5, c8 = (tid & 31) * 8, hh = c8 >> 6;
+                const float l_tot = (att_ls[(hh * 4 + 0) * RBM + r] + att_ls[(hh * 4 + 1) * RBM + r]) +
+                                    (att_ls[(hh * 4 + 2) * RBM + r] + att_ls[(hh * 4 + 3) * RBM + r]);
+                const float inv = l_tot > 0.f ? __builtin_amdgcn_rcpf(l_tot) : 0.f;
+                f32x4 o0, o1;
+                {
+                    const float* p0 = opart + r * XS_STRIDE + c8;
+                    constexpr int QS = RBM * XS_STRIDE;
+                    o0 = (*(const f32x4*)p0 + *(const f32x4*)(p0 + QS)) + (*(const f32x4*)(p0 + 2 * QS) + *(const f32x4*)(p0 + 3 * QS));
+                    o1 = (*(const f32x4*)(p0 + 4) + *(const f32x4*)(p0 + QS + 4)) + (*(const f32x4*)(p0 + 2 * QS + 4) + *(const f32x4*)(p0 + 3 * QS + 4));
+                }
+                *(u32x4*)(xn + r * XN_STRIDE + c8) = pack8<HT>(o0 * inv, o1 * inv);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];   // (earlier, they spill: 128 VGPRs)
         } else {
             // stage the 16-bit input tile (rows clamped), zero-padded to KP columns
             for (int id = tid; id < RBM * CPRW; id += NT) {
                 const int r = id / CPRW, c = id % CPRW;
                 int64_t grow = row0 + r;
-                grow = grow < a.M ? grow : a.M - 1;
+                grow = grow < Mlim ? grow : Mlim - 1;
                 const u32x4 v = c * 8 < D ? *(const u32x4*)(a.head_a + grow * D + c * 8) : (u32x4){0u, 0u, 0u, 0u};
                 *(u32x4*)(xn + r * XN_STRIDE + c * 8) = v;
             }
@@ -348,7 +563,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int64_t gr = row0 + mf * 16 + l15;
-                grows[mf] = gr < a.M ? gr : a.M - 1;
+                grows[mf] = gr < Mlim ? gr : Mlim - 1;
                 keep[mf] = true;
                 rs[mf] = *(const f32x4*)(a.head_res + grows[mf] * D + col);
             }
@@ -428,7 +643,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
                     for (int it = 0; it < VPL; ++it) {
                         const int c = (lane + 64 * it) * 4;
-                        if (c < D && row0 + wave * RPW + rr < a.M) *(f32x4*)(a.out_f32 + (row0 + wave * RPW + rr) * D + c) = xres[rr][it];
+                        if (c < D && row0 + wave * RPW + rr < Mlim) *(f32x4*)(a.out_f32 + (row0 + wave * RPW + rr) * D + c) = xres[rr][it];
                     }
             }
         }
@@ -600,7 +815,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 for (int it = 0; it < VPL; ++it) {
                     const int c = (lane + 64 * it) * 4;
                     const int64_t grow = row0 + wave * RPW + rr;
-                    if (c < D && grow < a.M) *(f32x4*)(a.out_f32 + grow * D + c) = v[rr][it];
+                    if (c < D && grow < Mlim) *(f32x4*)(a.out_f32 + grow * D + c) = v[rr][it];
                 }
         }
         if (a.ln2_g) {
@@ -616,8 +831,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                         const f32x4 o = c < D ? v[rr][it] : zero4;
                         const u32x2 pk = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
                         if constexpr (TAIL) *(u32x2*)(xn + r * XN_STRIDE + c) = pk;   // the tail's input tile
-                        if (c < D && grow < a.M && a.out16) *(u32x2*)((u16*)a.out16 + grow * D + c) = pk;
-                        if (c < D && grow < a.M && a.out2_f32) *(f32x4*)(a.out2_f32 + grow * D + c) = o;
+                        if (c < D && grow < Mlim && a.out16) *(u32x2*)((u16*)a.out16 + grow * D + c) = pk;
+                        if (c < D && grow < Mlim && a.out2_f32) *(f32x4*)(a.out2_f32 + grow * D + c) = o;
                     }
                 }
         }
@@ -644,7 +859,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int64_t grow = row0 + mf * 16 + l15;
-                if (grow >= a.M) continue;
+                if (grow >= Mlim) continue;
                 if constexpr (TGLU) {
                     if (f + 1 < t_nfrags) {                   // (value, gate) fragment pairs: tail_N % 32 == 0
                         f32x4 v0 = acc[mf][0] + bb[0];
@@ -657,8 +872,18 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 } else {
                     if (f < t_nfrags) {
                         const f32x4 v0 = acc[mf][0] + bb[0];
-                        const int64_t o = grow * ldo + f * 16 + 4 * g;
-                        *(u32x2*)((u16*)a.tail_out + o) = (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)};
+                        if (TVT && f * 16 >= 2 * D) {             // wave-uniform: a value fragment goes out transposed per head
+                            const int bb_ = (int)(grow / a.vt_T), t = (int)(grow - (int64_t)bb_ * a.vt_T);
+                            const int c = f * 16 + 4 * g - 2 * D;  // head (c >> 6), d = c & 63 .. + 3
+                            u16* vp = a.tail_vt + ((int64_t)bb_ * D + c) * a.vt_ld + t;
+                            vp[0] = HT::from_f32(v0.x);
+                            vp[a.vt_ld] = HT::from_f32(v0.y);
+                            vp[2 * (int64_t)a.vt_ld] = HT::from_f32(v0.z);
+                            vp[3 * (int64_t)a.vt_ld] = HT::from_f32(v0.w);
+                        } else {
+                            const int64_t o = grow * ldo + f * 16 + 4 * g;
+                            *(u32x2*)((u16*)a.tail_out + o) = (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)};
+                        }
                     }
                 }
             }
@@ -667,11 +892,12 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     CFM_STAMP(7);
 }
 
-template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU>
+template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU, bool HATT = false, bool TVT = false>
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
-    const unsigned grid = (unsigned)((a.M + RBM - 1) / RBM);
+    // HATT: tiles do not cross utterances (B x ceil(T / 32) workgroups)
+    const unsigned grid = HATT ? (unsigned)((((a.M / a.att_T) + 7) / 8) * 8 * ((a.att_T + RBM - 1) / RBM)) : (unsigned)((a.M + RBM - 1) / RBM);
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU>), dim3(grid), dim3(NT), 0, s, a);
+    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU, HATT, TVT>), dim3(grid), dim3(NT), 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -681,7 +907,14 @@ extern "C" int cfm_rowchain_supported(int32_t D, int32_t FF) { return (D == 256 
 
 extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d, "cfm_rowchain: null descriptor");
-    const bool head = d->head_a != nullptr, mid = d->w1f != nullptr, tail = d->tail_w != nullptr, dw = d->dw_w != nullptr;
+    const bool att = d->att_qkv != nullptr, tvt = d->tail_vt != nullptr;
+    const bool head = d->head_a != nullptr || att, mid = d->w1f != nullptr, tail = d->tail_w != nullptr, dw = d->dw_w != nullptr;
+    CFM_CHECK_ARG(!att || (!d->head_a && !mid && tail && d->tail_glu && !dw && d->D == 256 && d->att_H == 4 && d->att_vt && d->att_T > 0 && d->att_T <= 256 &&
+                           d->M % d->att_T == 0 && d->att_vt_ld >= 256 && d->att_vt_ld % 4 == 0 && (!d->att_p || (d->att_bias_u && d->att_bias_v))),
+                  "cfm_rowchain: the attention input stage needs the conv-in chain at D = 256 with 4 heads, T <= 256, M %% T == 0, transposed values with "
+                  "a row stride >= 256 (multiple of 4) and, with positions, both biases");
+    CFM_CHECK_ARG(!tvt || (tail && !d->tail_glu && d->D == 256 && d->tail_N == 768 && d->vt_T > 0 && d->M % d->vt_T == 0 && d->vt_ld >= d->vt_T),
+                  "cfm_rowchain: transposed values need the fused-QKV tail at D = 256, M %% vt_T == 0 and vt_ld >= vt_T");
     CFM_CHECK_ARG(!dw || (head && mid && !tail && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
                   "cfm_rowchain: the depthwise input stage needs a head + feed-forward chain, bias/scale/shift, 15 taps and M %% dw_T == 0");
     CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256), "cfm_rowchain: D=%d has no instance (144, 256)", d->D);
@@ -699,6 +932,10 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     a.b1 = d->b1; a.b2 = d->b2; a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32;
     a.out16 = d->out16; a.out2_f32 = d->out2_f32; a.tail_w = (const u16*)d->tail_w; a.tail_b = d->tail_b; a.tail_out = d->tail_out; a.M = d->M;
     a.tail_N = d->tail_N; a.out16_dtype = d->w_dtype; a.alpha = d->alpha; a.eps = d->eps;
+    a.tail_vt = (u16*)d->tail_vt; a.vt_T = d->vt_T; a.vt_ld = d->vt_ld;
+    a.att_qkv = (const u16*)d->att_qkv; a.att_vt = (const u16*)d->att_vt; a.att_p = (const u16*)d->att_p; a.att_bias_u = d->att_bias_u;
+    a.att_bias_v = d->att_bias_v; a.att_mask = d->att_mask; a.att_p_sb = d->att_p_sb; a.att_m_sb = d->att_m_sb; a.att_T = d->att_T;
+    a.att_vt_ld = d->att_vt_ld; a.att_scale = d->att_scale;
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->w_dtype == CFM_BF16;
     const int tfrags = tail ? d->tail_N / 16 : 0;
@@ -706,11 +943,14 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     const double M = (double)d->M;
     const double fl_head = head ? 2.0 * M * d->D * d->D : 0.0, fl_mid = mid ? 4.0 * M * d->D * d->FF : 0.0,
                  fl_tail = tail ? 2.0 * M * d->D * d->tail_N : 0.0;
-    const double fl = fl_head + fl_mid + fl_tail + (dw ? 2.0 * M * d->D * 15 : 0.0);
+    const double fl = fl_head + fl_mid + fl_tail + (dw ? 2.0 * M * d->D * 15 : 0.0) + (att ? 4.0 * M * d->att_T * d->D : 0.0);
 #define CFM_RC(HT, DD, FFV, HS, MIDV, TS, GLU, NAME) return launch_chain<HT, DD, FFV, HS, false, MIDV, TS, GLU>(a, s, NAME, fl)
 #define CFM_RCDW(HT, DD, FFV, NAME) return launch_chain<HT, DD, FFV, 1, true, true, 0, false>(a, s, NAME, fl)
     // the three roles of a conformer block (+ a bare QKV projection and a bare LayerNorm), for D = 256 (ff 2048) and D = 144 (ff 576)
     if (d->D == 256 && (!mid || d->FF == 2048)) {
+        if (att) { if (bf) return launch_chain<BF16, 256, 64, 1, false, false, 1, true, true, false>(a, s, "chain_attconvin_bf16_d256", fl); else return launch_chain<F16, 256, 64, 1, false, false, 1, true, true, false>(a, s, "chain_attconvin_f16_d256", fl); }
+        if (tvt && !head && mid && tsteps == 3) { if (bf) return launch_chain<BF16, 256, 2048, 0, false, true, 3, false, false, true>(a, s, "chain_macaron_vt_bf16_d256", fl); else return launch_chain<F16, 256, 2048, 0, false, true, 3, false, false, true>(a, s, "chain_macaron_vt_f16_d256", fl); }
+        if (tvt) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: transposed values only on the macaron chain");
         if (!head && mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 2048, 0, true, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 2048, 0, true, 3, false, "chain_macaron_f16_d256"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 1) { if (bf) CFM_RC(BF16, 256, 64, 1, false, 1, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 64, 1, false, 1, true, "chain_convin_f16_d256"); }
         if (head && mid && !tail && dw) { if (bf) CFM_RCDW(BF16, 256, 2048, "chain_dwfinal_bf16_d256"); else CFM_RCDW(F16, 256, 2048, "chain_dwfinal_f16_d256"); }

@@ -22,6 +22,8 @@ from convolution import ConvolutionModule
 from feedforward import PositionwiseFeedForwardModule, _inference_only
 
 _ABSENT = torch.ones((0, 0, 0), dtype=torch.bool)
+MERGE_ATTENTION = False    # attention as the input stage of the conv-in chain (3 launches per block instead of 4): built, parity-tested and
+                           # measured SLOWER at config 2 (27.7 us vs 9.7 + 13.1 us, rowchain.hip) -- opt-in
 
 
 class ConformerEncoderLayer(nn.Module):
@@ -111,6 +113,9 @@ class ConformerEncoderLayer(nn.Module):
         s.ctx = cfm.scratch("ctx", M * D, adt, dev).data_ptr()
         s.glu = cfm.scratch("glu", M * D, adt, dev).data_ptr()
         s.dw = cfm.scratch("dw", M * D, adt, dev).data_ptr()
+        if MERGE_ATTENTION and D == 256 and H == 4 and T <= 256 and adt != torch.float32:
+            # transposed values for the attention stage of the conv-in chain (cfm.h cfm_layer_scratch.vt); key columns past T are read, never written
+            s.vt, s.vt_ld = cfm.scratch("vt", B * D * 256, adt, dev, zero=True).data_ptr(), 256
         io = cfm.LayerIO()
         io.B, io.T, io.D, io.H, io.FF, io.ktaps = B, T, D, H, FF, self.kernel_size
         io.act_dtype, io.w_dtype = prec.act_code, prec.w_code

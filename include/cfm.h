@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFM_VERSION 200 /* 0.2.0: training entry points; the partial-FFN experiment and the W_frag GEMM variant left the ABI */
+#define CFM_VERSION 201 /* 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
 
 typedef void* cfm_stream_t;
 
@@ -223,6 +223,23 @@ typedef struct {
      * utterance edges -- exactly cfm_dwconv_bn_silu (convolution.py:43-45) without its launch and its round trip. */
     const float *dw_w, *dw_b, *dw_scale, *dw_shift;
     int32_t dw_T, dw_K;
+    /* optional, macaron chain with the fused-QKV tail at D = 256 (4 heads x 64): the value columns [2D, 3D) of row (b, t) are written
+     * transposed per head, tail_vt[((b*H + h)*64 + d) * vt_ld + t] (16 bit), INSTEAD of into tail_out -- the layout the attention stage
+     * below reads as MFMA fragments.  vt_T frames per utterance (M % vt_T == 0), vt_ld >= vt_T elements per row. */
+    void* tail_vt;
+    int32_t vt_T, vt_ld;
+    /* optional attention input stage of the conv-in chain (head_a NULL, att_qkv set): the head input is the self-attention context of the
+     * tile's 32 frames, computed in the same launch (attention.py:81-96 batch path: no cache, key-validity mask, one positional row per
+     * item) -- replaces a cfm_attention launch and the [M, D] context round trip.  Tiles do not cross utterances: B * ceil(T/32)
+     * workgroups.  att_qkv [B*T, 3D] rows q | k | -, att_vt the transposed values above (key columns >= T must hold finite numbers:
+     * zero-fill the buffer once), att_p one projected positional row per item (stride att_p_sb elements, 0 = shared) or NULL for plain
+     * MHSA, att_mask key validity bytes [B, >= T] (stride att_m_sb) or NULL.  D = 256, att_H = 4, att_T <= 256. */
+    const void *att_qkv, *att_vt, *att_p;
+    const float *att_bias_u, *att_bias_v;
+    const uint8_t* att_mask;
+    int64_t att_p_sb, att_m_sb;
+    int32_t att_T, att_H, att_vt_ld;
+    float att_scale;
 } cfm_rowchain_desc;
 
 int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
@@ -384,6 +401,9 @@ typedef struct {
 
 typedef struct {
     void *xn, *hid, *qkv, *pos, *ctx, *glu, *dw; /* activation-dtype scratch: [M,D],[M,FF],[M,3D],[R,D],[M,D],[M,D],[M,D] */
+    void* vt;      /* optional [B, D, vt_ld] activation-dtype, ZERO-FILLED ONCE by the caller: transposed values for the attention stage of the
+                      conv-in chain (cfm_rowchain_desc.att_*); NULL: attention runs as its own launch */
+    int32_t vt_ld; /* elements per row of vt: >= 256, multiple of 4 */
 } cfm_layer_scratch;
 
 typedef struct {

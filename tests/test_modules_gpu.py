@@ -803,6 +803,36 @@ def test_general_path_matches_chain_path_including_after_norm(pkg):
     assert relerr(y_general, y_chain) > 0                           # ... and it really was another path
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("relative", [True, False])
+def test_attention_inside_conv_in_chain_matches_separate_launches(pkg, mode, relative):
+    """Blocks at the config-2 width can run attention as the input stage of the conv-in chain (3 launches per block, rowchain.hip HATT; opt-in
+    because it measured slower); with encoder_layer.MERGE_ATTENTION off the same weights take the stand-alone attention kernel (4 launches).  Per element the arithmetic is
+    the same up to the order of the f32 sums over keys (4 key quarters instead of one pass): agreement far inside the mode's gate
+    against the oracle, on ragged lengths (masked keys, fully padded tile rows, a last tile of 13 frames) and with plain MHSA."""
+    from oracle import conformer_oracle as O
+    pkg.cfm.set_precision(mode)
+    cfg = CFG2 | dict(encoder_num_layers=3, use_relative=relative)
+    enc = build_encoder(pkg, cfg, 91)
+    x = dev(synth.fbank(92, 5, 700))                                 # T' = 174 = 5 tiles of 32 + 14
+    lens = torch.tensor([700, 655, 402, 260, 131], dtype=torch.int32, device=DEV)
+    try:
+        with torch.no_grad():
+            pkg.encoder_layer.MERGE_ATTENTION = True
+            y3, m3 = enc(x, lens)
+            pkg.encoder_layer.MERGE_ATTENTION = False
+            y4, m4 = enc(x, lens)
+    finally:
+        pkg.encoder_layer.MERGE_ATTENTION = False
+    assert torch.equal(m3, m4) and torch.isfinite(y3).all()
+    e = relerr(y3, y4)
+    print("  [%s] merged vs separate attention (relative=%s): %.3e" % (mode, relative, e))
+    assert 0 < e < TOL[mode] * 0.25, e                               # another path (not bit-identical), and close
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    y_ref, _ = O.encoder_forward(P, O.Config(**cfg), x.cpu(), lens.tolist())
+    check("merged attention vs oracle (relative=%s)" % relative, y3, y_ref, mode)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_chunked_attention_masks_d256_against_oracle(pkg, mode):
     """Chunk masks (B,T',T') at the config-2 width: dynamic chunk 8 with 3 left chunks, full context, and a static chunk size, ragged
