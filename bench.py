@@ -196,7 +196,7 @@ def selftest_cpu(args):
         dist.destroy_process_group()
 
 
-KERNEL_SYMBOL = {"chain_macaron": "cfm_rowchain_kernel", "chain_dwfinal": "cfm_rowchain_kernel", "chain_final": "cfm_rowchain_kernel", "chain_convin": "cfm_rowchain_kernel",
+KERNEL_SYMBOL = {"chain_dwfinal_macaron": "cfm_rowchain_kernel", "chain_macaron": "cfm_rowchain_kernel", "chain_dwfinal": "cfm_rowchain_kernel", "chain_final": "cfm_rowchain_kernel", "chain_convin": "cfm_rowchain_kernel",
                  "chain_qkv": "cfm_rowchain_kernel", "ffn_fused": "cfm_ffn_kernel", "ffn_partial": "cfm_ffnpart_kernel",
                  "gemm_conv": "cfm_gemm_kernel", "gemm": "cfm_gemm_kernel", "attn2": "cfm_attn2_kernel", "attn": "cfm_attn_kernel"}
 
@@ -210,8 +210,8 @@ def measured_traffic(kernel_name, d_model):
         return None
     kernels = json.load(open(files[-1]))["kernels"]
     # template arguments after <type, D, FF,: head steps, depthwise input stage, feed-forward, tail steps, GLU
-    role = {"chain_macaron": "0, false, true, 3, false", "chain_dwfinal": "1, true, true, 0, false", "chain_final": "1, false, true, 0, false",
-            "chain_convin": "1, false, false, 1, true"}
+    role = {"chain_dwfinal_macaron": "1, true, true, 3, false, false, false, true", "chain_macaron": "0, false, true, 3, false",
+            "chain_dwfinal": "1, true, true, 0, false", "chain_final": "1, false, true, 0, false", "chain_convin": "1, false, false, 1, true"}
     for prefix, sym in KERNEL_SYMBOL.items():
         if kernel_name.startswith(prefix):
             want = role.get(prefix)
@@ -382,6 +382,8 @@ def main():
                 # vector-memory path, 64 B/clk/CU at the 2.4 GHz the MFMA peak is quoted at
                 D, FF = CFG2["encoder_dim"], CFG2["hidden_dim"]
                 wbytes = 2 * (2 * D * FF + (3 * D * D if name.startswith("chain_macaron") else D * D))
+                if name.startswith("chain_dwfinal_macaron"):     # two feed-forwards + pointwise-conv-2 + the fused QKV projection
+                    wbytes = 2 * (4 * D * FF + D * D + 3 * D * D)
                 floor_us = wbytes / 64.0 / 2.4e9 * 1e6
                 roofline["weight_stream"] = {"bytes_per_cu_per_launch": wbytes, "path_peak": "64 B/clk/CU", "floor_us": round(floor_us, 2),
                                              "frac": round(floor_us / (avg_ms * 1e3), 4)}

@@ -81,7 +81,9 @@ class RowChainDesc(ctypes.Structure):
                 ("out2_f32", c_p), ("dw_w", c_p), ("dw_b", c_p), ("dw_scale", c_p), ("dw_shift", c_p), ("dw_T", c_i32), ("dw_K", c_i32),
                 ("tail_vt", c_p), ("vt_T", c_i32), ("vt_ld", c_i32),
                 ("att_qkv", c_p), ("att_vt", c_p), ("att_p", c_p), ("att_bias_u", c_p), ("att_bias_v", c_p), ("att_mask", c_p),
-                ("att_p_sb", c_i64), ("att_m_sb", c_i64), ("att_T", c_i32), ("att_H", c_i32), ("att_vt_ld", c_i32), ("att_scale", ctypes.c_float)]
+                ("att_p_sb", c_i64), ("att_m_sb", c_i64), ("att_T", c_i32), ("att_H", c_i32), ("att_vt_ld", c_i32), ("att_scale", ctypes.c_float),
+                ("s2_ln_g", c_p), ("s2_ln_b", c_p), ("s2_w1f", c_p), ("s2_w2n", c_p), ("s2_b1", c_p), ("s2_b2", c_p), ("s2_out_f32", c_p),
+                ("s2_alpha", ctypes.c_float)]
 
 
 _LAYER_W_FIELDS = [
@@ -145,7 +147,8 @@ class LayerIO(ctypes.Structure):
                 ("pad_valid", c_p), ("pos_embed", c_p), ("pos_rows", c_i32),
                 ("pos_proj", c_p), ("pos_proj_ld", c_i64),
                 ("attn_cache", c_p), ("cache_T", c_i32), ("new_cache", c_p), ("after_g", c_p), ("after_b", c_p), ("after_out", c_p),
-                ("kv_ring", c_p), ("stream_offset", c_p), ("ring_T", c_i32), ("causal_conv", c_i32), ("conv_cache", c_p), ("pos_shared", c_i32)]
+                ("kv_ring", c_p), ("stream_offset", c_p), ("ring_T", c_i32), ("causal_conv", c_i32), ("conv_cache", c_p), ("pos_shared", c_i32),
+                ("next_w", c_p), ("next_x_out", c_p), ("macaron_done", c_i32)]
 
 
 _lib = None

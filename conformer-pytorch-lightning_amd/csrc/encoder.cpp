@@ -91,8 +91,9 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     // 3-launch path: the attention runs as the input stage of the conv-in chain (batch path only: no cache / ring, key-validity mask, at most
     // one positional row per item, T <= 256, 4 heads x 64) on values the macaron chain's tail wrote transposed
     const bool merged = chains && s->vt && s->vt_ld >= 256 && s->vt_ld % 4 == 0 && D == 256 && H == 4 && !ring && Tc == 0 && !io->new_cache &&
-                        io->T <= 256 && (!has_pos || P == 1) && (!io->attn_mask || io->am_sq == 0);
-    if (chains) {
+                        io->T <= 256 && (!has_pos || P == 1) && (!io->attn_mask || io->am_sq == 0) && !io->macaron_done && !io->next_w;
+    CFM_CHECK_ARG(!io->macaron_done || chains, "encoder layer: macaron_done needs the chain path");
+    if (chains && !io->macaron_done) {
         cfm_rowchain_desc m = {};
         if (merged) { m.tail_vt = s->vt; m.vt_T = io->T; m.vt_ld = s->vt_ld; }
         m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2n = w->ffm_w2n; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
@@ -190,6 +191,17 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         fi.ln1_g = w->ln_final_g; fi.ln1_b = w->ln_final_b; fi.out_f32 = x_out;
         if (io->after_out) { fi.ln2_g = io->after_g; fi.ln2_b = io->after_b; fi.out2_f32 = io->after_out; }   // encoder.py:74 in the same launch
         fi.M = M; fi.D = D; fi.FF = FF; fi.w_dtype = c.w_dt; fi.alpha = 0.5f; fi.eps = eps;
+        if (io->next_w) {
+            // ... and the next block's macaron chain on the same rows, in the same launch (cfm.h cfm_layer_io.next_w)
+            const cfm_layer_weights* nw = io->next_w;
+            CFM_CHECK_ARG(dw_fused && !io->after_out && io->next_x_out && io->next_x_out != x_out && nw->ffm_w1f && nw->ffm_w2n && nw->qkv_wf && D == 256 && FF == 2048,
+                          "encoder layer: chaining into the next block needs the fused depthwise stage, no after_out, a distinct next_x_out and the next "
+                          "block's fragment-major packs (D = 256, FF = 2048)");
+            fi.out_f32 = nullptr;
+            fi.s2_ln_g = nw->ln_ffm_g; fi.s2_ln_b = nw->ln_ffm_b; fi.s2_w1f = nw->ffm_w1f; fi.s2_w2n = nw->ffm_w2n; fi.s2_b1 = nw->ffm_b1; fi.s2_b2 = nw->ffm_b2;
+            fi.s2_out_f32 = io->next_x_out; fi.s2_alpha = 0.5f;
+            fi.ln2_g = nw->ln_mha_g; fi.ln2_b = nw->ln_mha_b; fi.tail_w = nw->qkv_wf; fi.tail_b = nw->qkv_b; fi.tail_out = s->qkv; fi.tail_N = 3 * D; fi.tail_glu = 0;
+        }
         return cfm_rowchain(&fi, stream);
     }
     CFM_TRY(gemm(c, s->ctx, adt, D, w->out_w, w->out_w_lo, w->out_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, nullptr));

@@ -81,6 +81,13 @@ struct ChainArgs {
     int64_t att_p_sb, att_m_sb;
     int att_T, att_vt_ld;
     float att_scale;
+    // SEG2: a SECOND feed-forward segment on the same rows, in registers: after LN1 of the first (out_f32 optional then), LayerNorm
+    // (s2_ln) -> feed-forward (s2_*) -> + residual -> s2_out_f32; the second LayerNorm (ln2) and the tail then follow THIS segment.
+    const float *s2_ln_g, *s2_ln_b;
+    const u16 *s2_w1f, *s2_w2n;
+    const float *s2_b1, *s2_b2;
+    float* s2_out_f32;
+    float s2_alpha;
 };
 
 // Phase stamps for scripts/probe_chain.hip (built with -DCFM_CHAIN_STAMPS; never defined in the product build): thread 0 of each
@@ -163,9 +170,11 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
             if ((lane + 64 * it) * 4 < D) v[rr][it] = (v[rr][it] - mean[rr]) * rstd[rr] * gam[it] + bet[it];
 }
 
-template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU, bool HATT = false, bool TVT = false>
+template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false>
 __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr bool HEAD = HSTEPS > 0, TAIL = TSTEPS > 0;
+    constexpr int NSEG = SEG2 ? 2 : 1;
+    static_assert(!SEG2 || MID, "a second segment is a second feed-forward");
     static_assert(!HATT || (HEAD && !HDW && !MID && D == 256), "the attention input stage: conv-in chain, 4 heads x 64");
     static_assert(!TVT || (TAIL && !TGLU && D == 256), "transposed values: a fused-QKV tail with 64-wide heads");
     constexpr int DWK = 15, DWH = (DWK - 1) / 2, DWROWS = RBM + DWK - 1;     // depthwise taps, halo, rows of the halo tile
@@ -602,6 +611,11 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     const int np = wave & 7, kh = wave >> 3;
     const u32x4* w1p = (const u32x4*)a.w1f + lane;
     const u32x4* w2p = (const u32x4*)a.w2n + lane;
+    const float *seg_b1 = a.b1, *seg_b2 = a.b2, *seg_ln1_g = a.ln1_g, *seg_ln1_b = a.ln1_b;
+    float* seg_out = a.out_f32;
+    float seg_alpha = a.alpha;
+    f32x4 vcur[RPW][VPL];                                  // SEG2: the rows between the segments
+    f32x4 nx_g[VPL], nx_b[VPL];                            // SEG2: the second segment's input-norm parameters, requested during the first
     u32x4 ring[RING];
     auto pair_of = [&](int i) { const int q = i * NW + wave; return q < NPAIR1 ? q : NPAIR1 - 1; };
     auto frag_ptr = [&](int pos) {
@@ -616,6 +630,18 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     auto refill = [&](int pos) {
         if (pos + RING < NPOS) ring[pos % RING] = *frag_ptr(pos + RING);
     };
+    // parameters of the post norms: requested during the FFN, used after it
+    f32x4 pn_b2[VPL], pn_g1[VPL], pn_b1[VPL], pn_g2[VPL], pn_be2[VPL];
+    f32x4 v[RPW][VPL];                                     // the rows after the feed-forward (+ LN1)
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {     // unrolled: with a run-time segment index the pointer selects spill (127 VGPRs, 173 SGPRs)
+    const bool last_seg = sg == NSEG - 1;
+    if constexpr (SEG2) {
+        if (sg == 1) {
+            w1p = (const u32x4*)a.s2_w1f + lane; w2p = (const u32x4*)a.s2_w2n + lane;
+            seg_b1 = a.s2_b1; seg_b2 = a.s2_b2; seg_ln1_g = nullptr; seg_ln1_b = nullptr; seg_out = a.s2_out_f32; seg_alpha = a.s2_alpha;
+        }
+    }
     if constexpr (MID) {
 #pragma unroll
         for (int t = 0; t < RING; ++t)
@@ -623,7 +649,29 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     }
 
     // ================= rows -> LN_in -> xn ======================================================================
-    {
+    if (SEG2 && sg == 1) {
+        // second segment: the rows are in registers (vcur), no mask
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) xres[rr][it] = vcur[rr][it];
+        f32x4 w[RPW][VPL];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) w[rr][it] = xres[rr][it];
+        rows_layernorm<RPW, VPL, D>(w, nx_g, nx_b, a.eps, lane);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                if (c < KP) {
+                    const f32x4 o = c < D ? w[rr][it] : zero4;
+                    *(u32x2*)(xn + (wave * RPW + rr) * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
+                }
+            }
+    } else {
         int64_t (&grows)[RPW] = ln_rows;
         f32x4 (&gam)[VPL] = ln_gam, (&bet)[VPL] = ln_bet;
         bool (&keep)[RPW] = ln_keep;
@@ -647,28 +695,25 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                     }
             }
         }
-        f32x4 v[RPW][VPL];
+        f32x4 w[RPW][VPL];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-            for (int it = 0; it < VPL; ++it) v[rr][it] = xres[rr][it];
-        if (a.ln_g) rows_layernorm<RPW, VPL, D>(v, gam, bet, a.eps, lane);
+            for (int it = 0; it < VPL; ++it) w[rr][it] = xres[rr][it];
+        if (a.ln_g) rows_layernorm<RPW, VPL, D>(w, gam, bet, a.eps, lane);
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
                 if (c < KP) {
-                    const f32x4 o = (c < D && keep[rr]) ? v[rr][it] : zero4;
+                    const f32x4 o = (c < D && keep[rr]) ? w[rr][it] : zero4;
                     *(u32x2*)(xn + (wave * RPW + rr) * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
                 }
             }
     }
     __syncthreads();                                       // xn complete; every read of the x tile in region A is done
     CFM_STAMP(3);
-
-    // parameters of the post norms: requested during the FFN, used after it
-    f32x4 pn_b2[VPL], pn_g1[VPL], pn_b1[VPL], pn_g2[VPL], pn_be2[VPL];
 
     // ================= MID: feed-forward in two phases around the hidden tile ====================================
     if constexpr (MID) {
@@ -678,8 +723,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             const int q = i * NW + wave;
             const bool valid = NPAIR1 % NW == 0 ? true : q < NPAIR1;
             const int qc = pair_of(i);
-            const f32x4 bb0 = *(const f32x4*)(a.b1 + (2 * qc) * 16 + 4 * g);      // used after this pair's MFMAs
-            const f32x4 bb1 = *(const f32x4*)(a.b1 + (2 * qc + 1) * 16 + 4 * g);
+            const f32x4 bb0 = *(const f32x4*)(seg_b1 + (2 * qc) * 16 + 4 * g);      // used after this pair's MFMAs
+            const f32x4 bb1 = *(const f32x4*)(seg_b1 + (2 * qc + 1) * 16 + 4 * g);
             auto xfrag = [&](int mf, int kk) { return *(const u32x4*)(xn + (mf * 16 + l15) * XN_STRIDE + kk * 32 + 8 * g); };
             f32x4 acc1[MF][2];
             u32x4 xf[2][MF];
@@ -753,17 +798,27 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
         for (int it = 0; it < VPL; ++it) {
             const int c = (lane + 64 * it) * 4;
-            pn_b2[it] = c < D ? *(const f32x4*)(a.b2 + c) : zero4;
+            pn_b2[it] = c < D ? *(const f32x4*)(seg_b2 + c) : zero4;
         }
-        if (a.ln1_g) {
+        if (seg_ln1_g) {
 #pragma unroll
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
-                pn_g1[it] = c < D ? *(const f32x4*)(a.ln1_g + c) : zero4;
-                pn_b1[it] = c < D ? *(const f32x4*)(a.ln1_b + c) : zero4;
+                pn_g1[it] = c < D ? *(const f32x4*)(seg_ln1_g + c) : zero4;
+                pn_b1[it] = c < D ? *(const f32x4*)(seg_ln1_b + c) : zero4;
             }
         }
-        if (a.ln2_g) {
+        if constexpr (SEG2) {
+            if (sg == 0) {
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    nx_g[it] = c < D ? *(const f32x4*)(a.s2_ln_g + c) : zero4;
+                    nx_b[it] = c < D ? *(const f32x4*)(a.s2_ln_b + c) : zero4;
+                }
+            }
+        }
+        if (a.ln2_g && last_seg) {
 #pragma unroll
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
@@ -771,7 +826,9 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 pn_be2[it] = c < D ? *(const f32x4*)(a.ln2_b + c) : zero4;
             }
         }
-        if constexpr (TAIL) tail_prefetch();
+        if constexpr (TAIL) {
+            if (last_seg) tail_prefetch();
+        }
         __syncthreads();                                   // every wavefront is done reading the hidden tile
         // the two K halves meet in the f32 y tile (region A again), fixed order: half 0 stores, half 1 adds
         auto ytile = [&](int mf, int nf) { return xs + (mf * 16 + l15) * XS_STRIDE + (2 * np + nf) * 16 + 4 * g; };
@@ -796,7 +853,6 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 
     // ================= post norms: y1 -> out_f32, y2 -> out16 / next LDS tile =====================================
     if constexpr (MID) {
-        f32x4 v[RPW][VPL];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
@@ -804,19 +860,28 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
                 v[rr][it] = zero4;
-                if (c < D) v[rr][it] = a.alpha * (*(const f32x4*)(xs + r * XS_STRIDE + c) + pn_b2[it]) + xres[rr][it];
+                if (c < D) v[rr][it] = seg_alpha * (*(const f32x4*)(xs + r * XS_STRIDE + c) + pn_b2[it]) + xres[rr][it];
             }
         }
-        if (a.ln1_g) rows_layernorm<RPW, VPL, D>(v, pn_g1, pn_b1, a.eps, lane);
-        if (a.out_f32) {
+        if (seg_ln1_g) rows_layernorm<RPW, VPL, D>(v, pn_g1, pn_b1, a.eps, lane);
+        if (seg_out) {
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
                 for (int it = 0; it < VPL; ++it) {
                     const int c = (lane + 64 * it) * 4;
                     const int64_t grow = row0 + wave * RPW + rr;
-                    if (c < D && grow < Mlim) *(f32x4*)(a.out_f32 + grow * D + c) = v[rr][it];
+                    if (c < D && grow < Mlim) *(f32x4*)(seg_out + grow * D + c) = v[rr][it];
                 }
+        }
+        if constexpr (SEG2) {
+            if (!last_seg) {
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                    for (int it = 0; it < VPL; ++it) vcur[rr][it] = v[rr][it];
+                continue;                                  // (the next segment's barrier after its LayerNorm also ends this one's reads of the y tile)
+            }
         }
         if (a.ln2_g) {
             rows_layernorm<RPW, VPL, D>(v, pn_g2, pn_be2, a.eps, lane);
@@ -838,6 +903,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         }
         if constexpr (TAIL) __syncthreads();
     }
+    }   // segments
     CFM_STAMP(6);
 
     // ================= TAIL: t = xn . Wt^T + bt (GLU optional), 16-bit store ===================================
@@ -892,12 +958,12 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     CFM_STAMP(7);
 }
 
-template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU, bool HATT = false, bool TVT = false>
+template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false>
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
     // HATT: tiles do not cross utterances (B x ceil(T / 32) workgroups)
     const unsigned grid = HATT ? (unsigned)((((a.M / a.att_T) + 7) / 8) * 8 * ((a.att_T + RBM - 1) / RBM)) : (unsigned)((a.M + RBM - 1) / RBM);
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU, HATT, TVT>), dim3(grid), dim3(NT), 0, s, a);
+    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU, HATT, TVT, SEG2>), dim3(grid), dim3(NT), 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -915,7 +981,10 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
                   "a row stride >= 256 (multiple of 4) and, with positions, both biases");
     CFM_CHECK_ARG(!tvt || (tail && !d->tail_glu && d->D == 256 && d->tail_N == 768 && d->vt_T > 0 && d->M % d->vt_T == 0 && d->vt_ld >= d->vt_T),
                   "cfm_rowchain: transposed values need the fused-QKV tail at D = 256, M %% vt_T == 0 and vt_ld >= vt_T");
-    CFM_CHECK_ARG(!dw || (head && mid && !tail && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
+    const bool seg2 = d->s2_w1f != nullptr;
+    CFM_CHECK_ARG(!seg2 || (mid && d->s2_w2n && d->s2_b1 && d->s2_b2 && d->s2_ln_g && d->s2_ln_b && d->s2_out_f32 && d->ln2_g),
+                  "cfm_rowchain: a second segment needs a first feed-forward, its own weights / biases / input norm / output and ln2");
+    CFM_CHECK_ARG(!dw || (head && mid && (!tail || seg2) && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
                   "cfm_rowchain: the depthwise input stage needs a head + feed-forward chain, bias/scale/shift, 15 taps and M %% dw_T == 0");
     CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256), "cfm_rowchain: D=%d has no instance (144, 256)", d->D);
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_rowchain: w_dtype must be bf16 or fp16");
@@ -936,6 +1005,8 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     a.att_qkv = (const u16*)d->att_qkv; a.att_vt = (const u16*)d->att_vt; a.att_p = (const u16*)d->att_p; a.att_bias_u = d->att_bias_u;
     a.att_bias_v = d->att_bias_v; a.att_mask = d->att_mask; a.att_p_sb = d->att_p_sb; a.att_m_sb = d->att_m_sb; a.att_T = d->att_T;
     a.att_vt_ld = d->att_vt_ld; a.att_scale = d->att_scale;
+    a.s2_ln_g = d->s2_ln_g; a.s2_ln_b = d->s2_ln_b; a.s2_w1f = (const u16*)d->s2_w1f; a.s2_w2n = (const u16*)d->s2_w2n; a.s2_b1 = d->s2_b1;
+    a.s2_b2 = d->s2_b2; a.s2_out_f32 = d->s2_out_f32; a.s2_alpha = d->s2_alpha;
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->w_dtype == CFM_BF16;
     const int tfrags = tail ? d->tail_N / 16 : 0;
@@ -943,7 +1014,7 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     const double M = (double)d->M;
     const double fl_head = head ? 2.0 * M * d->D * d->D : 0.0, fl_mid = mid ? 4.0 * M * d->D * d->FF : 0.0,
                  fl_tail = tail ? 2.0 * M * d->D * d->tail_N : 0.0;
-    const double fl = fl_head + fl_mid + fl_tail + (dw ? 2.0 * M * d->D * 15 : 0.0) + (att ? 4.0 * M * d->att_T * d->D : 0.0);
+    const double fl = fl_head + fl_mid * (seg2 ? 2.0 : 1.0) + fl_tail + (dw ? 2.0 * M * d->D * 15 : 0.0) + (att ? 4.0 * M * d->att_T * d->D : 0.0);
 #define CFM_RC(HT, DD, FFV, HS, MIDV, TS, GLU, NAME) return launch_chain<HT, DD, FFV, HS, false, MIDV, TS, GLU>(a, s, NAME, fl)
 #define CFM_RCDW(HT, DD, FFV, NAME) return launch_chain<HT, DD, FFV, 1, true, true, 0, false>(a, s, NAME, fl)
     // the three roles of a conformer block (+ a bare QKV projection and a bare LayerNorm), for D = 256 (ff 2048) and D = 144 (ff 576)
@@ -951,6 +1022,8 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
         if (att) { if (bf) return launch_chain<BF16, 256, 64, 1, false, false, 1, true, true, false>(a, s, "chain_attconvin_bf16_d256", fl); else return launch_chain<F16, 256, 64, 1, false, false, 1, true, true, false>(a, s, "chain_attconvin_f16_d256", fl); }
         if (tvt && !head && mid && tsteps == 3) { if (bf) return launch_chain<BF16, 256, 2048, 0, false, true, 3, false, false, true>(a, s, "chain_macaron_vt_bf16_d256", fl); else return launch_chain<F16, 256, 2048, 0, false, true, 3, false, false, true>(a, s, "chain_macaron_vt_f16_d256", fl); }
         if (tvt) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: transposed values only on the macaron chain");
+        if (seg2 && head && dw && tail && !d->tail_glu && tsteps == 3) { if (bf) return launch_chain<BF16, 256, 2048, 1, true, true, 3, false, false, false, true>(a, s, "chain_dwfinal_macaron_bf16_d256", fl); else return launch_chain<F16, 256, 2048, 1, true, true, 3, false, false, false, true>(a, s, "chain_dwfinal_macaron_f16_d256", fl); }
+        if (seg2) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: a second segment only on the depthwise + final chain followed by a QKV tail (D = 256)");
         if (!head && mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 2048, 0, true, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 2048, 0, true, 3, false, "chain_macaron_f16_d256"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 1) { if (bf) CFM_RC(BF16, 256, 64, 1, false, 1, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 64, 1, false, 1, true, "chain_convin_f16_d256"); }
         if (head && mid && !tail && dw) { if (bf) CFM_RCDW(BF16, 256, 2048, "chain_dwfinal_bf16_d256"); else CFM_RCDW(F16, 256, 2048, "chain_dwfinal_f16_d256"); }

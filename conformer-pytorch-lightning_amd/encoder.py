@@ -57,6 +57,13 @@ class ConformerEncoder(nn.Module):
         fuse_after = (cfm.rowchain_supported(self.encoder_dim, self.encoders[0].hidden_dim, prec) and
                       self.after_norm.weight.dtype == torch.float32 and self.after_norm.eps == 1e-5)
         y_after = torch.empty_like(x) if fuse_after else None
+        # consecutive blocks chained: block i's last launch runs block i+1's macaron chain too (batch path on the row chains at the
+        # config-2 width; encoder_layer.CHAIN_BLOCKS)
+        import encoder_layer as _el
+        e0 = self.encoders[0]
+        chain = (_el.CHAIN_BLOCKS and not _el.MERGE_ATTENTION and fuse_after and caches is None and ring is None and conv is None and self.encoder_dim == 256 and
+                 e0.hidden_dim == 2048 and e0.kernel_size == 15 and not getattr(e0.conv_module, "causal", False) and
+                 all(b.chain_ready(prec) for b in self.encoders))
         for i, block in enumerate(self.encoders):
             nxt = self.encoders[i + 1].norm_ff_macaron if i + 1 < n else None
             cache_i = None
@@ -68,6 +75,8 @@ class ConformerEncoder(nn.Module):
             out, nc = block.fused_forward(cur, attn_mask, pos_embed, pad_mask, cache_i, xn_ready=ready, next_norm=nxt,
                                           out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pos_shared=pos_shared,
                                           ring=None if ring is None else (ring[0][i], ring[1]), conv_cache=None if conv is None else conv[i],
+                                          chain_next=(self.encoders[i + 1], bufs[(i + 1) & 1]) if chain and i + 1 < n else None,
+                                          macaron_done=chain and i > 0,
                                           after=(self.after_norm.weight.detach(), self.after_norm.bias.detach(), y_after)
                                           if fuse_after and i + 1 == n else None)
             if new_caches is not None:

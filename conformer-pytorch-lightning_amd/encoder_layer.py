@@ -22,6 +22,7 @@ from convolution import ConvolutionModule
 from feedforward import PositionwiseFeedForwardModule, _inference_only
 
 _ABSENT = torch.ones((0, 0, 0), dtype=torch.bool)
+CHAIN_BLOCKS = True        # the final chain of block i also runs the macaron chain of block i+1 (one launch and one residual round trip less)
 MERGE_ATTENTION = False    # attention as the input stage of the conv-in chain (3 launches per block instead of 4): built, parity-tested and
                            # measured SLOWER at config 2 (27.7 us vs 9.7 + 13.1 us, rowchain.hip) -- opt-in
 
@@ -60,12 +61,22 @@ class ConformerEncoderLayer(nn.Module):
             self._fused = (key, struct, keep)
         return self._fused[1]
 
+    def chain_ready(self, prec):
+        """True when this block's weight struct carries every fragment-major pack of the row-chain path (cfm_encoder_layer_forward then
+        takes that path, a precondition for chaining consecutive blocks)."""
+        w = self._weights(prec)
+        return all(getattr(w, f) for f in ("ffm_w1f", "ffm_w2n", "ff_w1f", "ff_w2n", "qkv_wf", "out_wf", "pw1_wf", "pw2_wf"))
+
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
-                      want_cache=True, pos_proj=None, pos_shared=False, after=None, ring=None, conv_cache=None):
+                      want_cache=True, pos_proj=None, pos_shared=False, after=None, ring=None, conv_cache=None, chain_next=None,
+                      macaron_done=False):
         """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified.
         ring = (kv_ring f32 [B,H,ring_T,2dk], offsets int32 [B]): per-stream streaming state (include/cfm.h cfm_layer_io.kv_ring);
         attn_mask is then the (B,1,ring_T) slot mask and pos_embed the B*ring_T positional rows.  conv_cache f32 [B,K-1,D]: the
-        opt-in causal convolution's left context (only with conv_module.causal)."""
+        opt-in causal convolution's left context (only with conv_module.causal).
+        chain_next = (next block, its output buffer): this block's last launch also runs the NEXT block's macaron chain (cfm.h
+        cfm_layer_io.next_w); the next block is then called with macaron_done=True and the same output buffer, and THIS call's
+        returned tensor does not hold the block output.  Only ConformerEncoder._run_blocks uses it."""
         _inference_only(self, "ConformerEncoderLayer.fused_forward")
         cfm.require_hip(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
@@ -146,6 +157,12 @@ class ConformerEncoderLayer(nn.Module):
             raise RuntimeError("a conv cache needs the opt-in causal convolution (conv_module.causal = True)")
         if out is None:
             out = torch.empty_like(x)
+        if chain_next is not None:
+            nxt_w = chain_next[0]._weights(prec)
+            if chain_next[1].data_ptr() == out.data_ptr() or chain_next[1].shape != out.shape or chain_next[1].dtype != torch.float32:
+                raise RuntimeError("chain_next: the next block's output buffer must be a distinct float32 tensor of the same shape")
+            io.next_w, io.next_x_out = ctypes.cast(ctypes.pointer(nxt_w), ctypes.c_void_p), chain_next[1].data_ptr()
+        io.macaron_done = 1 if macaron_done else 0
         ng = nb = None
         if next_norm is not None:
             ng, nb = next_norm.weight.data_ptr(), next_norm.bias.data_ptr()

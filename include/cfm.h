@@ -240,6 +240,16 @@ typedef struct {
     int64_t att_p_sb, att_m_sb;
     int32_t att_T, att_H, att_vt_ld;
     float att_scale;
+    /* optional SECOND feed-forward segment on the same rows, kept in registers (final chain of block i + macaron chain of block i+1):
+     *     y1 = LN1(y)                       (as above; out_f32 may be NULL then: nothing else reads the block's output)
+     *     z  = y1 + s2_alpha * FFN2( LN(y1; s2_ln_g, s2_ln_b) )   -> s2_out_f32
+     *     y2 = LN(z; ln2_g, ln2_b) -> out16 / the tail's input;  the tail follows z.
+     * Needs w1f (a first feed-forward), ln2_g and the same FF for both. */
+    const float *s2_ln_g, *s2_ln_b;
+    const void *s2_w1f, *s2_w2n;
+    const float *s2_b1, *s2_b2;
+    float* s2_out_f32;
+    float s2_alpha;
 } cfm_rowchain_desc;
 
 int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
@@ -439,6 +449,17 @@ typedef struct {
     int32_t pos_shared;       /* 1: the pos_rows == Tk positional rows are the SAME for every batch item (batched streaming step: all
                                  streams at one offset).  Beyond the reference, whose forward_chunk only works at batch 1
                                  (attention.py:78-88); per item it equals that batch-1 call. */
+    /* Chaining consecutive blocks (chain path only): the final chain of this block and the macaron chain of the NEXT block are both
+     * row-local, so one launch can run them back to back on rows that stay in registers (cfm_rowchain_desc.s2_*): one launch, one f32
+     * read and one f32 write of the residual stream less per block.
+     *   next_w != NULL : after norm_final, run the next block's macaron feed-forward + norm_mha + fused QKV projection as well; the
+     *                    next block's post-macaron residual goes to next_x_out (f32 [B*T,D]) and its q|k|v rows to s->qkv.  x_out then
+     *                    does NOT receive this block's output (it is left holding the residual stream before the feed-forward).
+     *   macaron_done   : this block's macaron chain already ran in the previous block's call: x_out holds its residual, s->qkv its
+     *                    projections; x_in is not read. */
+    const cfm_layer_weights* next_w;
+    float* next_x_out;
+    int32_t macaron_done;
 } cfm_layer_io;
 
 /* x_in f32 [B*T,D] (not modified) -> x_out f32 [B*T,D] = norm_final(block(x_in)).

@@ -804,6 +804,27 @@ def test_general_path_matches_chain_path_including_after_norm(pkg):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_chained_blocks_are_bit_identical_to_one_launch_per_chain(pkg, mode):
+    """encoder_layer.CHAIN_BLOCKS: the final chain of block i also runs the macaron chain of block i+1 on rows that stay in registers
+    (rowchain.hip SEG2).  Same operations in the same order on the same values -- bit-identical to separate launches; ragged batch,
+    M not a multiple of 32, 4 blocks (first / middle / last positions of the chaining)."""
+    pkg.cfm.set_precision(mode)
+    enc = build_encoder(pkg, CFG2 | dict(encoder_num_layers=4), 93)
+    x = dev(synth.fbank(94, 3, 530))
+    lens = torch.tensor([530, 401, 77], dtype=torch.int32, device=DEV)
+    try:
+        with torch.no_grad():
+            pkg.encoder_layer.CHAIN_BLOCKS = True
+            y1, m1 = enc(x, lens)
+            pkg.encoder_layer.CHAIN_BLOCKS = False
+            y2, m2 = enc(x, lens)
+    finally:
+        pkg.encoder_layer.CHAIN_BLOCKS = True
+    assert torch.equal(m1, m2) and torch.isfinite(y1).all() and float(y1.abs().max()) > 0.1
+    assert torch.equal(y1, y2), relerr(y1, y2)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("relative", [True, False])
 def test_attention_inside_conv_in_chain_matches_separate_launches(pkg, mode, relative):
     """Blocks at the config-2 width can run attention as the input stage of the conv-in chain (3 launches per block, rowchain.hip HATT; opt-in
@@ -818,12 +839,14 @@ def test_attention_inside_conv_in_chain_matches_separate_launches(pkg, mode, rel
     lens = torch.tensor([700, 655, 402, 260, 131], dtype=torch.int32, device=DEV)
     try:
         with torch.no_grad():
+            pkg.encoder_layer.CHAIN_BLOCKS = False                 # (the chained launch writes q|k|v rows, not transposed values)
             pkg.encoder_layer.MERGE_ATTENTION = True
             y3, m3 = enc(x, lens)
             pkg.encoder_layer.MERGE_ATTENTION = False
             y4, m4 = enc(x, lens)
     finally:
         pkg.encoder_layer.MERGE_ATTENTION = False
+        pkg.encoder_layer.CHAIN_BLOCKS = True
     assert torch.equal(m3, m4) and torch.isfinite(y3).all()
     e = relerr(y3, y4)
     print("  [%s] merged vs separate attention (relative=%s): %.3e" % (mode, relative, e))
