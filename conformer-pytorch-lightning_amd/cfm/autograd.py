@@ -413,6 +413,7 @@ def _train_weights_struct(layer, pks):
     return w
 
 
+USE_PACK_KERNEL = os.environ.get("CFM_PACK_KERNEL", "1") != "0"   # one cfm_pack_matrices launch per block and step instead of ~25 torch ops
 OVERLAP_WGRAD = os.environ.get("CFM_OVERLAP_WGRAD", "0") != "0"   # measured at config 3: 21.3 ms per step with, 19.7 ms without
 _SIDE = {}
 
@@ -521,8 +522,9 @@ class EncoderLayerFn(torch.autograd.Function):
         if ctx.flat and not _composite_ok(layer, x):
             raise RuntimeError("a block registered with a flat parameter leaf (trainer.py) needs the composite train path")
         if _composite_ok(layer, x):
-            pks = (packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
-                   packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
+            pks = packing.pack_layer_train(layer, prec, rel) if USE_PACK_KERNEL else (
+                packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
+                packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
             return _layer_composite_forward(ctx, _f32c(x.reshape(B * T, D)), layer, prec, mask8, m_str, keep, pks, B, T, D).view(B, T, D)
         pks = (packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
                packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))

@@ -292,6 +292,105 @@ def pack_conv_module_train(mod, prec):
     return _train_cache(mod).get(srcs, prec, build)
 
 
+class _LayerPackPlan:
+    """The 8 weight matrices of one conformer block (two feed-forwards, fused q|k|v, out-projection, the GLU-interleaved pointwise-conv-1,
+    pointwise-conv-2) as ONE cfm_pack_matrices launch per optimizer step: the destination tensors and the job table are built once (the
+    parameters' addresses do not move: the optimizer writes in place), a rebuild is one kernel + the three small bias vectors."""
+
+    def __init__(self, layer, prec, relative):
+        ffm, att, cv, ff = layer.feed_forward_macaron, layer.self_attn, layer.conv_module, layer.feed_forward
+        dev = ffm.w_1.weight.device
+        D = cv.pointwise_conv2.weight.shape[0]
+        self.idx = glu_interleave_index(D, dev)
+        self.relative = relative
+        self.srcs = [ffm.w_1.weight, ffm.w_2.weight, att.linear_q.weight, att.linear_k.weight, att.linear_v.weight, att.linear_out.weight,
+                     cv.pointwise_conv1.weight, cv.pointwise_conv2.weight, ff.w_1.weight, ff.w_2.weight]
+        self.ptrs = tuple(t.data_ptr() for t in self.srcs)
+        for t in self.srcs:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise TypeError("the training packs need contiguous float32 parameters")
+        wdt = torch.bfloat16 if prec.split else prec.w_dtype
+
+        def rows_of(t, n, k, perm=None):
+            r = t.data_ptr() + torch.arange(n, device=dev, dtype=torch.int64) * (k * 4)
+            return r if perm is None else r[perm]
+
+        def alloc(n, k):
+            mk = lambda: torch.empty((n, k), dtype=wdt, device=dev)
+            return mk(), (mk() if prec.split else None), torch.empty((k, n), dtype=wdt, device=dev), (torch.empty((k, n), dtype=wdt, device=dev) if prec.split else None)
+
+        FF = ffm.w_1.weight.shape[0]
+        specs = [("ffm_w1", rows_of(ffm.w_1.weight, FF, D), FF, D), ("ffm_w2", rows_of(ffm.w_2.weight, D, FF), D, FF),
+                 ("qkv", torch.cat([rows_of(att.linear_q.weight, D, D), rows_of(att.linear_k.weight, D, D), rows_of(att.linear_v.weight, D, D)]), 3 * D, D),
+                 ("out", rows_of(att.linear_out.weight, D, D), D, D),
+                 ("pw1", rows_of(cv.pointwise_conv1.weight, 2 * D, D, self.idx), 2 * D, D), ("pw2", rows_of(cv.pointwise_conv2.weight, D, D), D, D),
+                 ("ff_w1", rows_of(ff.w_1.weight, FF, D), FF, D), ("ff_w2", rows_of(ff.w_2.weight, D, FF), D, FF)]
+        self.keep, self.out, jobs, tile0 = [], {}, [], 0
+        for name, rows, n, k in specs:
+            if n % 8 or k % 8:
+                raise ValueError("training packs: matrix dims must be multiples of 8")
+            rows = rows.contiguous()
+            w, wl, wt, wtl = alloc(n, k)
+            self.keep.append(rows)
+            self.out[name] = (w, wl, wt, wtl)
+            jobs.append([rows.data_ptr(), n, k, w.data_ptr(), _c.ptr(wl) or 0, wt.data_ptr(), _c.ptr(wtl) or 0, tile0])
+            tile0 += ((n + 63) // 64) * ((k + 63) // 64)
+        self.tiles = tile0
+        self.jobs = torch.tensor(jobs, dtype=torch.int64).to(dev)
+        self.prec = prec
+
+    def valid_for(self, prec):
+        return prec.name == self.prec.name and tuple(t.data_ptr() for t in self.srcs) == self.ptrs
+
+    def run(self, layer):
+        prec = self.prec
+        _c.check(_c.lib().cfm_pack_matrices(self.jobs.data_ptr(), self.jobs.shape[0], self.tiles, _c.BF16 if prec.split else prec.w_code, 1 if prec.split else 0,
+                                            _c.stream()), "cfm_pack_matrices")
+        ffm, att, cv, ff = layer.feed_forward_macaron, layer.self_attn, layer.conv_module, layer.feed_forward
+        o = self.out
+
+        def ffn(mod, pre):
+            (w1, w1l, w1t, w1tl), (w2, w2l, w2t, w2tl) = o[pre + "_w1"], o[pre + "_w2"]
+            return Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias), w1t=w1t, w1t_lo=w1tl, w2t=w2t, w2t_lo=w2tl)
+        bq = att.linear_q.bias.detach().float()
+        if self.relative:
+            bq = bq + att.pos_bias_u.detach().float().reshape(-1)
+        qkv_b = torch.cat([bq, att.linear_k.bias.detach().float(), att.linear_v.bias.detach().float()], 0).contiguous()
+        (qkv, qkvl, qkvt, qkvtl), (out, outl, outt, outtl) = o["qkv"], o["out"]
+        pa = Packed(qkv_w=qkv, qkv_w_lo=qkvl, qkv_t=qkvt, qkv_t_lo=qkvtl, qkv_b=qkv_b, out_w=out, out_w_lo=outl, out_t=outt, out_t_lo=outtl,
+                    out_b=f32(att.linear_out.bias))
+        D = cv.pointwise_conv2.weight.shape[0]
+        dev = qkv.device
+        bn = cv.norm
+        b1 = (cv.pointwise_conv1.bias.detach() if cv.pointwise_conv1.bias is not None else torch.zeros(2 * D, device=dev))[self.idx]
+        dwb = cv.depthwise_conv.bias.detach() if cv.depthwise_conv.bias is not None else torch.zeros(D, device=dev)
+        gamma = bn.weight.detach() if bn.weight is not None else torch.ones(D, device=dev)
+        beta = bn.bias.detach() if bn.bias is not None else torch.zeros(D, device=dev)
+        (pw1, pw1l, pw1t, pw1tl), (pw2, pw2l, pw2t, pw2tl) = o["pw1"], o["pw2"]
+        pc = Packed(pw1_w=pw1, pw1_w_lo=pw1l, pw1_t=pw1t, pw1_t_lo=pw1tl, pw1_b=f32(b1), pw2_w=pw2, pw2_w_lo=pw2l, pw2_t=pw2t, pw2_t_lo=pw2tl,
+                    pw2_b=f32(cv.pointwise_conv2.bias), dw_w=f32(cv.depthwise_conv.weight.detach()[:, 0, :]), dw_b=f32(dwb), gamma=f32(gamma),
+                    beta=f32(beta), idx=self.idx)
+        return ffn(ffm, "ffm"), pa, pc, ffn(ff, "ff")
+
+
+def pack_layer_train(layer, prec, relative):
+    """(macaron FFN, attention, conv module, FFN) training packs of one block, the 8 matrices through one cfm_pack_matrices launch.
+    Same values as pack_ffn_train / pack_mhsa_train / pack_conv_module_train (tests compare them)."""
+    st = layer.__dict__.get("_pack_layer_train")
+    srcs = layer.__dict__.get("_pack_layer_srcs")
+    if srcs is None:                                   # every parameter a pack depends on (LayerNorm parameters are read in place)
+        srcs = [p for n, p in layer.named_parameters() if not n.startswith("norm_")]
+        layer.__dict__["_pack_layer_srcs"] = srcs
+    key = _key(srcs, prec)
+    if st is not None and st[0] == key:
+        return st[2]
+    with torch.no_grad():
+        plan = st[1] if st is not None and st[1].valid_for(prec) else _LayerPackPlan(layer, prec, relative)
+        val = plan.run(layer)
+    layer.__dict__["_pack_layer_train"] = (key, plan, val)
+    return val
+
+
 def pack_subsampling_train(mod, prec):
     c1, c2, lin = mod.conv[0], mod.conv[2], mod.out[0]
 

@@ -564,6 +564,58 @@ __global__ void cfm_dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, Cf
         out[id] = cfm_hash32(d.seed, (unsigned)id) >= d.thresh ? 1 : 0;
 }
 
+// Weight packs of the training path in one launch: a table of jobs, each "gather N source rows of K f32 values (a device array of row
+// pointers: concatenations and row permutations are just pointer tables) into the 16-bit matrix dst [N,K] and its transpose dst_t [K,N]"
+// (+ the bf16 lo planes of the f32-accurate mode).  One 64 x 64 tile per workgroup through an LDS tile, so both outputs are written in
+// 16-byte pieces along their own fast axis.  Job = 8 x int64: rows, N, K, dst, dst_lo, dst_t, dst_t_lo, first tile.
+__global__ __launch_bounds__(256) void cfm_pack_kernel(const int64_t* __restrict__ jobs, int n_jobs, int dt, int split) {
+    __shared__ float tile[64][65];
+    int j = 0;
+    while (j + 1 < n_jobs && jobs[(j + 1) * 8 + 7] <= (int64_t)blockIdx.x) ++j;     // uniform
+    const int64_t* job = jobs + j * 8;
+    const float* const* rows = (const float* const*)job[0];
+    const int N = (int)job[1], K = (int)job[2];
+    u16 *dst = (u16*)job[3], *dst_lo = (u16*)job[4], *dst_t = (u16*)job[5], *dst_t_lo = (u16*)job[6];
+    const int t = (int)((int64_t)blockIdx.x - job[7]);
+    const int tiles_k = (K + 63) / 64;
+    const int n0 = (t / tiles_k) * 64, k0 = (t % tiles_k) * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = i * 256 + tid, r = id >> 4, c4 = (id & 15) * 4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (n0 + r < N && k0 + c4 < K) v = *(const f32x4*)(rows[n0 + r] + k0 + c4);       // K % 4 == 0
+        tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    auto emit = [&](u16* hi_p, u16* lo_p, const f32x4& a, const f32x4& b) {
+        if (split) {
+            u32x4 hi, lo;
+            split8(a, b, hi, lo);
+            *(u32x4*)hi_p = hi;
+            *(u32x4*)lo_p = lo;
+        } else {
+            *(u32x4*)hi_p = dt == CFM_BF16 ? pack8<BF16>(a, b) : pack8<F16>(a, b);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = i * 256 + tid, r = id >> 3, c8 = (id & 7) * 8;
+        if (dst && n0 + r < N && k0 + c8 < K) {                                             // K % 8 == 0
+            const f32x4 a = {tile[r][c8], tile[r][c8 + 1], tile[r][c8 + 2], tile[r][c8 + 3]};
+            const f32x4 b = {tile[r][c8 + 4], tile[r][c8 + 5], tile[r][c8 + 6], tile[r][c8 + 7]};
+            const int64_t o = (int64_t)(n0 + r) * K + k0 + c8;
+            emit(dst + o, dst_lo + o, a, b);
+        }
+        if (dst_t && k0 + r < K && n0 + c8 < N) {                                           // N % 8 == 0; row r of the transpose = column k0 + r
+            const f32x4 a = {tile[c8][r], tile[c8 + 1][r], tile[c8 + 2][r], tile[c8 + 3][r]};
+            const f32x4 b = {tile[c8 + 4][r], tile[c8 + 5][r], tile[c8 + 6][r], tile[c8 + 7][r]};
+            const int64_t o = (int64_t)(k0 + r) * N + n0 + c8;
+            emit(dst_t + o, dst_t_lo + o, a, b);
+        }
+    }
+}
+
 inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
     int64_t b = (n + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -707,6 +759,15 @@ extern "C" int cfm_dropout_rows(const void* x, int32_t x_dtype, void* y, int32_t
     CFM_LAUNCH(cfm_dropout_rows_kernel, dim3((unsigned)grid_for(M * (N / 4))), dim3(256), 0, s, x, x_dtype, y, y_dtype, row_mask, alpha, cfm_make_drop(p, seed),
                cfm_make_drop(p2, seed2), M, N);
     return cfm_launch_status("cfm_dropout_rows");
+}
+
+extern "C" int cfm_pack_matrices(const int64_t* jobs_dev, int32_t n_jobs, int64_t total_tiles, int32_t w_dtype, int32_t split, cfm_stream_t stream) {
+    CFM_CHECK_ARG(jobs_dev && n_jobs > 0 && n_jobs <= 64 && total_tiles > 0 && total_tiles < ((int64_t)1 << 31), "cfm_pack_matrices: bad arguments (at most 64 jobs)");
+    CFM_CHECK_ARG(split ? w_dtype == CFM_BF16 : cfm_is16(w_dtype), "cfm_pack_matrices: 16-bit destination type (split: bf16 hi/lo planes)");
+    hipStream_t s = (hipStream_t)stream;
+    CfmProfScope prof("pack_matrices", s, 0.0, (double)total_tiles * 64 * 64 * 8);
+    CFM_LAUNCH(cfm_pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, jobs_dev, n_jobs, w_dtype, split);
+    return cfm_launch_status("cfm_pack_matrices");
 }
 
 extern "C" int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream_t stream) {

@@ -577,6 +577,15 @@ int cfm_dropout_rows(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, c
                      float p2, uint32_t seed2, int64_t M, int32_t N, cfm_stream_t stream);
 int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream_t stream);
 
+/* Weight packs of the training path, any number of matrices in one launch (csrc/train.hip cfm_pack_kernel).  jobs_dev: DEVICE array of
+ * n_jobs x 8 int64 -- { rows, N, K, dst, dst_lo, dst_t, dst_t_lo, first_tile }: `rows` a device array of N pointers to f32 source rows of K
+ * contiguous values (concatenated or permuted sources are just pointer tables: the fused q|k|v matrix, the GLU-interleaved pointwise
+ * conv), dst [N,K] and dst_t [K,N] the 16-bit matrix and its transpose (either may be 0), *_lo the bf16 lo planes when split != 0,
+ * first_tile the prefix sum of ceil(N/64) * ceil(K/64) over the preceding jobs; total_tiles the sum over all jobs.  N % 8 == 0, K % 8 == 0.
+ * Replaces the per-step torch casts / transposes of cfm/packing.py (what the reference's optimizer step makes necessary: the kernels
+ * read 16-bit copies of the f32 master weights). */
+int cfm_pack_matrices(const int64_t* jobs_dev, int32_t n_jobs, int64_t total_tiles, int32_t w_dtype, int32_t split, cfm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * One conformer block in TRAIN mode as two host calls (csrc/train_layer.cpp): encoder_layer.py:49-71 under module.train() and its
  * backward, the same launches in the same order as the op-by-op composition of cfm/autograd.py.  All buffers are the caller's:

@@ -392,3 +392,35 @@ def test_attention_dropout_forward_backward(cfm, B, T, H, dk, mode):
                       split=split, drop=(p, seed))
     for sl in (slice(0, D), slice(D, 2 * D), slice(2 * D, 3 * D)):
         assert relerr(dqkv[:, sl].float(), g_ref[:, sl]) < (1e-4 if split else 3e-2)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
+def test_pack_kernel_equals_torch_packs(mode):
+    """cfm_pack_matrices (one launch for the 8 matrices of a block: casts, transposes, the fused q|k|v concatenation, the GLU row
+    interleave, hi/lo planes in the f32-accurate mode) against the torch-op packs it replaces: bit-identical, also after an in-place
+    weight update through a raw pointer + packing.bump_epoch() (what the trainer's Adam kernel does)."""
+    import cfm
+    import encoder_layer
+    from cfm import packing
+    torch.manual_seed(3)
+    prec = cfm.Precision(mode)
+    layer = encoder_layer.ConformerEncoderLayer(256, 15, 0.1, 0.1, 2048, 4, True).to("cuda")
+    for rep in range(2):
+        got = packing.pack_layer_train(layer, prec, True)
+        ref = (packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, True),
+               packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
+        n = 0
+        for g, r in zip(got, ref):
+            for k, v in r.__dict__.items():
+                w = getattr(g, k)
+                if v is None:
+                    assert w is None, k
+                    continue
+                assert isinstance(w, torch.Tensor) and w.shape == v.shape and w.dtype == v.dtype, k
+                assert torch.equal(w, v), (mode, rep, k)
+                n += 1
+        assert n >= 29
+        with torch.no_grad():
+            for p in layer.parameters():
+                p.data.add_(0.01 * torch.randn_like(p))            # (bumps versions too; the epoch covers raw-pointer writers)
+        packing.bump_epoch()
