@@ -136,6 +136,13 @@ class LayerWeights(ctypes.Structure):
     _fields_ = [(n, c_p) for n in _LAYER_W_FIELDS]
 
 
+class LnBwdDesc(ctypes.Structure):
+    _fields_ = [("x", c_p), ("dy", c_p), ("gamma", c_p), ("row_mask", c_p), ("dres", c_p), ("dx", c_p), ("dgamma", c_p), ("dbeta", c_p), ("ws", c_p),
+                ("dx2", c_p), ("M", c_i64), ("D", c_i32), ("dy_dtype", c_i32), ("dx2_dtype", c_i32), ("accumulate", c_i32),
+                ("eps", ctypes.c_float), ("alpha2", ctypes.c_float), ("p1", ctypes.c_float), ("p2", ctypes.c_float),
+                ("seed1", ctypes.c_uint32), ("seed2", ctypes.c_uint32)]
+
+
 class LayerScratch(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw", "vt")] + [("vt_ld", c_i32)]
 
@@ -183,6 +190,7 @@ def lib():
         L.cfm_conv1_relu_mma.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_conv12_supported.argtypes = [c_i32, c_i32]
         L.cfm_pack_matrices.argtypes = [c_p, c_i32, c_i64, c_i32, c_i32, c_p]
+        L.cfm_layernorm_bwd_fused.argtypes = [ctypes.POINTER(LnBwdDesc), c_p]
         L.cfm_conv12_relu.argtypes = [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_valid_mask.argtypes = [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_chunk_mask.argtypes = [c_p, c_i32, c_i32, c_i32, c_p]
@@ -232,7 +240,7 @@ def lib():
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
-                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices",
+                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_layernorm_bwd_fused",
                      "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L

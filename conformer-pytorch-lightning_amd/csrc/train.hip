@@ -79,10 +79,20 @@ int reduce_partials(const float* part, int nblk, int J, int J1, float alpha, flo
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int LNB_ROWS = 8;       // 2 rows per wavefront: at M = 2 k rows a 32-row workgroup left three quarters of the CUs idle (12 us -> ~4 us)
 
+// Optional second output (LnBwd2): the NEXT consumer of dx in a conformer block's backward is a residual branch whose gradient enters its
+// GEMMs as dropout-mask * alpha * dx in the activation dtype (cfm_dropout_rows); written here it saves that launch and its read of dx.
+struct LnBwd2 {
+    void* y;
+    int dt;
+    float alpha;
+    CfmDrop d1, d2;
+};
+
 template <int ITERS>
 __global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy, int dy_dt,
                                                                 const float* __restrict__ gamma, const uint8_t* __restrict__ mask,
-                                                                const float* dres, float* dx, float* __restrict__ ws, float eps, int64_t M, int D) {
+                                                                const float* dres, float* dx, float* __restrict__ ws, float eps, int64_t M, int D,
+                                                                float* acc_g, float* acc_b, LnBwd2 o2) {
     __shared__ float red[4][2][ITERS * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[ITERS], db[ITERS], gm[ITERS];
@@ -140,6 +150,17 @@ __global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __r
                 f32x4 o = (gm[it] * dv[it] - m1 - xv[it] * m2) * rstd;
                 if (dres) o += *(const f32x4*)(dres + row * D + c);
                 *(f32x4*)(dx + row * D + c) = o;
+                if (o2.y) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = o[e] * o2.alpha;
+                        if (o2.d1.thresh) u = cfm_drop(o2.d1, (unsigned)(row * D + c + e), u);
+                        if (o2.d2.thresh) u = cfm_drop(o2.d2, (unsigned)(row * D + c + e), u);
+                        t[e] = u;
+                    }
+                    store4(o2.y, o2.dt, row * D + c, t);
+                }
             }
         }
     }
@@ -155,7 +176,9 @@ __global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __r
     __syncthreads();
     for (int j = threadIdx.x; j < 2 * D; j += 256) {
         const int which = j / D, c = j - which * D;
-        ws[((int64_t)blockIdx.x * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        const float v = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        if (acc_g) unsafeAtomicAdd((which ? acc_b : acc_g) + c, v);      // one pass: the workgroups meet in the (caller-zeroed or running) sums
+        else ws[((int64_t)blockIdx.x * 2 + which) * D + c] = v;
     }
 }
 
@@ -626,22 +649,40 @@ inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
 // ================================================================================================================================
 extern "C" int64_t cfm_layernorm_bwd_ws(int64_t M, int32_t D) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * (int64_t)D; }
 
+static int layernorm_bwd_impl(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres, float* dx,
+                              float* dgamma, float* dbeta, float* ws, bool accumulate, const LnBwd2& o2, float eps, int64_t M, int32_t D, hipStream_t s) {
+    const int nblk = (int)((M + LNB_ROWS - 1) / LNB_ROWS);
+    float *ag = accumulate ? dgamma : nullptr, *ab = accumulate ? dbeta : nullptr;
+    {
+        CfmProfScope prof("layernorm_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(dy_dtype) + (dres ? 4 : 0) + (o2.y ? cfm_elt_size(o2.dt) : 0)));
+        const dim3 grid((unsigned)nblk), block(256);
+        if (D <= 256) CFM_LAUNCH((cfm_layernorm_bwd_kernel<1>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
+        else if (D <= 512) CFM_LAUNCH((cfm_layernorm_bwd_kernel<2>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
+        else CFM_LAUNCH((cfm_layernorm_bwd_kernel<4>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
+        if (int rc = cfm_launch_status("cfm_layernorm_bwd")) return rc;
+    }
+    if (accumulate) return CFM_OK;
+    return reduce_partials(ws, nblk, 2 * D, D, 1.0f, dgamma, dbeta, s, "cfm_layernorm_bwd (reduce)");
+}
+
 extern "C" int cfm_layernorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres,
                                  float* dx, float* dgamma, float* dbeta, float* ws, float eps, int64_t M, int32_t D, cfm_stream_t stream) {
     CFM_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && ws, "cfm_layernorm_bwd: null pointer");
     CFM_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "cfm_layernorm_bwd: need D %% 4 == 0 and D <= 1024 (M=%lld D=%d)", (long long)M, D);
     CFM_CHECK_ARG(dy_dtype >= CFM_F32 && dy_dtype <= CFM_F16, "cfm_layernorm_bwd: bad dy dtype");
-    hipStream_t s = (hipStream_t)stream;
-    const int nblk = (int)((M + LNB_ROWS - 1) / LNB_ROWS);
-    {
-        CfmProfScope prof("layernorm_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(dy_dtype) + (dres ? 4 : 0)));
-        const dim3 grid((unsigned)nblk), block(256);
-        if (D <= 256) CFM_LAUNCH((cfm_layernorm_bwd_kernel<1>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D);
-        else if (D <= 512) CFM_LAUNCH((cfm_layernorm_bwd_kernel<2>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D);
-        else CFM_LAUNCH((cfm_layernorm_bwd_kernel<4>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D);
-        if (int rc = cfm_launch_status("cfm_layernorm_bwd")) return rc;
-    }
-    return reduce_partials(ws, nblk, 2 * D, D, 1.0f, dgamma, dbeta, s, "cfm_layernorm_bwd (reduce)");
+    LnBwd2 none = {};
+    return layernorm_bwd_impl(x, dy, dy_dtype, gamma, row_mask, dres, dx, dgamma, dbeta, ws, false, none, eps, M, D, (hipStream_t)stream);
+}
+
+extern "C" int cfm_layernorm_bwd_fused(const cfm_ln_bwd_desc* d, cfm_stream_t stream) {
+    CFM_CHECK_ARG(d && d->x && d->dy && d->gamma && d->dx && d->dgamma && d->dbeta && (d->accumulate || d->ws), "cfm_layernorm_bwd_fused: null pointer");
+    CFM_CHECK_ARG(d->M > 0 && d->D > 0 && d->D % 4 == 0 && d->D <= 1024, "cfm_layernorm_bwd_fused: need D %% 4 == 0 and D <= 1024");
+    CFM_CHECK_ARG(d->dy_dtype >= CFM_F32 && d->dy_dtype <= CFM_F16 && (!d->dx2 || (d->dx2_dtype >= CFM_F32 && d->dx2_dtype <= CFM_F16)), "cfm_layernorm_bwd_fused: bad dtype");
+    CFM_CHECK_ARG(d->p1 >= 0.f && d->p1 < 1.f && d->p2 >= 0.f && d->p2 < 1.f && d->M * d->D < ((int64_t)1 << 32), "cfm_layernorm_bwd_fused: p in [0,1), fewer than 2^32 elements");
+    LnBwd2 o2 = {};
+    if (d->dx2) { o2.y = d->dx2; o2.dt = d->dx2_dtype; o2.alpha = d->alpha2; o2.d1 = cfm_make_drop(d->p1, d->seed1); o2.d2 = cfm_make_drop(d->p2, d->seed2); }
+    return layernorm_bwd_impl(d->x, d->dy, d->dy_dtype, d->gamma, d->row_mask, d->dres, d->dx, d->dgamma, d->dbeta, d->ws, d->accumulate != 0, o2, d->eps, d->M,
+                              d->D, (hipStream_t)stream);
 }
 
 extern "C" int cfm_glu_bwd(const void* u, int32_t u_dtype, const void* dg, int32_t dg_dtype, void* du, int32_t du_dtype, int64_t M, int32_t D,

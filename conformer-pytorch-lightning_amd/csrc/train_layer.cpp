@@ -104,23 +104,42 @@ int ffn_fwd(const TCtx& c, const float* x, const float* lg, const float* lb, con
     return gemm(c, h, c.adt, c.FF, w2, w2l, b2, x_out, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, x, 0.5f, nullptr, 0, nullptr, nullptr, p_o, s_o);
 }
 
-// d (f32 [M,D], the gradient of the sub-block's output) is updated in place to the gradient of its input
-int ffn_bwd(const TCtx& c, const cfm_layer_train_scratch* t, void* dyb_buf, void* dz_buf, float* d, const float* x, const float* lg, const void* xn, const void* z,
+// What the NEXT sub-block (in backward order) wants from a LayerNorm backward besides dx: its branch gradient as a GEMM operand,
+// dropout(alpha * dx) in the activation dtype -- cfm_dropout_rows folded into the launch that produces dx (buf == nullptr: nothing).
+struct Next {
+    void* buf;
+    float alpha, p1;
+    uint32_t s1;
+    float p2;
+    uint32_t s2;
+};
+
+// LayerNorm backward of a sub-block: dx = dres + dLN(dy) in place on the residual gradient, parameter gradients into the (zero-filled,
+// accumulating) slab -- with atomics in one launch unless the caller asked for reproducible sums -- and the next sub-block's operand
+int ln_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const float* x, const void* dy, const float* gamma, const uint8_t* mask, const float* dres, float* dx,
+           float* gg, float* gb, const Next& nx) {
+    cfm_ln_bwd_desc d = {};
+    d.x = x; d.dy = dy; d.dy_dtype = CFM_F32; d.gamma = gamma; d.row_mask = mask; d.dres = dres; d.dx = dx; d.dgamma = gg; d.dbeta = gb; d.ws = t->ln_ws;
+    d.accumulate = c.io->deterministic ? 0 : 1;
+    d.dx2 = nx.buf; d.dx2_dtype = c.adt; d.alpha2 = nx.alpha; d.p1 = nx.p1; d.seed1 = nx.s1; d.p2 = nx.p2; d.seed2 = nx.s2;
+    d.eps = 1e-5f; d.M = c.M; d.D = c.D;
+    return cfm_layernorm_bwd_fused(&d, c.st);
+}
+
+// d (f32 [M,D], the gradient of the sub-block's output) is updated in place to the gradient of its input.  dyb_buf != nullptr: the branch
+// gradient through the output dropout is already there (written by the previous LayerNorm backward, see Next)
+int ffn_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const void* dyb_buf, void* dz_buf, float* d, const float* x, const float* lg, const void* xn, const void* z,
             const void* h, const void* w1t, const void* w1tl, const void* w2t, const void* w2tl, float* gW1, float* gb1, float* gW2, float* gb2, float* glg,
-            float* glb, float p_h, uint32_t s_h, float p_o, uint32_t s_o) {
+            float* glb, float p_h, uint32_t s_h, const Next& nx) {
     const void* dyb = d;
     int dyb_dt = CFM_F32;
     float alpha = 0.5f;
-    if (p_o > 0.f || c.side) {   // the branch gradient through the output dropout, as a GEMM operand (with a side stream: always its own buffer --
-                                 // d is overwritten by this sub-block's LayerNorm backward while the weight-gradient product may still read it)
-        CFM_TRY(cfm_dropout_rows(d, CFM_F32, dyb_buf, c.adt, nullptr, 0.5f, p_o, s_o, 0.f, 0, c.M, c.D, c.st));
-        dyb = dyb_buf; dyb_dt = c.adt; alpha = 1.0f;
-    }
+    if (dyb_buf) { dyb = dyb_buf; dyb_dt = c.adt; alpha = 1.0f; }
     CFM_TRY(wgrad(c, dyb, dyb_dt, c.D, h, c.adt, c.FF, gW2, gb2, c.M, c.D, c.FF, alpha, nullptr, nullptr, nullptr));
     CFM_TRY(gemm(c, dyb, dyb_dt, c.D, w2t, w2tl, nullptr, dz_buf, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_DSILU, nullptr, alpha, nullptr, 0, nullptr, z, p_h, s_h));
     CFM_TRY(wgrad(c, dz_buf, c.adt, c.FF, xn, c.adt, c.D, gW1, gb1, c.M, c.FF, c.D, 1.0f, nullptr, nullptr, nullptr));
     CFM_TRY(gemm(c, dz_buf, c.adt, c.FF, w1t, w1tl, nullptr, t->dxn, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
-    return cfm_layernorm_bwd(x, t->dxn, CFM_F32, lg, nullptr, d, d, glg, glb, t->ln_ws, 1e-5f, c.M, c.D, c.st);
+    return ln_bwd(c, t, x, t->dxn, lg, nullptr, d, d, glg, glb, nx);
 }
 
 }  // namespace
@@ -183,20 +202,29 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
     const int M = c.M, D = c.D, adt = c.adt;
     const uint32_t sd = io->seed;
     float* d = dx;                                        // the residual stream's gradient, updated in place from the block's output to its input
+    // Each sub-block's branch gradient (dropout mask * alpha * d, act dtype) is written by the LayerNorm backward that produces d -- when it is
+    // needed at all: with dropout, or with a side stream (d is overwritten by the sub-block's own LayerNorm backward while a weight-gradient
+    // product on the side stream may still read its operand; one buffer per sub-block then)
+    const bool br = io->p_branch > 0.f || c.side;
+    float pa1 = io->p_branch, pa2 = io->p_attn_out;
+    uint32_t sa1 = site_seed(sd, 4), sa2 = site_seed(sd, 5);
+    if (pa1 <= 0.f && pa2 > 0.f) { pa1 = pa2; sa1 = sa2; pa2 = 0.f; }
+    const bool bra = pa1 > 0.f || c.side;
+    const Next n_ff = {br ? t->dyb : nullptr, 0.5f, io->p_branch, site_seed(sd, 8), 0.f, 0};
+    const Next n_conv = {br ? (c.side ? t->dyb2 : t->dyb) : nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0};
+    const Next n_att = {bra ? (c.side ? t->dyb3 : t->dyb) : nullptr, 1.0f, pa1, sa1, pa2, sa2};
+    const Next n_ffm = {br ? (c.side ? t->dyb4 : t->dyb) : nullptr, 0.5f, io->p_branch, site_seed(sd, 2), 0.f, 0};
+    const Next n_none = {nullptr, 0.f, 0.f, 0, 0.f, 0};
     // (5) norm_final
-    CFM_TRY(cfm_layernorm_bwd(sv->x4, dy, CFM_F32, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, t->ln_ws, 1e-5f, M, D, stream));
+    CFM_TRY(ln_bwd(c, t, sv->x4, dy, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, n_ff));
     // (4) feed-forward
-    CFM_TRY(ffn_bwd(c, t, t->dyb, t->dz, d, sv->x3, w->ln_ff_g, sv->xn4, sv->z2, sv->h2, w->ff_w1t, w->ff_w1t_lo, w->ff_w2t, w->ff_w2t_lo, g->ff_w1, g->ff_b1, g->ff_w2, g->ff_b2,
-                    g->ln_ff_g, g->ln_ff_b, io->p_hidden, site_seed(sd, 7), io->p_branch, site_seed(sd, 8)));
+    CFM_TRY(ffn_bwd(c, t, n_ff.buf, t->dz, d, sv->x3, w->ln_ff_g, sv->xn4, sv->z2, sv->h2, w->ff_w1t, w->ff_w1t_lo, w->ff_w2t, w->ff_w2t_lo, g->ff_w1, g->ff_b1, g->ff_w2, g->ff_b2,
+                    g->ln_ff_g, g->ln_ff_b, io->p_hidden, site_seed(sd, 7), n_conv));
     // (3) convolution module: x3 = x2 + mask * drop(s . Wpw2^T + b)
     {
         const void* dyb = d;
         int dyb_dt = CFM_F32;
-        void* buf = c.side ? t->dyb2 : t->dyb;
-        if (io->p_branch > 0.f || c.side) {
-            CFM_TRY(cfm_dropout_rows(d, CFM_F32, buf, adt, nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0, M, D, stream));
-            dyb = buf; dyb_dt = adt;
-        }
+        if (n_conv.buf) { dyb = n_conv.buf; dyb_dt = adt; }
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, io->pad_valid, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, io->pad_valid, 1, nullptr, nullptr, 0.f, 0));
         CFM_TRY(cfm_dwconv_bn_train_bwd(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
@@ -204,20 +232,13 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
         CFM_TRY(cfm_glu_bwd(sv->u, adt, t->dglu, adt, t->du, adt, M, D, stream));
         CFM_TRY(wgrad(c, t->du, adt, 2 * D, sv->xn3, adt, D, g->slab, g->slab, M, 2 * D, D, 1.0f, nullptr, g->pw1_row_off, g->pw1_bias_off));
         CFM_TRY(gemm(c, t->du, adt, 2 * D, w->pw1_t, w->pw1_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 2 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
-        CFM_TRY(cfm_layernorm_bwd(sv->x2, t->dxn, CFM_F32, w->ln_conv_g, io->pad_valid, d, d, g->ln_conv_g, g->ln_conv_b, t->ln_ws, 1e-5f, M, D, stream));
+        CFM_TRY(ln_bwd(c, t, sv->x2, t->dxn, w->ln_conv_g, io->pad_valid, d, d, g->ln_conv_g, g->ln_conv_b, n_att));
     }
     // (2) self-attention: x2 = x1 + drop(ctx . Wo^T + bo)
     {
-        float p1 = io->p_branch, p2 = io->p_attn_out;
-        uint32_t s1 = site_seed(sd, 4), s2 = site_seed(sd, 5);
-        if (p1 <= 0.f && p2 > 0.f) { p1 = p2; s1 = s2; p2 = 0.f; }
         const void* dyb = d;
         int dyb_dt = CFM_F32;
-        void* buf = c.side ? t->dyb3 : t->dyb;
-        if (p1 > 0.f || c.side) {
-            CFM_TRY(cfm_dropout_rows(d, CFM_F32, buf, adt, nullptr, 1.0f, p1, s1, p2, s2, M, D, stream));
-            dyb = buf; dyb_dt = adt;
-        }
+        if (n_att.buf) { dyb = n_att.buf; dyb_dt = adt; }
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->ctx, adt, D, g->out_w, g->out_b, M, D, D, 1.0f, nullptr, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->out_t, w->out_t_lo, nullptr, t->dctx, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
         cfm_attn_bwd_desc b = {};
@@ -234,12 +255,11 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
             hipMemcpyAsync(g->pos_bias_u, g->q_bias, (size_t)D * 4, hipMemcpyDeviceToDevice, (hipStream_t)(c.side ? c.side : stream)) != hipSuccess)
             return cfm_fail(CFM_ERR_LAUNCH, "train layer: copy of the pos_bias_u gradient failed");
         CFM_TRY(gemm(c, t->dqkv, adt, 3 * D, w->qkv_t, w->qkv_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 3 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
-        CFM_TRY(cfm_layernorm_bwd(sv->x1, t->dxn, CFM_F32, w->ln_mha_g, nullptr, d, d, g->ln_mha_g, g->ln_mha_b, t->ln_ws, 1e-5f, M, D, stream));
+        CFM_TRY(ln_bwd(c, t, sv->x1, t->dxn, w->ln_mha_g, nullptr, d, d, g->ln_mha_g, g->ln_mha_b, n_ffm));
     }
     // (1) macaron feed-forward
-    CFM_TRY(ffn_bwd(c, t, c.side ? t->dyb4 : t->dyb, c.side ? t->dz2 : t->dz, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t,
-                    w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2, g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), io->p_branch,
-                    site_seed(sd, 2)));
+    CFM_TRY(ffn_bwd(c, t, n_ffm.buf, c.side ? t->dz2 : t->dz, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t,
+                    w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2, g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), n_none));
     if (c.side) return stream_after(c.side, c.st);       // join: the block's gradients are complete when the main stream gets past this point
     return CFM_OK;
 }

@@ -500,6 +500,25 @@ int cfm_joint_act(const float* enc, int64_t ld_e, const float* pred, int64_t ld_
  *                       backward of nn.LayerNorm at encoder_layer.py:57,60,64,68,70 and encoder.py:74.   D % 4 == 0, D <= 1024.
  */
 int64_t cfm_layernorm_bwd_ws(int64_t M, int32_t D);
+/* The same backward with two launches folded in (what a conformer block's backward does right before and after it):
+ *   accumulate != 0 : dgamma / dbeta are ADDED to with f32 atomics in the same launch (no workspace pass; the caller zero-fills them or
+ *                     carries a running sum; summation order varies from run to run) -- 0: two-stage through ws, overwritten, reproducible;
+ *   dx2 != NULL     : also writes dropout(alpha2 * dx) in dx2_dtype -- the next residual branch's gradient as a GEMM operand, exactly
+ *                     cfm_dropout_rows(dx, .., alpha2, p1, seed1, p2, seed2) without its launch. */
+typedef struct {
+    const float* x;
+    const void* dy;
+    const float* gamma;
+    const uint8_t* row_mask;
+    const float* dres;
+    float *dx, *dgamma, *dbeta, *ws;
+    void* dx2;
+    int64_t M;
+    int32_t D, dy_dtype, dx2_dtype, accumulate;
+    float eps, alpha2, p1, p2;
+    uint32_t seed1, seed2;
+} cfm_ln_bwd_desc;
+int cfm_layernorm_bwd_fused(const cfm_ln_bwd_desc* d, cfm_stream_t stream);
 int cfm_layernorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres,
                       float* dx, float* dgamma, float* dbeta, float* ws, float eps, int64_t M, int32_t D, cfm_stream_t stream);
 

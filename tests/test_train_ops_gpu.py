@@ -424,3 +424,39 @@ def test_pack_kernel_equals_torch_packs(mode):
             for p in layer.parameters():
                 p.data.add_(0.01 * torch.randn_like(p))            # (bumps versions too; the epoch covers raw-pointer writers)
         packing.bump_epoch()
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_layernorm_bwd_fused_equals_separate_launches(accumulate):
+    """cfm_layernorm_bwd_fused: dx identical to cfm_layernorm_bwd; the second output identical to cfm_dropout_rows on dx (two dropouts, bf16);
+    parameter gradients identical through the workspace (accumulate = 0) and added on top of what is there by atomics (accumulate = 1: order of
+    the f32 sums differs, 1e-5)."""
+    import ctypes
+    import cfm
+    torch.manual_seed(11)
+    M, D = 1237, 256
+    x = torch.randn((M, D), device="cuda")
+    dy = torch.randn((M, D), device="cuda")
+    dres = torch.randn((M, D), device="cuda")
+    gamma = torch.randn((D,), device="cuda")
+    mask = (torch.rand((M,), device="cuda") > 0.2).to(torch.uint8)
+    dx_ref, dg_ref, db_ref = cfm.layernorm_bwd(x, dy, gamma, row_mask=mask, dres=dres)
+    y_ref = cfm.dropout_rows(dx_ref, torch.bfloat16, alpha=0.5, drop=(0.1, 77), drop2=(0.2, 78))
+    dx = torch.empty_like(x)
+    dx2 = torch.empty((M, D), dtype=torch.bfloat16, device="cuda")
+    base_g, base_b = torch.randn((D,), device="cuda"), torch.randn((D,), device="cuda")
+    dg, db = base_g.clone(), base_b.clone()
+    ws = torch.empty((int(cfm.lib().cfm_layernorm_bwd_ws(M, D)),), device="cuda")
+    d = cfm.LnBwdDesc()
+    d.x, d.dy, d.gamma, d.row_mask, d.dres, d.dx, d.dgamma, d.dbeta, d.ws, d.dx2 = (t.data_ptr() for t in (x, dy, gamma, mask, dres, dx, dg, db, ws, dx2))
+    d.M, d.D, d.dy_dtype, d.dx2_dtype, d.accumulate = M, D, cfm.F32, cfm.BF16, accumulate
+    d.eps, d.alpha2, d.p1, d.p2, d.seed1, d.seed2 = 1e-5, 0.5, 0.1, 0.2, 77, 78
+    cfm.check(cfm.lib().cfm_layernorm_bwd_fused(ctypes.byref(d), cfm.stream()), "cfm_layernorm_bwd_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    assert torch.equal(dx2.view(torch.int16), y_ref.view(torch.int16))
+    if accumulate:
+        assert float((dg - base_g - dg_ref).abs().max()) < 1e-5 * float(dg_ref.abs().max()) + 1e-5
+        assert float((db - base_b - db_ref).abs().max()) < 1e-5 * float(db_ref.abs().max()) + 1e-5
+    else:
+        assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
