@@ -77,7 +77,8 @@ int reduce_partials(const float* part, int nblk, int J, int J1, float alpha, flo
 //   xhat = (x - mean) * rstd;  gy = gamma * dy;   dx = dres + rstd * (gy - mean_D(gy) - xhat * mean_D(gy * xhat))
 //   dgamma = sum_rows dy * xhat;  dbeta = sum_rows dy          (per-workgroup partials -> ws[blk][2][D])
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr int LNB_ROWS = 8;       // 2 rows per wavefront: at M = 2 k rows a 32-row workgroup left three quarters of the CUs idle (12 us -> ~4 us)
+constexpr int LNB_WAVES = 8;      // 2 rows per wavefront (at M = 2 k rows a 32-row, 4-wavefront workgroup left three quarters of the CUs idle: 12 us -> ~4 us);
+constexpr int LNB_ROWS = 2 * LNB_WAVES;   // 8 wavefronts halve the workgroups that meet in the parameter-gradient sums (atomics of the one-launch form: 10.3 us with 4)
 
 // Optional second output (LnBwd2): the NEXT consumer of dx in a conformer block's backward is a residual branch whose gradient enters its
 // GEMMs as dropout-mask * alpha * dx in the activation dtype (cfm_dropout_rows); written here it saves that launch and its read of dx.
@@ -89,11 +90,11 @@ struct LnBwd2 {
 };
 
 template <int ITERS>
-__global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy, int dy_dt,
+__global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy, int dy_dt,
                                                                 const float* __restrict__ gamma, const uint8_t* __restrict__ mask,
                                                                 const float* dres, float* dx, float* __restrict__ ws, float eps, int64_t M, int D,
                                                                 float* acc_g, float* acc_b, LnBwd2 o2) {
-    __shared__ float red[4][2][ITERS * 256];
+    __shared__ float red[LNB_WAVES][2][ITERS * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[ITERS], db[ITERS], gm[ITERS];
 #pragma unroll
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __r
         gm[it] = c < D ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float invD = 1.0f / (float)D;
-    for (int r = wave; r < LNB_ROWS; r += 4) {
+    for (int r = wave; r < LNB_ROWS; r += LNB_WAVES) {
         const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + r;
         if (row >= M) break;                               // wave-uniform
         const bool keep = mask ? mask[row] != 0 : true;
@@ -174,9 +175,11 @@ __global__ __launch_bounds__(256) void cfm_layernorm_bwd_kernel(const float* __r
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < 2 * D; j += 256) {
+    for (int j = threadIdx.x; j < 2 * D; j += 64 * LNB_WAVES) {
         const int which = j / D, c = j - which * D;
-        const float v = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < LNB_WAVES; wv += 4) v += (red[wv][which][c] + red[wv + 1][which][c]) + (red[wv + 2][which][c] + red[wv + 3][which][c]);
         if (acc_g) unsafeAtomicAdd((which ? acc_b : acc_g) + c, v);      // one pass: the workgroups meet in the (caller-zeroed or running) sums
         else ws[((int64_t)blockIdx.x * 2 + which) * D + c] = v;
     }
@@ -655,7 +658,7 @@ static int layernorm_bwd_impl(const float* x, const void* dy, int32_t dy_dtype, 
     float *ag = accumulate ? dgamma : nullptr, *ab = accumulate ? dbeta : nullptr;
     {
         CfmProfScope prof("layernorm_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(dy_dtype) + (dres ? 4 : 0) + (o2.y ? cfm_elt_size(o2.dt) : 0)));
-        const dim3 grid((unsigned)nblk), block(256);
+        const dim3 grid((unsigned)nblk), block(64 * LNB_WAVES);
         if (D <= 256) CFM_LAUNCH((cfm_layernorm_bwd_kernel<1>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
         else if (D <= 512) CFM_LAUNCH((cfm_layernorm_bwd_kernel<2>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
         else CFM_LAUNCH((cfm_layernorm_bwd_kernel<4>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
