@@ -43,7 +43,7 @@ class GemmTnDesc(ctypes.Structure):
                 ("a_dtype", c_i32), ("b_dtype", c_i32), ("mma_dtype", c_i32), ("split", c_i32), ("accumulate", c_i32), ("splits", c_i32),
                 ("alpha", ctypes.c_float),
                 ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
-                ("row_off", c_p), ("colsum_off", c_p)]
+                ("row_off", c_p), ("colsum_off", c_p), ("tile", c_i32)]
 
 
 class AttnBwdDesc(ctypes.Structure):

@@ -17,6 +17,7 @@
 //   bias   the column sums of A (d loss / d bias) ride along in the k-tile-0 workgroups: the A tile is in LDS anyway
 //   conv   B rows may be the implicit im2col rows of a channels-last image (3x3 stride 2): the front-end's conv2 weight gradient
 //   SPLIT  f32 operands split into bf16 hi/lo planes while staging, 3 MFMAs per fragment pair (the f32-accurate mode)
+#include <math.h>
 #include <string>
 
 #include "cfm_common.h"
@@ -35,7 +36,7 @@ struct TnArgs {
     int M, N, K;
     float alpha;
     int convC, T1, F1, T2, F2;
-    int chunks_per_split, atomic;
+    int chunks_per_split, atomic;   // atomic: 1 = f32 atomic adds, 0 = plain store, 2 = plain read-add-store (accumulate with ONE workgroup per tile)
     const int64_t* row_off;
     const int64_t* colsum_off;
 };
@@ -157,8 +158,15 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
     for (int i = 0; i < FR; ++i)
 #pragma unroll
         for (int j = 0; j < FR; ++j) acc[i][j] = zf;
-    float csum = 0.f;                                // bias gradient: thread t < 128 owns column n0 + t (k-tile 0 workgroups only)
-    const bool do_colsum = g.colsum != nullptr && tile_k == 0 && tid < TN_BN;
+    // bias gradient (k-tile 0 workgroups, their wavefronts of k-half 0): the column sums of A are one more MFMA per A fragment against a
+    // fragment of ones -- every output row then holds sum_m A[m][n].  (The first version summed the A tile column by column out of LDS,
+    // MCH dependent 2-byte reads per chunk: 2 us per 128-row chunk in exactly the workgroups that finish last.)
+    f32x4 acs[FR];
+#pragma unroll
+    for (int i = 0; i < FR; ++i) acs[i] = zf;
+    const bool do_colsum = g.colsum != nullptr && tile_k == 0 && wc == 0;      // wave-uniform
+    const unsigned one2 = pack2<HT>(1.0f, 1.0f);
+    const u32x4 ones = {one2, one2, one2, one2};
 
     gload(chunk_begin);
     int buf = 0;
@@ -191,12 +199,12 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
                     }
                     acc[i][j] = HT::mfma(bf[j], af[i], acc[i][j]);
                 }
-        }
-        if (do_colsum) {
-#pragma unroll 8
-            for (int r = 0; r < MCH; ++r) {
-                csum += HT::to_f32(At[r * TN_STR + tid]);
-                if constexpr (SPLIT) csum += BF16::to_f32(At[PLANE + r * TN_STR + tid]);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    if constexpr (SPLIT) acs[i] = HT::mfma(ones, afl[i], acs[i]);
+                    acs[i] = HT::mfma(ones, af[i], acs[i]);
+                }
             }
         }
         // two buffers, one barrier per chunk: chunk ch+1 is stored into the other buffer, whose last readers (chunk ch-1) all passed
@@ -215,15 +223,219 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
             if (k >= g.K) continue;                  // K % 4 == 0: the 4 columns are valid together
             float* c = g.C + (g.row_off ? g.row_off[n] : (int64_t)n * g.ldc) + k;
             const f32x4 v = acc[i][j] * g.alpha;
-            if (g.atomic) {
+            if (g.atomic == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, v[r]);
+            } else if (g.atomic == 2) {
+                *(f32x4*)c = *(const f32x4*)c + v;
             } else {
                 *(f32x4*)c = v;
             }
         }
     }
-    if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n0 + tid] : (int64_t)(n0 + tid)), csum * g.alpha);
+    if (do_colsum && g4 == 0) {
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+            const int n = n0 + wr * (TILE / 2) + i * 16 + l15;
+            if (n < g.N) unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n] : (int64_t)n), acs[i].x * g.alpha);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The same product for 16-bit operands (every weight gradient of a bf16 / fp16 training step), staged by LDS-DMA with several chunks in
+// flight.  The register-staged kernel above keeps ONE chunk ahead, and the compiler drains vmcnt(0) at its loop back-edge, so every chunk
+// of a workgroup pays a full memory latency (measured: 2 us per 128-row chunk, 94-104 TFLOP/s at M = 2 380 / 4 000 rows) while a chunk's
+// compute is 16 MFMAs per wavefront.  Here a chunk is 64 rows x 64 columns of each operand = 4 global_load_lds requests per thread with no
+// register destination; FOUR LDS buffers, chunks c+1 .. c+3 in flight while chunk c is multiplied (48 KB per workgroup, two workgroups
+// per CU), a counted s_waitcnt vmcnt(8) and a raw s_barrier per chunk.  The DMA's LDS image is lane-linear (rows of 128 B, no padding), so
+// the 16-byte chunk index is XOR-swizzled by (row >> 1) & 7 on the source address and again on the transposed read: rows r and r + 2 of
+// a ds_read_b64_tr_b16 group would otherwise share banks.  Rows past M read a 16-byte zero.  64 x 64 tiles only, no row mask.
+__device__ __attribute__((aligned(16))) unsigned cfm_tn_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <typename HT, bool CONV, int TILE>
+__global__ __launch_bounds__(256, TILE == 64 ? 2 : 1) void cfm_gemm_tn_dma_kernel(const TnArgs g) {
+    // Measured (scripts/bench_gemm_tn_splits.py, M = 2 380): ONE 64 x 64 workgroup walks its rows at ~0.6 us per 64-row chunk whatever is in
+    // flight (8 buffers instead of 4: 27 us instead of 24 for 2 380 rows) -- with one wavefront per SIMD the chunk's own chain of address
+    // arithmetic, barrier, 16 transposed reads and 8 dependent MFMAs is exposed; every split added costs ~1.5-5 us of atomics; the
+    // 128 x 128 tile is slower at these sizes (36 vs 24 us for a feed-forward weight).  Hence the split rule in cfm_gemm_tn.
+    constexpr int MCH = 64, NBUF = 4, FR = TILE / 32;
+    constexpr int RB = TILE * 2;                       // bytes of a tile row (128 or 256)
+    constexpr int PPR = TILE / 8;                      // 16-byte pieces per row
+    constexpr int RPQ = 64 / PPR;                      // rows per 1 KB request (8 or 4)
+    constexpr int NQ = MCH / RPQ / 4;                  // requests per wavefront, operand and chunk (2 or 4)
+    constexpr int OPB = MCH * RB;                      // bytes of one operand chunk (8 or 16 KB)
+    constexpr int INFL = (NBUF - 2) * 2 * NQ;          // requests of the NBUF - 2 chunks that may stay in flight behind the one being waited for
+    constexpr int WAIT = 0x0F70 | (INFL & 0xF) | ((INFL >> 4) << 14);   // s_waitcnt vmcnt(INFL)
+    // The requests are issued from an asm statement (the recipe of /opt/skills/guides/cdna_hip_programming.md: M0 written in the statement that
+    // reads it), so they are absent from hipcc's wait-count bookkeeping: issued through __builtin_amdgcn_global_load_lds, hipcc puts an
+    // s_waitcnt vmcnt(0) in front of the fragment reads of every chunk (one LDS array or four) and nothing stays in flight.  The waits
+    // are the two explicit ones below.
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 2 * OPB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_k = (g.K + TILE - 1) / TILE;
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
+    const int n0 = tile_n * TILE, k0 = tile_k * TILE;
+    const int chunk_begin = blockIdx.y * g.chunks_per_split;
+    const int total_chunks = (g.M + MCH - 1) / MCH;
+    int chunk_end = chunk_begin + g.chunks_per_split;
+    chunk_end = chunk_end < total_chunks ? chunk_end : total_chunks;
+    const int nch = chunk_end - chunk_begin;
+    if (nch <= 0) return;                              // uniform, before any barrier
+
+    // ---- staging: request q of wavefront w fills rows 8 (w + 4 q) .. + 7 of an operand chunk; lane L lands at position L & 7 of row
+    //      8 (w + 4 q) + (L >> 3) and fetches the 16-byte piece (L & 7) ^ ((row >> 1) & 7) of that row
+    // 128-byte rows: rows r and r + 2 share banks -> (r >> 1) & 7; 256-byte rows: every row starts at bank 0 -> r & 7 (the 4 consecutive rows of a
+    // transposed read then sit in 4 different 16-byte columns)
+    auto swz = [](int row) { return TILE == 64 ? (row >> 1) & 7 : row & 7; };
+    int srow[NQ], scol[NQ];
+    bool a_ok[NQ], b_ok[NQ];
+    int64_t b_koff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        srow[q] = RPQ * (wave + 4 * q) + lane / PPR;
+        scol[q] = ((lane % PPR) ^ swz(srow[q])) * 8;                 // (128-wide rows: the XOR stays inside the row's first / second 8 pieces)
+        a_ok[q] = n0 + scol[q] < g.N;
+        b_ok[q] = k0 + scol[q] < g.K;
+        b_koff[q] = k0 + scol[q];
+        if constexpr (CONV) {
+            const int kk = k0 + scol[q];
+            const int tap = kk / g.convC, ci = kk - tap * g.convC;
+            const int k3 = tap / 3, f3 = tap - 3 * k3;
+            b_koff[q] = (int64_t)(k3 * g.F1 + f3) * g.convC + ci;
+        }
+    }
+    const char* const zsrc = (const char*)cfm_tn_zero16;
+    auto glds16 = [&](const char* gsrc, unsigned char* lds_dst) __attribute__((always_inline)) {
+        unsigned keep;
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_dst;      // wave-uniform LDS byte address
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    };
+    auto stage = [&](int buf, int chunk) __attribute__((always_inline)) {
+        unsigned char* const At = smem + buf * (2 * OPB);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int m = chunk * MCH + srow[q];
+            const bool row_ok = m < g.M;
+            const int mc = row_ok ? m : 0;
+            const char* pa = (const char*)((const u16*)g.A + ((int64_t)mc * g.lda + n0 + scol[q]));
+            int64_t boff;
+            if constexpr (CONV) {
+                const int per_b = g.T2 * g.F2;
+                const int b = mc / per_b, rem = mc - b * per_b;
+                const int t2 = rem / g.F2, f2 = rem - t2 * g.F2;
+                boff = ((int64_t)(b * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.convC + b_koff[q];
+            } else {
+                boff = (int64_t)mc * g.ldb + b_koff[q];
+            }
+            const char* pb = (const char*)((const u16*)g.B + boff);
+            pa = (row_ok && a_ok[q]) ? pa : zsrc;
+            pb = (row_ok && b_ok[q]) ? pb : zsrc;
+            glds16(pa, At + (wave + 4 * q) * 1024);
+            glds16(pb, At + OPB + (wave + 4 * q) * 1024);
+        }
+    };
+    // transposed fragment: 16 columns from c0, the 32 rows of m-step ms; 8-byte piece (l15 & 3) of rows 4 g4 + (l15 >> 2) and + 16
+    auto frag = [&](const unsigned char* tile, int ms, int c0) __attribute__((always_inline)) {
+        const int row = ms * 32 + 4 * g4 + (l15 >> 2);
+        const int col = c0 + (l15 & 3) * 4;
+        const int sw = swz(row);                         // rows row and row + 16 swizzle alike
+        const unsigned char* pa = tile + row * RB + (((col >> 3) ^ sw) << 4) + (col & 4) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 16 * RB));
+        const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+        return (u32x4){lo2.x, lo2.y, hi2.x, hi2.y};
+    };
+
+    const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[FR][FR], acs[FR];
+#pragma unroll
+    for (int i = 0; i < FR; ++i) {
+        acs[i] = zf;
+#pragma unroll
+        for (int j = 0; j < FR; ++j) acc[i][j] = zf;
+    }
+    const bool do_colsum = g.colsum != nullptr && tile_k == 0 && wc == 0;
+    const unsigned one2 = pack2<HT>(1.0f, 1.0f);
+    const u32x4 ones = {one2, one2, one2, one2};
+
+    // prologue: chunks 0 .. 2 in flight (requests past the last chunk read zeros: every chunk slot costs the same 4 requests per thread,
+    // which keeps the counted waits below exact)
+    auto chunk_id = [&](int c) { return c < nch ? chunk_begin + c : total_chunks; };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) stage(i, chunk_id(i));
+    for (int c = 0; c < nch; ++c) {
+        __builtin_amdgcn_s_waitcnt(WAIT);                // chunk c has landed, chunks c+1 .. c+NBUF-2 may still be in flight
+        __builtin_amdgcn_s_barrier();                    // ... for every wavefront; and everyone is done reading the buffer chunk c+3 goes to
+        stage((c + NBUF - 1) % NBUF, chunk_id(c + NBUF - 1));
+        const unsigned char* const At = smem + (c % NBUF) * (2 * OPB);
+        const unsigned char* const Bt = At + OPB;
+#pragma unroll
+        for (int ms = 0; ms < MCH / 32; ++ms) {
+            u32x4 af[FR], bf[FR];
+#pragma unroll
+            for (int i = 0; i < FR; ++i) af[i] = frag(At, ms, wr * (TILE / 2) + i * 16);
+#pragma unroll
+            for (int j = 0; j < FR; ++j) bf[j] = frag(Bt, ms, wc * (TILE / 2) + j * 16);
+#pragma unroll
+            for (int i = 0; i < FR; ++i)
+#pragma unroll
+                for (int j = 0; j < FR; ++j) acc[i][j] = HT::mfma(bf[j], af[i], acc[i][j]);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < FR; ++i) acs[i] = HT::mfma(ones, af[i], acs[i]);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // the zero-source requests of the tail: no DMA may still be writing LDS when the workgroup ends
+
+#pragma unroll
+    for (int i = 0; i < FR; ++i) {
+        const int n = n0 + wr * (TILE / 2) + i * 16 + l15;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int j = 0; j < FR; ++j) {
+            const int k = k0 + wc * (TILE / 2) + j * 16 + 4 * g4;
+            if (k >= g.K) continue;
+            float* cp = g.C + (g.row_off ? g.row_off[n] : (int64_t)n * g.ldc) + k;
+            const f32x4 v = acc[i][j] * g.alpha;
+            if (g.atomic == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(cp + r, v[r]);
+            } else if (g.atomic == 2) {
+                *(f32x4*)cp = *(const f32x4*)cp + v;
+            } else {
+                *(f32x4*)cp = v;
+            }
+        }
+    }
+    if (do_colsum && g4 == 0) {
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+            const int n = n0 + wr * (TILE / 2) + i * 16 + l15;
+            if (n < g.N) unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n] : (int64_t)n), acs[i].x * g.alpha);
+        }
+    }
+}
+
+template <typename HT>
+int launch_tn_dma(const TnArgs& a, bool conv, int tile, int splits, hipStream_t s, const char* name) {
+    const int tiles = ((a.N + tile - 1) / tile) * ((a.K + tile - 1) / tile);
+    CfmProfScope prof(name, s, 2.0 * a.M * (double)a.N * a.K, (double)a.M * (a.N + a.K) * 2 + 4.0 * a.N * a.K);
+    const dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+    if (tile == 128) {
+        if (conv) CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, true, 128>), grid, block, 0, s, a);
+        else CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, false, 128>), grid, block, 0, s, a);
+    } else {
+        if (conv) CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, true, 64>), grid, block, 0, s, a);
+        else CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, false, 64>), grid, block, 0, s, a);
+    }
+    return cfm_launch_status(name);
 }
 
 template <typename HT, bool SPLIT, bool A32, bool B32>
@@ -269,13 +481,23 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     // 64 x 64 tiles while the output is small (fewer than 128 tiles of 128 x 128: every weight of the d = 256 / 512 blocks), 128 x 128 for
     // the big ones (the CTC head's 5008 x 256, the front-end convolutions): then about one workgroup per CU
     const int t128 = ((d->N + 127) / 128) * ((d->K + 127) / 128);
-    const int tile = (t128 >= 128 || chunks128 >= 128) ? 128 : 64;     // M >= 8 k rows: enough splits of >= 4 chunks even with few big tiles
-    const int mch = tile == 64 ? 2 * mch128 : mch128;
+    CFM_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128, "cfm_gemm_tn: tile must be 0 (auto), 64 or 128");
+    const int tile = d->tile ? d->tile : ((t128 >= 128 || chunks128 >= 128) ? 128 : 64);     // M >= 8 k rows: enough splits of >= 4 chunks even with few big tiles
+    const bool a32 = d->a_dtype == CFM_F32, b32 = d->b_dtype == CFM_F32;
+    // 16-bit operands without a row mask: the LDS-DMA kernel (64-row chunks, several in flight)
+    const bool dma = !a32 && !b32 && !d->split && !d->row_mask;
+    const int mch = dma ? 64 : (tile == 64 ? 2 * mch128 : mch128);
     const int chunks = (d->M + mch - 1) / mch;
     const int tiles = ((d->N + tile - 1) / tile) * ((d->K + tile - 1) / tile);
     int splits = d->splits;
     if (splits <= 0) {
-        splits = (256 + tiles - 1) / tiles;
+        if (dma) {
+            // measured optimum at M = 2 380 / 1 300 rows (profiles/r02_gemm_tn_splits.txt): 4 splits for 16 tiles, 3 for 32, 2-3 for 48, 1-2 for 128;
+            // a split's cost (atomics) is fixed and its gain shrinks with the rows it removes, so the optimum grows like sqrt(M)
+            splits = (int)(16.0 / sqrt((double)tiles) * sqrt((double)d->M / 2400.0) + 0.5);
+        } else {
+            splits = (256 + tiles - 1) / tiles;
+        }
         const int max_s = (chunks * mch + 255) / 256;       // at least 256 rows per split
         splits = splits > max_s ? max_s : splits;
     }
@@ -288,14 +510,14 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     a.row_off = d->row_off; a.colsum_off = d->colsum_off;
     a.chunks_per_split = (chunks + splits - 1) / splits;
     splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;   // no empty split
-    a.atomic = (splits > 1 || d->accumulate) ? 1 : 0;
+    a.atomic = splits > 1 ? 1 : (d->accumulate ? 2 : 0);
     if (!d->accumulate) {
         if (a.atomic && hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->K * 4, (size_t)d->N, s) != hipSuccess)
             return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of C failed");
         if (d->colsum && hipMemsetAsync(d->colsum, 0, (size_t)d->N * 4, s) != hipSuccess)
             return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of colsum failed");
     }
-    const bool a32 = d->a_dtype == CFM_F32, b32 = d->b_dtype == CFM_F32;
+    if (dma) return d->mma_dtype == CFM_BF16 ? launch_tn_dma<BF16>(a, conv, tile, splits, s, "gemm_tn_dma_bf16") : launch_tn_dma<F16>(a, conv, tile, splits, s, "gemm_tn_dma_f16");
     if (d->split) return launch_tn<BF16, true, true, true>(a, conv, tile, splits, s, "gemm_tn_bf16x3");
 #define CFM_TN(HT, NAME)                                                                              \
     do {                                                                                              \

@@ -144,6 +144,7 @@ typedef struct {
      * pointwise-conv-1 pack) write each reference parameter's gradient where it lives in a flat gradient buffer.  int64 [N], device. */
     const int64_t* row_off;
     const int64_t* colsum_off;
+    int32_t tile; /* 0 = chosen by the library; 64 or 128: output tile edge (experiments, scripts/bench_gemm_tn_splits.py) */
 } cfm_gemm_tn_desc;
 
 int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream);
