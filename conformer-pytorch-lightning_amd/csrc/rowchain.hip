@@ -713,7 +713,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             }
     }
     __syncthreads();                                       // xn complete; every read of the x tile in region A is done
-    CFM_STAMP(3);
+    CFM_STAMP(sg == 0 ? 3 : 10);
 
     // ================= MID: feed-forward in two phases around the hidden tile ====================================
     if constexpr (MID) {
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             }
         }
         __syncthreads();
-        CFM_STAMP(4);
+        CFM_STAMP(sg == 0 ? 4 : 11);
 
         // ---- phase 2: y = hidden . W2^T, fragments (2 np, 2 np + 1), K half kh
         f32x4 acc2[MF][2];
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         }
         __syncthreads();
     }
-    CFM_STAMP(5);
+    CFM_STAMP(sg == 0 ? 5 : 12);
 
     // ================= post norms: y1 -> out_f32, y2 -> out16 / next LDS tile =====================================
     if constexpr (MID) {
@@ -876,6 +876,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         }
         if constexpr (SEG2) {
             if (!last_seg) {
+                CFM_STAMP(13);
 #pragma unroll
                 for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll

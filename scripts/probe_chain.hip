@@ -18,6 +18,44 @@ static void* dalloc(size_t bytes, int fill) {
 
 static const char* PHASE[8] = {"", "head: stage A tile", "head: GEMM + epilogue", "rows + LN_in", "FFN phase 1 (hidden)", "FFN phase 2 + y tile", "post norms", "tail GEMM + stores"};
 
+// the chained launch (final chain of block i + macaron chain of block i+1): stamps 0..5 first segment, 13 its post norms, 10..12 the second
+// segment's LayerNorm / phase 1 / phase 2, 6 post norms, 7 tail
+static void run_seg2(const char* name, cfm_rowchain_desc d, int M) {
+    d.M = M;
+    const int grid = (M + 31) / 32;
+    for (int i = 0; i < 5; ++i) if (cfm_rowchain(&d, nullptr) != 0) { fprintf(stderr, "%s: %s\n", name, cfm_last_error()); exit(1); }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    const int reps = 50;
+    for (int i = 0; i < reps; ++i) cfm_rowchain(&d, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(1024 * 16);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(cfm_chain_stamps), sizeof(long long) * 1024 * 16);
+    const int nb = grid < 1024 ? grid : 1024;
+    static const int order[12] = {0, 1, 2, 3, 4, 5, 13, 10, 11, 12, 6, 7};
+    static const char* what[12] = {"", "depthwise + BatchNorm + SiLU input stage", "head GEMM (pointwise-conv-2) + epilogue", "rows + LN_ff", "FFN phase 1 (hidden)",
+                                   "FFN phase 2 + y tile", "post norms (LN_final)", "LN_ffm (next block)", "FFN_m phase 1", "FFN_m phase 2 + y tile",
+                                   "post norms (LN_mha)", "tail GEMM (q|k|v) + stores"};
+    printf("%-10s M=%5d grid=%4d  %7.2f us/launch (back-to-back)\n", name, M, grid, ms * 1000.f / reps);
+    double tot = 0;
+    for (int i = 1; i < 12; ++i) {
+        double sum = 0; long long mx = 0;
+        for (int b = 0; b < nb; ++b) {
+            const long long dt = h[b * 16 + order[i]] - h[b * 16 + order[i - 1]];
+            sum += (double)dt; mx = dt > mx ? dt : mx;
+        }
+        printf("    %-42s %9.0f cycles mean   %9lld max\n", what[i], sum / nb, mx);
+        tot += sum / nb;
+    }
+    double wsum = 0;
+    for (int b = 0; b < nb; ++b) wsum += (double)(h[b * 16 + 9] - h[b * 16 + 8]);
+    printf("    in-kernel total %9.0f cycles mean = %.2f us mean by the 100 MHz wall clock (=> %.2f GHz)\n", tot, wsum / nb / 100.0, tot / (wsum / nb * 10.0));
+}
+
 static void run(const char* name, cfm_rowchain_desc d, int M) {
     d.M = M;
     const int grid = (M + 31) / 32;
@@ -101,6 +139,13 @@ int main() {
     cfm_rowchain_desc fdw = fin;                           // final with the depthwise conv + BatchNorm + SiLU in its input stage
     fdw.dw_w = vec; fdw.dw_b = vec; fdw.dw_scale = vec; fdw.dw_shift = vec; fdw.dw_T = 249; fdw.dw_K = 15;
     run("dw-final", fdw, 7968);
+    {
+        cfm_rowchain_desc ch = fdw;                       // + the next block's macaron chain in the same launch (SEG2)
+        ch.out_f32 = nullptr;
+        ch.s2_ln_g = vec; ch.s2_ln_b = vec; ch.s2_w1f = w1f; ch.s2_w2n = w2f; ch.s2_b1 = vec; ch.s2_b2 = vec; ch.s2_out_f32 = out; ch.s2_alpha = 0.5f;
+        ch.ln2_g = vec; ch.ln2_b = vec; ch.tail_w = wt; ch.tail_b = vec; ch.tail_out = t16; ch.tail_N = 768;
+        run_seg2("dw-final+macaron", ch, 7968);
+    }
 
     {   // cold weights: rotate 12 weight sets (as 12 layers do), so every launch first-touches its weights on all 8 XCDs
         const int L = 12;
