@@ -110,7 +110,7 @@ class LayerTrainIO(ctypes.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("FF", c_i32), ("ktaps", c_i32), ("act_dtype", c_i32), ("w_dtype", c_i32),
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64), ("pad_valid", c_p),
                 ("p_hidden_m", ctypes.c_float), ("p_hidden", ctypes.c_float), ("p_branch", ctypes.c_float), ("p_attn", ctypes.c_float),
-                ("p_attn_out", ctypes.c_float), ("seed", ctypes.c_uint32), ("deterministic", c_i32), ("side_stream", c_p)]
+                ("p_attn_out", ctypes.c_float), ("seed", ctypes.c_uint32), ("deterministic", c_i32), ("grads_accumulate", c_i32), ("side_stream", c_p)]
 
 
 _TRAIN_SAVED = ["xn1", "z1", "h1", "xn2", "qkv", "ctx", "xn3", "u", "glu", "s", "xn4", "z2", "h2", "x1", "x2", "x3", "x4", "c", "lse", "stats"]
@@ -190,6 +190,7 @@ def lib():
         L.cfm_conv1_relu_mma.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_conv12_supported.argtypes = [c_i32, c_i32]
         L.cfm_pack_matrices.argtypes = [c_p, c_i32, c_i64, c_i32, c_i32, c_p]
+        L.cfm_dwconv_bn_train_bwd_acc.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_layernorm_bwd_fused.argtypes = [ctypes.POINTER(LnBwdDesc), c_p]
         L.cfm_conv12_relu.argtypes = [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_valid_mask.argtypes = [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
@@ -240,7 +241,7 @@ def lib():
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
-                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_layernorm_bwd_fused",
+                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
                      "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L

@@ -413,6 +413,8 @@ def _train_weights_struct(layer, pks):
     return w
 
 
+DIRECT_GRADS = os.environ.get("CFM_DIRECT_GRADS", "0") != "0"     # flat-leaf blocks add their gradients straight into the trainer's gradient buffer: measured
+# SLOWER at config 3 (17.8 vs 17.1 ms per step: the atomics / read-add-stores then hit a cold 139 MB buffer instead of a just-zeroed slab in cache) -- opt-in
 USE_PACK_KERNEL = os.environ.get("CFM_PACK_KERNEL", "1") != "0"   # one cfm_pack_matrices launch per block and step instead of ~25 torch ops
 OVERLAP_WGRAD = os.environ.get("CFM_OVERLAP_WGRAD", "0") != "0"   # measured at config 3: 21.3 ms per step with, 19.7 ms without
 _SIDE = {}
@@ -480,7 +482,13 @@ def _layer_composite_backward(ctx, dy):
     # named_parameters-order layout; zero-filled: weight / bias gradients are accumulated into it by the split-M products
     leaf = layer.__dict__.get("_flat_leaf") if ctx.flat else None
     lay = layer_grad_layout(layer, layer.__dict__.get("_flat_grad_offsets") if ctx.flat else None)
-    slab = torch.zeros((leaf.numel() if leaf is not None else lay["numel"],), dtype=torch.float32, device=dev)
+    # A block registered with a gradient SINK (trainer.py: its range of the step's flat gradient buffer + a "ready" callback) has its gradients
+    # added straight into that buffer -- no zero-filled slab, no AccumulateGrad add; needs the accumulating (atomic) LayerNorm sums
+    sink = layer.__dict__.get("_flat_grad_sink") if (ctx.flat and DIRECT_GRADS and not cfm.ops._deterministic[0]) else None
+    if sink is not None and (sink[0].numel() != leaf.numel() or sink[0].device != dev):
+        sink = None
+    io.grads_accumulate = 1 if sink is not None else 0
+    slab = sink[0] if sink is not None else torch.zeros((leaf.numel() if leaf is not None else lay["numel"],), dtype=torch.float32, device=dev)
     g = cfm.LayerTrainGrads()
     g.slab = slab.data_ptr()
     for name, field in _GRAD_FIELDS.items():
@@ -507,6 +515,9 @@ def _layer_composite_backward(ctx, dy):
     dx = torch.empty((M, D), dtype=torch.float32, device=dev)
     cfm.check(cfm.lib().cfm_encoder_layer_train_backward(ctypes.byref(w), ctypes.byref(io), ctypes.byref(sv), ctypes.byref(sc), ctypes.byref(g), x0.data_ptr(),
                                                          dyc.data_ptr(), dx.data_ptr(), cfm.stream()), "cfm_encoder_layer_train_backward")
+    if sink is not None:
+        sink[1]()                                           # the trainer's ready hook (bucket all-reduce), after the kernels are enqueued
+        return dx, None, lay
     return dx, slab, lay
 
 

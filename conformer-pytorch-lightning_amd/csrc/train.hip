@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __rest
 }
 
 // second stage of the BatchNorm backward sums: dbeta = S1, dgamma = S2, coef = (S1/N, S2/N)
-__global__ __launch_bounds__(256) void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, double inv_n, float* dgamma, float* dbeta, float* coef) {
+__global__ __launch_bounds__(256) void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, double inv_n, float* dgamma, float* dbeta, float* coef, int acc) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wavefront per channel
     if (c >= D) return;
@@ -408,14 +408,14 @@ __global__ __launch_bounds__(256) void cfm_bn_bwd_finalize_kernel(const float* _
         s2 += shfl_xor_f64(s2, o);
     }
     if (lane != 0) return;
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
+    dbeta[c] = (acc ? dbeta[c] : 0.f) + (float)s1;          // acc: on top of what is there (one writer per element: reproducible)
+    dgamma[c] = (acc ? dgamma[c] : 0.f) + (float)s2;
     coef[c] = (float)(s1 * inv_n);
     coef[D + c] = (float)(s2 * inv_n);
 }
 
 // second stage of the depthwise gradients: dw_w[c][k] (the layout of depthwise_conv.weight (D,1,K)) and dw_b[c]
-__global__ __launch_bounds__(1024) void cfm_dwconv_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, float* dw_w, float* dw_b) {
+__global__ __launch_bounds__(1024) void cfm_dwconv_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, float* dw_w, float* dw_b, int acc) {
     __shared__ float red[RP_Q][64];
     const int jc = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int id = blockIdx.x * 64 + jc;                                // output (slot, c), 16 threads each (fixed-order partial sums)
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(1024) void cfm_dwconv_bwd_finalize_kernel(const flo
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < RP_Q; ++i) s += red[i][jc];
-        if (slot < DWK) dw_w[c * DWK + slot] = s;
-        else dw_b[c] = s;
+        float* o = slot < DWK ? dw_w + c * DWK + slot : dw_b + c;
+        *o = (acc ? *o : 0.f) + s;
     }
 }
 
@@ -732,6 +732,12 @@ extern "C" int cfm_dwconv_bn_train(const void* g, int32_t g_dtype, const float* 
 extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
                                        void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
                                        int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream) {
+    return cfm_dwconv_bn_train_bwd_acc(ds, ds_dtype, c, stats, g, g_dtype, w, dg_out, dg_dtype, dw_w, dw_b, dgamma, dbeta, dy_ws, ws, B, T, D, ktaps, 0, stream);
+}
+
+extern "C" int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
+                                           void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
+                                           int32_t B, int32_t T, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream) {
     CFM_CHECK_ARG(ds && c && stats && g && w && dg_out && dw_w && dw_b && dgamma && dbeta && dy_ws && ws, "cfm_dwconv_bn_train_bwd: null pointer");
     CFM_CHECK_ARG(ktaps == DWK, "cfm_dwconv_bn_train_bwd: %d taps (only %d is built)", ktaps, DWK);
     CFM_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 512 && B <= 65535, "cfm_dwconv_bn_train_bwd: need D %% 4 == 0, D <= 512 (B=%d T=%d D=%d)", B, T, D);
@@ -746,7 +752,7 @@ extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const f
     }
     {
         CfmProfScope prof("bn_bwd_finalize", s, 0.0, (double)nb * 2 * D * 4);
-        CFM_LAUNCH(cfm_bn_bwd_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, nb, D, 1.0 / (double)M, dgamma, dbeta, coef);
+        CFM_LAUNCH(cfm_bn_bwd_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, nb, D, 1.0 / (double)M, dgamma, dbeta, coef, accumulate);
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (finalize)")) return rc;
     }
     const int nblk_t = (T + DWT - 1) / DWT;
@@ -758,7 +764,7 @@ extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const f
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (conv)")) return rc;
     }
     CfmProfScope prof("dwconv_bwd_finalize", s, 0.0, (double)B * nblk_t * 16 * D * 4);
-    CFM_LAUNCH(cfm_dwconv_bwd_finalize_kernel, dim3((unsigned)((16 * D + 63) / 64)), dim3(64 * RP_Q), 0, s, (const float*)part, B * nblk_t, D, dw_w, dw_b);
+    CFM_LAUNCH(cfm_dwconv_bwd_finalize_kernel, dim3((unsigned)((16 * D + 63) / 64)), dim3(64 * RP_Q), 0, s, (const float*)part, B * nblk_t, D, dw_w, dw_b, accumulate);
     return cfm_launch_status("cfm_dwconv_bn_train_bwd (reduce)");
 }
 

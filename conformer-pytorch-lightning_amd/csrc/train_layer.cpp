@@ -199,6 +199,7 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
     c.split = io->act_dtype == CFM_F32; c.st = stream;
     c.side = io->side_stream && io->side_stream != stream ? io->side_stream : nullptr;
     CFM_CHECK_ARG(!c.side || (t->dz2 && t->dyb2 && t->dyb3 && t->dyb4), "cfm_encoder_layer_train_backward: a side stream needs the dz2 / dyb2..4 scratch buffers");
+    CFM_CHECK_ARG(!io->grads_accumulate || !io->deterministic, "cfm_encoder_layer_train_backward: grads_accumulate needs deterministic == 0");
     const int M = c.M, D = c.D, adt = c.adt;
     const uint32_t sd = io->seed;
     float* d = dx;                                        // the residual stream's gradient, updated in place from the block's output to its input
@@ -227,8 +228,8 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
         if (n_conv.buf) { dyb = n_conv.buf; dyb_dt = adt; }
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, io->pad_valid, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, io->pad_valid, 1, nullptr, nullptr, 0.f, 0));
-        CFM_TRY(cfm_dwconv_bn_train_bwd(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
-                                        io->B, io->T, D, io->ktaps, stream));
+        CFM_TRY(cfm_dwconv_bn_train_bwd_acc(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
+                                            io->B, io->T, D, io->ktaps, io->grads_accumulate, stream));
         CFM_TRY(cfm_glu_bwd(sv->u, adt, t->dglu, adt, t->du, adt, M, D, stream));
         CFM_TRY(wgrad(c, t->du, adt, 2 * D, sv->xn3, adt, D, g->slab, g->slab, M, 2 * D, D, 1.0f, nullptr, g->pw1_row_off, g->pw1_bias_off));
         CFM_TRY(gemm(c, t->du, adt, 2 * D, w->pw1_t, w->pw1_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 2 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));

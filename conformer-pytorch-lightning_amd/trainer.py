@@ -23,6 +23,8 @@ accumulate / clip logic inject a torch implementation from tests/.
 """
 import math
 
+import functools
+
 import torch
 import torch.distributed as dist
 
@@ -118,6 +120,8 @@ class DataParallelTrainer:
                 leaf.grad = self.flat_g[lo:hi]
                 blk.__dict__["_flat_leaf"] = leaf
                 blk.__dict__["_flat_grad_offsets"] = {n: off_of[id(p)] - lo for n, p in blk.named_parameters()}
+                # gradient sink: the block's backward adds into this range directly and then calls the ready hook itself (cfm/autograd.py)
+                blk.__dict__["_flat_grad_sink"] = (self.flat_g[lo:hi], functools.partial(self._on_grad, leaf))
                 self.leaves.append(leaf)
                 for p in ps:
                     in_block[id(p)] = leaf

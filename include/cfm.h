@@ -542,6 +542,11 @@ int cfm_dwconv_bn_train(const void* g, int32_t g_dtype, const float* w, const fl
 int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
                             void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
                             int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream);
+/* accumulate != 0: the four parameter gradients (dw_w, dw_b, dgamma, dbeta) are added to what the buffers hold (one writer per element:
+ * reproducible) instead of overwritten -- a gradient buffer shared by the micro-batches of an optimizer step. */
+int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
+                                void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
+                                int32_t B, int32_t T, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream);
 
 /* Front-end backward (convolution.py:60-63).  cfm_col2im_relu_bwd: dcol [B*T2*F2, 9*C] = dh2 . W2 (cfm_gemm on the transposed conv2 pack,
  * K order (kt,kf,c)) -> dh1 [B,T1,F1,C] = ReLU'(h1) * (transposed im2col of dcol).  cfm_conv1_wgrad: dh1 and the fbank input x [B,T,F]
@@ -642,6 +647,9 @@ typedef struct {
     float p_hidden_m, p_hidden, p_branch, p_attn, p_attn_out;
     uint32_t seed;
     int32_t deterministic;
+    /* backward only: the gradient slab is a running sum (the optimizer step's flat gradient buffer itself) -- every parameter gradient is ADDED
+     * to it and nothing in it is overwritten.  Needs deterministic == 0 (the LayerNorm sums are added with atomics). */
+    int32_t grads_accumulate;
     /* backward only, optional: a second HIP stream of the same device.  The weight-gradient products do not feed the chain of input
      * gradients, so they are issued there (each after an event on its operands) and overlap with the chain on the main stream -- at
      * training batch sizes no single kernel fills the chip; the main stream waits for the side stream before the call's work is

@@ -122,3 +122,36 @@ def test_trainer_bf16_loss_goes_down(p_drop):
     losses = [float(tr.step(data)) for _ in range(20)]
     print("  bf16 training loss (dropout %.1f): %.3f -> %.3f" % (p_drop, losses[0], losses[-1]))
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0]
+
+
+def test_direct_gradient_sink_equals_accumulate_grad():
+    """Blocks registered with a gradient sink can add their gradients straight into the trainer's flat gradient buffer (cfm/autograd.py
+    DIRECT_GRADS, opt-in -- it measured slower: no zero-filled slab, no AccumulateGrad add) -- the flat gradient after 2 accumulated micro-batches equals the
+    autograd-accumulated one up to the order of f32 atomic sums, the buckets are still launched once each and in order, and the buffer is
+    clean again after the step."""
+    import cfm
+    import trainer as T
+    from cfm import autograd as ag
+    cfm.set_precision("fp32")
+    try:
+        g, meta = load_golden("train_cfg1")
+        data = micro_batches(2, 900)
+        grads = {}
+        for direct in (True, False):
+            ag.DIRECT_GRADS = direct
+            enc, dec = build(meta)
+            tr = T.DataParallelTrainer([enc, dec], make_loss(enc, dec), lr=1e-3, warmup_steps=2, accum_grad=2, grad_clip=4.0, bucket_mb=1.0, always_reduce=False)
+            seen = {}
+            orig_finish = tr.finish
+            tr.finish = lambda: seen.setdefault("g", tr.flat_g.clone())        # look at the accumulated gradient instead of stepping
+            torch.manual_seed(5)
+            tr.step(data)
+            assert tr.reduce_log == list(range(len(tr.buckets)))
+            grads[direct] = seen["g"]
+            tr.finish = orig_finish
+        a, b = grads[True], grads[False]
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) < 2e-5 * scale, float((a - b).abs().max()) / scale
+    finally:
+        ag.DIRECT_GRADS = False
+        cfm.set_precision("bf16")
