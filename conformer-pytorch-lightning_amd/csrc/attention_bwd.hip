@@ -288,6 +288,234 @@ __global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_kernel(const AttnBwdArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Fast forms for what a bf16 / fp16 training step actually runs: d_k = 64, 16-bit q / k / v / dO rows (16-byte aligned), no mask or a
+// key-validity mask (B, 1, Tk).  Same products, same element-wise arithmetic, same MFMA order as the general kernels above --
+// bit-identical results (tests) -- but
+//   * tiles are staged as they lie in memory (16-byte pieces into the swizzled row-major image, no f32 round trip) and the TRANSPOSED
+//     operands of the second products are read straight out of that image with ds_read_b64_tr_b16: no transposed copy is written
+//     (the general kernels spend 32 two-byte LDS stores per thread and tile on it);
+//   * two LDS buffers and a register prefetch: the next tile's global loads are in flight while this one is multiplied, one barrier per
+//     tile instead of two with the loads exposed in between;
+//   * mask bytes: the dkv kernel's lane owns ONE key (loaded once), the dq kernel stages the tile's 64 validity bytes with the tile;
+//   * 16 KB of LDS per buffer pair: several workgroups per CU.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+// A-operand fragment of the transposed tile: column d = fd*16 + l15, rows 32 k2 + 4 g .. + 3 and + 16 (the k order of the packed accumulators)
+__device__ __forceinline__ u32x4 tr_frag64(const u32x4* tile, int k2, int fd, int l15, int g) {
+    const int row = k2 * 32 + 4 * g + (l15 >> 2);
+    const int col = fd * 16 + (l15 & 3) * 4;
+    const unsigned char* pa = (const unsigned char*)tile + row * 128 + (((col >> 3) ^ ((row >> 1) & 7)) << 4) + (col & 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pa));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pa + 16 * 128));
+    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+    return (u32x4){lo2.x, lo2.y, hi2.x, hi2.y};
+}
+
+// this thread's two 16-byte pieces of a 64-row x 64-column 16-bit tile (rows r0 .. r0+63 of src; rows >= nrows read as zero)
+__device__ __forceinline__ void tile_load64(const u16* src, int64_t base, int64_t stride, int r0, int nrows, int tid, u32x4 (&r)[2]) {
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) {
+        const int id = pss * 256 + tid, row = id >> 3, c = id & 7;
+        const int rr = r0 + row;
+        const u32x4 v = *(const u32x4*)(src + base + (int64_t)(rr < nrows ? rr : 0) * stride + c * 8);
+        r[pss] = rr < nrows ? v : (u32x4){0u, 0u, 0u, 0u};
+    }
+}
+__device__ __forceinline__ void tile_store64(u32x4* tile, int tid, const u32x4 (&r)[2]) {
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) {
+        const int id = pss * 256 + tid;
+        tile[k_swz(id >> 3, id & 7)] = r[pss];
+    }
+}
+template <typename HT>
+__device__ __forceinline__ void tile_dot64(const u32x4* tile, const u32x4 (&fr)[2], f32x4 (&acc)[4], int l15, int g) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc[f] = HT::mfma(tile[k_swz(f * 16 + l15, kk * 4 + g)], fr[kk], acc[f]);
+    }
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dq_fast_kernel(const AttnBwdArgs a) {
+    constexpr int TP = KT * 8;                           // u32x4 per tile
+    __shared__ u32x4 Ks[2][TP], Vs[2][TP];
+    __shared__ __attribute__((aligned(16))) uint8_t Ms[2][KT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qi = blockIdx.x * QT + wave * 16 + l15;
+    const int qc = qi < a.Tq ? qi : a.Tq - 1;
+    constexpr int dk = 64;
+    const u16 *qp = (const u16*)a.q, *kp = (const u16*)a.k, *vp = (const u16*)a.v, *dop = (const u16*)a.dout;
+    u32x4 qf[2], dof[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        qf[kk] = *(const u32x4*)(qp + (int64_t)b * a.q_sb + (int64_t)qc * a.q_st + h * dk + kk * 32 + g * 8);
+        dof[kk] = *(const u32x4*)(dop + ((int64_t)b * a.Tq + qc) * ((int64_t)a.H * dk) + (int64_t)h * dk + kk * 32 + g * 8);
+    }
+    const int64_t rid = ((int64_t)b * a.H + h) * a.Tq + qc;
+    const float lse_q = qi < a.Tq ? a.lse[rid] : -INFINITY;
+    const float delta_q = a.delta[rid];
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t kb = (int64_t)b * a.k_sb + (int64_t)h * dk, vb = (int64_t)b * a.v_sb + (int64_t)h * dk;
+    const int ntiles = (a.Tk + KT - 1) / KT;
+    u32x4 rk[2], rv[2];
+    uint8_t rm = 1;
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        tile_load64(kp, kb, a.k_st, t * KT, a.Tk, tid, rk);
+        tile_load64(vp, vb, a.v_st, t * KT, a.Tk, tid, rv);
+        if (tid < KT) {
+            const int kj = t * KT + tid;
+            rm = kj < a.Tk ? 1 : 0;
+            if (rm && a.mask) rm = a.mask[(int64_t)b * a.m_sb + kj] != 0;
+        }
+    };
+    auto put = [&](int buf) __attribute__((always_inline)) {
+        tile_store64(Ks[buf], tid, rk);
+        tile_store64(Vs[buf], tid, rv);
+        if (tid < KT) Ms[buf][tid] = rm;
+    };
+    fetch(0);
+    put(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * KT;
+        if (t + 1 < ntiles) fetch(t + 1);
+        f32x4 s[4], dp[4];
+        tile_dot64<HT>(Ks[buf], qf, s, l15, g);          // s[f][r]: key k0 + f*16 + g*4 + r, query qi
+        tile_dot64<HT>(Vs[buf], dof, dp, l15, g);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const unsigned mb = *(const unsigned*)(&Ms[buf][f * 16 + g * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kj = k0 + f * 16 + g * 4 + r;
+                const bool ok = ((mb >> (8 * r)) & 0xffu) != 0 && lse_q != -INFINITY;
+                const float p = ok ? __expf(s[f][r] * a.scale - lse_q) : 0.f;
+                float dpe = dp[f][r];
+                if (a.drop.thresh) dpe = cfm_drop(a.drop, (unsigned)rid * (unsigned)a.Tk + (unsigned)kj, dpe);
+                s[f][r] = p * (dpe - delta_q) * a.scale;   // dS
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const u32x4 ph = pack8<HT>(s[2 * k2], s[2 * k2 + 1]);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) acc[fd] = HT::mfma(tr_frag64(Ks[buf], k2, fd, l15, g), ph, acc[fd]);   // dQ^T[d, q] += K^T[d, key] dS^T[key, q]
+        }
+        if (t + 1 < ntiles) put(buf ^ 1);
+        __syncthreads();
+    }
+    if (qi < a.Tq) {
+        const int64_t ob = (int64_t)b * a.q_sb + (int64_t)qi * a.q_st + h * dk;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) store_row4(a.dq, a.io_dt, ob + fd * 16 + g * 4, acc[fd]);
+    }
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_fast_kernel(const AttnBwdArgs a) {
+    constexpr int TP = QT * 8;
+    __shared__ u32x4 Qs[2][TP], Os[2][TP];
+    __shared__ __attribute__((aligned(16))) float Ls[2][QT], Ds[2][QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int kj = blockIdx.x * KT + wave * 16 + l15;
+    const int kc = kj < a.Tk ? kj : a.Tk - 1;
+    constexpr int dk = 64;
+    const u16 *qp = (const u16*)a.q, *kp = (const u16*)a.k, *vp = (const u16*)a.v, *dop = (const u16*)a.dout;
+    u32x4 kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        kf[kk] = *(const u32x4*)(kp + (int64_t)b * a.k_sb + (int64_t)kc * a.k_st + h * dk + kk * 32 + g * 8);
+        vf[kk] = *(const u32x4*)(vp + (int64_t)b * a.v_sb + (int64_t)kc * a.v_st + h * dk + kk * 32 + g * 8);
+    }
+    bool key_ok = kj < a.Tk;
+    if (key_ok && a.mask) key_ok = a.mask[(int64_t)b * a.m_sb + kj] != 0;
+    f32x4 acc_k[4], acc_v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_k[i] = acc_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t qb = (int64_t)b * a.q_sb + (int64_t)h * dk, ob = (int64_t)b * a.Tq * ((int64_t)a.H * dk) + (int64_t)h * dk;
+    const int64_t rb = ((int64_t)b * a.H + h) * a.Tq;
+    const int ntiles = (a.Tq + QT - 1) / QT;
+    u32x4 rq[2], ro[2];
+    float rl = -INFINITY, rd = 0.f;
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        tile_load64(qp, qb, a.q_st, t * QT, a.Tq, tid, rq);
+        tile_load64(dop, ob, (int64_t)a.H * dk, t * QT, a.Tq, tid, ro);
+        if (tid < QT) {
+            const int qq = t * QT + tid;
+            const int qx = qq < a.Tq ? qq : a.Tq - 1;
+            const float l = a.lse[rb + qx], d = a.delta[rb + qx];
+            rl = qq < a.Tq ? l : -INFINITY;
+            rd = qq < a.Tq ? d : 0.f;
+        }
+    };
+    auto put = [&](int buf) __attribute__((always_inline)) {
+        tile_store64(Qs[buf], tid, rq);
+        tile_store64(Os[buf], tid, ro);
+        if (tid < QT) { Ls[buf][tid] = rl; Ds[buf][tid] = rd; }
+    };
+    fetch(0);
+    put(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, q0 = t * QT;
+        if (t + 1 < ntiles) fetch(t + 1);
+        f32x4 s[4], dp[4];
+        tile_dot64<HT>(Qs[buf], kf, s, l15, g);          // s[f][r]: query q0 + f*16 + g*4 + r, key kj
+        tile_dot64<HT>(Os[buf], vf, dp, l15, g);
+        f32x4 pv[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const f32x4 L4 = *(const f32x4*)(&Ls[buf][f * 16 + g * 4]), D4 = *(const f32x4*)(&Ds[buf][f * 16 + g * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + f * 16 + g * 4 + r;
+                const float L = L4[r];
+                const bool ok = key_ok && L != -INFINITY;   // (queries past Tq carry L = -inf)
+                const float p = ok ? __expf(s[f][r] * a.scale - L) : 0.f;
+                float pd = p, dpe = dp[f][r];
+                if (a.drop.thresh) {
+                    const unsigned e = (unsigned)(rb + (qq < a.Tq ? qq : 0)) * (unsigned)a.Tk + (unsigned)(kj < a.Tk ? kj : 0);
+                    pd = cfm_drop(a.drop, e, p);
+                    dpe = cfm_drop(a.drop, e, dpe);
+                }
+                pv[f][r] = pd;
+                s[f][r] = p * (dpe - D4[r]) * a.scale;     // dS
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const u32x4 ph = pack8<HT>(pv[2 * k2], pv[2 * k2 + 1]), sh = pack8<HT>(s[2 * k2], s[2 * k2 + 1]);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                acc_v[fd] = HT::mfma(tr_frag64(Os[buf], k2, fd, l15, g), ph, acc_v[fd]);   // dV^T[d, key] += dO^T[d, q] P[q, key]
+                acc_k[fd] = HT::mfma(tr_frag64(Qs[buf], k2, fd, l15, g), sh, acc_k[fd]);   // dK^T[d, key] += Q'^T[d, q] dS[q, key]
+            }
+        }
+        if (t + 1 < ntiles) put(buf ^ 1);
+        __syncthreads();
+    }
+    if (kj < a.Tk) {
+        const int64_t ko = (int64_t)b * a.k_sb + (int64_t)kj * a.k_st + h * dk, vo = (int64_t)b * a.v_sb + (int64_t)kj * a.v_st + h * dk;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            store_row4(a.dkk, a.io_dt, ko + fd * 16 + g * 4, acc_k[fd]);
+            store_row4(a.dv, a.io_dt, vo + fd * 16 + g * 4, acc_v[fd]);
+        }
+    }
+}
+
+static bool g_attn_bwd_general_only = false;      // tests: force the general kernels
+
 template <typename HT, bool SPLIT>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char* n_dkv) {
     const double fl = 2.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
@@ -298,17 +526,37 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char
         CFM_LAUNCH(cfm_attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
         if (int rc = cfm_launch_status("cfm_attention_bwd (delta)")) return rc;
     }
+    bool fast = false;
+    if constexpr (!SPLIT) {
+        const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        fast = !g_attn_bwd_general_only && a.dk == 64 && a.io_dt == HT::kId && a.do_dt == HT::kId && (!a.mask || a.m_sq == 0) && a.q_st % 8 == 0 &&
+               a.k_st % 8 == 0 && a.v_st % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.dout);
+    }
     {
         CfmProfScope prof(n_dq, s, 3.0 * fl, by);
-        CFM_LAUNCH((cfm_attn_bwd_dq_kernel<HT, SPLIT>), dim3((unsigned)((a.Tq + QT - 1) / QT), (unsigned)a.H, (unsigned)a.B), dim3(256), 0, s, a);
+        const dim3 grid((unsigned)((a.Tq + QT - 1) / QT), (unsigned)a.H, (unsigned)a.B);
+        if constexpr (!SPLIT) {
+            if (fast) CFM_LAUNCH((cfm_attn_bwd_dq_fast_kernel<HT>), grid, dim3(256), 0, s, a);
+            else CFM_LAUNCH((cfm_attn_bwd_dq_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
+        } else {
+            CFM_LAUNCH((cfm_attn_bwd_dq_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
+        }
         if (int rc = cfm_launch_status("cfm_attention_bwd (dq)")) return rc;
     }
     CfmProfScope prof(n_dkv, s, 4.0 * fl, by);
-    CFM_LAUNCH((cfm_attn_bwd_dkv_kernel<HT, SPLIT>), dim3((unsigned)((a.Tk + KT - 1) / KT), (unsigned)a.H, (unsigned)a.B), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((a.Tk + KT - 1) / KT), (unsigned)a.H, (unsigned)a.B);
+    if constexpr (!SPLIT) {
+        if (fast) CFM_LAUNCH((cfm_attn_bwd_dkv_fast_kernel<HT>), grid, dim3(256), 0, s, a);
+        else CFM_LAUNCH((cfm_attn_bwd_dkv_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
+    } else {
+        CFM_LAUNCH((cfm_attn_bwd_dkv_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
+    }
     return cfm_launch_status("cfm_attention_bwd (dkv)");
 }
 
 }  // namespace
+
+extern "C" void cfm_attention_bwd_force_general(int32_t on) { g_attn_bwd_general_only = on != 0; }
 
 extern "C" int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d && d->q && d->k && d->v && d->out && d->dout && d->lse && d->grad_q && d->grad_k && d->grad_v && d->delta, "cfm_attention_bwd: null pointer");

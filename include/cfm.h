@@ -581,6 +581,10 @@ typedef struct {
     uint32_t drop_seed;
 } cfm_attn_bwd_desc;
 int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream);
+/* d_k = 64 with 16-bit, 16-byte-aligned q / k / v / dO rows and no mask or a key-validity mask (m_sq == 0) takes fast kernels (tiles staged as
+ * they lie in memory, transposed operands read with ds_read_b64_tr_b16, next tile prefetched) -- bit-identical to the general ones, which
+ * this switch forces (tests). */
+void cfm_attention_bwd_force_general(int32_t on);
 
 /* CTC backward (csrc/ctc.hip): cfm_ctc_nll_train is cfm_ctc_nll that also keeps log alpha (alpha f32 [B,T,2*Umax+2]), the per-frame
  * log-sum-exp (lse f32 [B,T]) and nll_shifted f32 [B] (-log P of the per-frame-shifted recursion: the posteriors' normaliser); cfm_ctc_grad runs the beta recursion and writes d loss / d logits [B,T,ld] = gscale[b] * (softmax - occupancy)

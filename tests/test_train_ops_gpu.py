@@ -460,3 +460,39 @@ def test_layernorm_bwd_fused_equals_separate_launches(accumulate):
         assert float((db - base_b - db_ref).abs().max()) < 1e-5 * float(db_ref.abs().max()) + 1e-5
     else:
         assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("mkind,drop", [("none", None), ("pad", None), ("pad", (0.1, 991))])
+def test_attention_backward_fast_kernels_are_bit_identical_to_general(cfm, mode, mkind, drop):
+    """d_k = 64 with 16-bit rows takes the fast backward kernels (tiles staged as they lie in memory, transposed operands by
+    ds_read_b64_tr_b16, prefetched tiles); cfm_attention_bwd_force_general switches them off: same products in the same order -- identical
+    bits, on a ragged batch whose length is not a multiple of the 64-row tile."""
+    B, T, H, dk = 3, 217, 4, 64
+    D = H * dk
+    dt = W_DT[mode]
+    mma = cfm.BF16 if mode == "bf16" else cfm.F16
+    qkv = rnd((B * T, 3 * D), 61, 0.7).to(dt)
+    dout = rnd((B * T, D), 62).to(dt)
+    mask = None
+    if mkind == "pad":
+        mask = (torch.arange(T)[None, :] < torch.tensor([T, 150, 64])[:, None]).cuda()[:, None, :]
+    m8 = None if mask is None else mask.contiguous().view(torch.uint8)
+    mstr = (0, 0) if mask is None else (T, 0)
+    st = (T * 3 * D, 3 * D)
+    ctx = torch.empty((B * T, D), dtype=dt, device="cuda")
+    lse = torch.empty((B, H, T), dtype=torch.float32, device="cuda")
+    cfm.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], B, H, T, T, dk, st, st + (dk,), st + (dk,), ctx, mask=m8, mask_str=mstr, mma_code=mma, lse=lse, drop=drop)
+    res = []
+    try:
+        for force in (0, 1):
+            cfm.lib().cfm_attention_bwd_force_general(force)
+            dqkv = torch.zeros_like(qkv)
+            cfm.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ctx, dout, lse, B, H, T, T, dk, st, st, st, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], mask=m8, mask_str=mstr,
+                              mma_code=mma, drop=drop)
+            torch.cuda.synchronize()
+            res.append(dqkv)
+    finally:
+        cfm.lib().cfm_attention_bwd_force_general(0)
+    assert float(res[0].float().abs().max()) > 1e-3
+    assert torch.equal(res[0].view(torch.int16), res[1].view(torch.int16)), float((res[0].float() - res[1].float()).abs().max())
