@@ -604,7 +604,10 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
         const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
         const long t64x128 = (long)((a.M - a.m_begin + 63) / 64) * ((a.N + 127) / 128);
         tile = t128 >= 224 ? 1 : (t64x128 >= 224 ? 2 : 3);
-        if constexpr (!SPLIT) {                   // narrow outputs (N = D) at training batch sizes: 64 x 64 tiles fill under half the CUs
+        if constexpr (!SPLIT) {
+            // short K and one to two rounds of 128 x 128 tiles (a feed-forward's first product at a training micro-batch: 304 tiles of 4 K steps,
+            // the second round nearly empty): 32 x 64 tiles, measured 11.2 vs 14.9 us at M = 2 380, N = 2 048 (scripts/bench_gemm_tiles.py)
+            if (tile == 1 && a.K <= 256 && t128 < 512) tile = 5;                   // narrow outputs (N = D) at training batch sizes: 64 x 64 tiles fill under half the CUs
             const long t64 = (long)((a.M - a.m_begin + 63) / 64) * ((a.N + 63) / 64), t32x64 = (long)((a.M - a.m_begin + 31) / 32) * ((a.N + 63) / 64);
             if (tile == 3 && t64 < 192 && t32x64 >= 96) tile = 5;
         }
