@@ -523,6 +523,66 @@ def joint_forward(P, prefix, enc_out, pred_out, pre_project=True):
     return linear(torch.tanh(enc_out + pred_out), _w(P, prefix, "ffn_out.weight"), _w(P, prefix, "ffn_out.bias"))
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# RNN-T greedy search (test infrastructure, like everything in this file): the reference's basic_greedy_search,
+# /root/reference/src/model.py:215-269, restated for ONE utterance with the predictor of src/predictor.py:76-86 (Embedding -> LSTM ->
+# Linear, one symbol per call) and the joint of src/joint.py:20-38.  model.py itself cannot be imported here (torchaudio is absent,
+# SURVEY.md 8c): the LOOP is pinned by this restatement only; the predictor / joint STEP it calls is pinned by tokens generated with the
+# reference's own modules (tests/golden/greedy.npz, tests/golden/make_golden.py gen_greedy).
+# ----------------------------------------------------------------------------------------------------------------------
+def _lstm_cell(P, prefix, layer, x, h, c):
+    w_ih, w_hh = _w(P, prefix, "rnn.weight_ih_l%d" % layer), _w(P, prefix, "rnn.weight_hh_l%d" % layer)
+    b_ih, b_hh = _w(P, prefix, "rnn.bias_ih_l%d" % layer), _w(P, prefix, "rnn.bias_hh_l%d" % layer)
+    gates = x @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+    i, f, g, o = gates.chunk(4, dim=-1)
+    c1 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    return torch.sigmoid(o) * torch.tanh(c1), c1
+
+
+def predictor_step(P, prefix, token, h, c):
+    """predictor.py:76-86 with padding = 0: token () int, h / c (L, H) -> (projection output (P,), h', c')."""
+    x = _w(P, prefix, "embed.weight")[int(token)]
+    hs, cs = [], []
+    for l in range(h.shape[0]):
+        x, c1 = _lstm_cell(P, prefix, l, x, h[l], c[l])
+        hs.append(x)
+        cs.append(c1)
+    return linear(x, _w(P, prefix, "projection.weight"), _w(P, prefix, "projection.bias")), torch.stack(hs), torch.stack(cs)
+
+
+def rnnt_greedy_search(P, pred_prefix, joint_prefix, enc_out, enc_len, blank=0, n_steps=64, token=None, state=None):
+    """model.py:215-269 for one utterance: enc_out (T', E), enc_len valid frames.  Returns (tokens, (token, (h, c)))."""
+    dt = enc_out.dtype
+    L, H = _num_lstm_layers(P, pred_prefix), _w(P, pred_prefix, "rnn.weight_hh_l0").shape[1]
+    h, c = (torch.zeros((L, H), dtype=dt), torch.zeros((L, H), dtype=dt)) if state is None else (state[0].to(dt), state[1].to(dt))
+    token = blank if token is None else int(token)
+    t, hyps, prev_nonblank, per_frame = 0, [], True, 0
+    pred_out, new_h, new_c = None, h, c
+    while t < int(enc_len):                                            # model.py:243
+        if prev_nonblank:                                              # :245-248
+            pred_out, new_h, new_c = predictor_step(P, pred_prefix, token, h, c)
+        logits = joint_forward(P, joint_prefix, enc_out[t][None, None, :], pred_out[None, None, :]).reshape(-1)   # :250-252
+        k = int(torch.argmax(torch.log_softmax(logits, dim=-1)))       # :254
+        if k != blank:                                                 # :255-261
+            hyps.append(k)
+            prev_nonblank = True
+            per_frame += 1
+            token, h, c = k, new_h, new_c
+        if k == blank or per_frame >= n_steps:                         # :263-267
+            if k == blank:
+                prev_nonblank = False
+            t += 1
+            per_frame = 0
+    return hyps, (token, (h, c))
+
+
+def _num_lstm_layers(P, prefix):
+    n = 0
+    while (prefix + "rnn.weight_ih_l%d" % n) in P:
+        n += 1
+    return n
+
+
 def encoder_flops_per_utt(T, F=80, D=256, FF=2048, K=15, L=12):
     """2*MAC of the GEMM/conv/attention contractions of one utterance's forward (elementwise/LN excluded)."""
     t1, f1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1

@@ -315,6 +315,73 @@ def gen_joint():
     save("joint", arrays, dict(cases=cases))
 
 
+GREEDY_CASES = [   # name, V, E (encoder dim), P (predictor output), J, embed, hidden, layers, T', n_steps, seed
+    ("small", 73, 144, 96, 64, 48, 80, 2, 23, 3, 51),
+    ("cap1", 73, 144, 96, 64, 48, 80, 1, 17, 1, 52),
+    ("config4", 5002, 512, 512, 512, 256, 256, 2, 31, 4, 53),
+]
+
+
+def greedy_modules(pred_cls, joint_cls, V, E, Pd, J, emb, hid, layers, seed):
+    """predictor + joint with synthetic parameters (tests/synth.py: load_synth_, then greedy_joint_ so that blanks and symbols alternate)."""
+    pr = pred_cls(V, emb, Pd, hid, 0.1, layers).eval()
+    jn = joint_cls(V, E, Pd, J).eval()
+    synth.load_synth_(pr, seed)
+    synth.load_synth_(jn, seed + 1)
+    synth.greedy_joint_(jn, V)
+    return pr, jn
+
+
+def gen_greedy():
+    """Tokens of the greedy search (model.py:215-269) with the REFERENCE's RNNPredictor.forward_step (predictor.py:76-86) and
+    TransducerJoint.forward (joint.py:20-38) doing every step; the loop around them is restated here line by line because model.py does not
+    import in this container (torchaudio).  Also a continued search: the second half of an utterance started from the first half's
+    (token, LSTM state), as greedy_search_streaming_app does (model.py:186-196)."""
+    import joint as ref_joint  # noqa: E402
+    import predictor as ref_predictor  # noqa: E402
+
+    def search(pr, jn, enc, n_steps, token=None, cache=None, blank=0):
+        padding = torch.zeros(1, 1)
+        tok = torch.tensor([blank]).reshape(1, 1) if token is None else token
+        cache = pr.init_state(tok) if cache is None else cache
+        t, hyps, prev, per_frame, pred_out, new_cache = 0, [], True, 0, None, None
+        while t < enc.size(1):
+            if prev:
+                pred_out, new_cache = pr.forward_step(tok, padding, cache)
+            k = jn(enc[:, t:t + 1, :], pred_out).log_softmax(dim=-1).argmax(dim=-1).squeeze()
+            if k != blank:
+                hyps.append(int(k))
+                prev = True
+                per_frame += 1
+                tok = k.reshape(1, 1)
+                cache = new_cache
+            if k == blank or per_frame >= n_steps:
+                if k == blank:
+                    prev = False
+                t += 1
+                per_frame = 0
+        return hyps, tok, cache
+
+    arrays, cases = {}, []
+    for name, V, E, Pd, J, emb, hid, layers, T, n_steps, seed in GREEDY_CASES:
+        pr, jn = greedy_modules(ref_predictor.RNNPredictor, ref_joint.TransducerJoint, V, E, Pd, J, emb, hid, layers, seed)
+        lens = [T, T - 5, max(1, T // 2)]
+        with torch.no_grad():
+            for u, n in enumerate(lens):
+                enc = torch.from_numpy(synth.normal(seed + 10 + u, (1, T, E), 1.0))
+                hyps, _, _ = search(pr, jn, enc[:, :n], n_steps)
+                arrays["%s_utt%d" % (name, u)] = np.asarray(hyps, dtype=np.int64)
+                if u == 0:                                              # the same utterance in two calls with carried state
+                    a, tok, cache = search(pr, jn, enc[:, :T // 2], n_steps)
+                    b, _, _ = search(pr, jn, enc[:, T // 2:], n_steps, token=tok, cache=cache)
+                    arrays["%s_utt0_first" % name] = np.asarray(a, dtype=np.int64)
+                    arrays["%s_utt0_second" % name] = np.asarray(b, dtype=np.int64)
+                    # (a + b differs from hyps only through the "previous output was non-blank" flag, which a new call resets)
+        cases.append(dict(name=name, V=V, E=E, P=Pd, J=J, embed=emb, hidden=hid, layers=layers, T=T, n_steps=n_steps, seed=seed, lens=lens))
+        print("  greedy %-8s tokens per utterance: %s" % (name, [len(arrays["%s_utt%d" % (name, u)]) for u in range(3)]))
+    save("greedy", arrays, dict(cases=cases))
+
+
 # ----------------------------------------------------------------------------- training (config 3): losses and gradients
 GRAD_SAMPLES = 1024
 
@@ -443,4 +510,5 @@ if __name__ == "__main__":
     gen_encoders()
     gen_ctc()
     gen_joint()
+    gen_greedy()
     gen_train()

@@ -25,6 +25,11 @@ def _fill_one(rs, name, shape):
     if leaf in ("pos_bias_u", "pos_bias_v"):
         lim = float(np.sqrt(6.0 / (shape[0] + shape[1])))
         return rs.uniform(-lim, lim, n).reshape(shape).astype(np.float32)
+    if leaf.startswith("weight_ih_l") or leaf.startswith("weight_hh_l"):      # nn.LSTM matrices (4H, in): torch's own U(-1/sqrt(H), 1/sqrt(H))
+        lim = 1.0 / float(np.sqrt(shape[0] // 4))
+        return rs.uniform(-lim, lim, n).reshape(shape).astype(np.float32)
+    if leaf.startswith("bias_ih_l") or leaf.startswith("bias_hh_l"):
+        return rs.uniform(-0.1, 0.1, n).reshape(shape).astype(np.float32)
     if leaf == "weight" and len(shape) == 1:          # LayerNorm / BatchNorm gain
         return (1.0 + 0.1 * rs.standard_normal(n)).reshape(shape).astype(np.float32)
     if leaf == "bias":
@@ -60,3 +65,16 @@ def fbank(seed, batch, frames, dim=80):
 def normal(seed, shape, scale=1.0):
     rs = np.random.RandomState(seed)
     return (scale * rs.standard_normal(tuple(shape))).astype(np.float32)
+
+
+def greedy_joint_(joint, vocab_size):
+    """After load_synth_: reshape a joint's synthetic parameters so that a greedy search over them is not degenerate (with the plain
+    synthetic values the argmax over V classes is almost never the blank and hardly depends on the predictor: every frame would emit
+    symbols up to the per-frame cap) -- predictor path x 2, encoder path x 0.7, blank bias raised.  Shared by the golden generator and
+    the tests, like every other synthetic value."""
+    import torch
+    with torch.no_grad():
+        joint.pred_ffn.weight.mul_(2.0)
+        joint.enc_ffn.weight.mul_(0.7)
+        joint.ffn_out.bias[0] += 0.6 if vocab_size < 1000 else 0.8
+    return joint
