@@ -510,5 +510,5 @@ if __name__ == "__main__":
     gen_encoders()
     gen_ctc()
     gen_joint()
-    gen_greedy()
     gen_train()
+    gen_greedy()          # last: the generators above keep the torch RNG stream they were committed with
