@@ -253,17 +253,20 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
 // a ds_read_b64_tr_b16 group would otherwise share banks.  Rows past M read a 16-byte zero.  64 x 64 tiles only, no row mask.
 __device__ __attribute__((aligned(16))) unsigned cfm_tn_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <typename HT, bool CONV, int TILE>
-__global__ __launch_bounds__(256, TILE == 64 ? 2 : 1) void cfm_gemm_tn_dma_kernel(const TnArgs g) {
+template <typename HT, bool CONV, int TILE, int NG>
+__global__ __launch_bounds__(256 * NG, 1) void cfm_gemm_tn_dma_kernel(const TnArgs g) {
     // Measured (scripts/bench_gemm_tn_splits.py, M = 2 380): ONE 64 x 64 workgroup walks its rows at ~0.6 us per 64-row chunk whatever is in
     // flight (8 buffers instead of 4: 27 us instead of 24 for 2 380 rows) -- with one wavefront per SIMD the chunk's own chain of address
     // arithmetic, barrier, 16 transposed reads and 8 dependent MFMAs is exposed; every split added costs ~1.5-5 us of atomics; the
     // 128 x 128 tile is slower at these sizes (36 vs 24 us for a feed-forward weight).  Hence the split rule in cfm_gemm_tn.
-    constexpr int MCH = 64, NBUF = 4, FR = TILE / 32;
+    // NG = 2 (the 64 x 64 tile): TWO groups of four wavefronts share the tile -- a chunk is 128 rows, staged by all eight, group 0 multiplies
+    // its first 64 rows and group 1 the other 64 into accumulators of their own, which meet through LDS after the last chunk: the same
+    // instruction chain per iteration covers twice the rows (two wavefronts per SIMD), without a second split's atomics.
+    constexpr int MCH = 64 * NG, NBUF = 4, FR = TILE / 32;
     constexpr int RB = TILE * 2;                       // bytes of a tile row (128 or 256)
     constexpr int PPR = TILE / 8;                      // 16-byte pieces per row
     constexpr int RPQ = 64 / PPR;                      // rows per 1 KB request (8 or 4)
-    constexpr int NQ = MCH / RPQ / 4;                  // requests per wavefront, operand and chunk (2 or 4)
+    constexpr int NQ = MCH / RPQ / (4 * NG);           // requests per wavefront, operand and chunk (2 or 4)
     constexpr int OPB = MCH * RB;                      // bytes of one operand chunk (8 or 16 KB)
     constexpr int INFL = (NBUF - 2) * 2 * NQ;          // requests of the NBUF - 2 chunks that may stay in flight behind the one being waited for
     constexpr int WAIT = 0x0F70 | (INFL & 0xF) | ((INFL >> 4) << 14);   // s_waitcnt vmcnt(INFL)
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256, TILE == 64 ? 2 : 1) void cfm_gemm_tn_dma_kerne
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = lane >> 4, l15 = lane & 15;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
     const int tiles_k = (g.K + TILE - 1) / TILE;
     const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
     const int n0 = tile_n * TILE, k0 = tile_k * TILE;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256, TILE == 64 ? 2 : 1) void cfm_gemm_tn_dma_kerne
     int64_t b_koff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        srow[q] = RPQ * (wave + 4 * q) + lane / PPR;
+        srow[q] = RPQ * (wave + 4 * NG * q) + lane / PPR;
         scol[q] = ((lane % PPR) ^ swz(srow[q])) * 8;                 // (128-wide rows: the XOR stays inside the row's first / second 8 pieces)
         a_ok[q] = n0 + scol[q] < g.N;
         b_ok[q] = k0 + scol[q] < g.K;
@@ -336,8 +339,8 @@ __global__ __launch_bounds__(256, TILE == 64 ? 2 : 1) void cfm_gemm_tn_dma_kerne
             const char* pb = (const char*)((const u16*)g.B + boff);
             pa = (row_ok && a_ok[q]) ? pa : zsrc;
             pb = (row_ok && b_ok[q]) ? pb : zsrc;
-            glds16(pa, At + (wave + 4 * q) * 1024);
-            glds16(pb, At + OPB + (wave + 4 * q) * 1024);
+            glds16(pa, At + (wave + 4 * NG * q) * 1024);
+            glds16(pb, At + OPB + (wave + 4 * NG * q) * 1024);
         }
     };
     // transposed fragment: 16 columns from c0, the 32 rows of m-step ms; 8-byte piece (l15 & 3) of rows 4 g4 + (l15 >> 2) and + 16
@@ -376,7 +379,8 @@ __global__ __launch_bounds__(256, TILE == 64 ? 2 : 1) void cfm_gemm_tn_dma_kerne
         const unsigned char* const At = smem + (c % NBUF) * (2 * OPB);
         const unsigned char* const Bt = At + OPB;
 #pragma unroll
-        for (int ms = 0; ms < MCH / 32; ++ms) {
+        for (int msl = 0; msl < 2; ++msl) {
+            const int ms = grp * 2 + msl;                // this group's 64 rows of the chunk
             u32x4 af[FR], bf[FR];
 #pragma unroll
             for (int i = 0; i < FR; ++i) af[i] = frag(At, ms, wr * (TILE / 2) + i * 16);
@@ -393,6 +397,26 @@ __global__ __launch_bounds__(256, TILE == 64 ? 2 : 1) void cfm_gemm_tn_dma_kerne
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // the zero-source requests of the tail: no DMA may still be writing LDS when the workgroup ends
+    if constexpr (NG == 2) {                             // group 1's sums join group 0's (fixed order), group 0 writes the tile
+        __syncthreads();
+        f32x4* const xch = (f32x4*)smem + ((wave & 3) * (FR * FR + FR)) * 64 + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+#pragma unroll
+                for (int j = 0; j < FR; ++j) xch[(i * FR + j) * 64] = acc[i][j];
+                xch[(FR * FR + i) * 64] = acs[i];
+            }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+#pragma unroll
+            for (int j = 0; j < FR; ++j) acc[i][j] += xch[(i * FR + j) * 64];
+            acs[i] += xch[(FR * FR + i) * 64];
+        }
+    }
 
 #pragma unroll
     for (int i = 0; i < FR; ++i) {
@@ -427,13 +451,13 @@ template <typename HT>
 int launch_tn_dma(const TnArgs& a, bool conv, int tile, int splits, hipStream_t s, const char* name) {
     const int tiles = ((a.N + tile - 1) / tile) * ((a.K + tile - 1) / tile);
     CfmProfScope prof(name, s, 2.0 * a.M * (double)a.N * a.K, (double)a.M * (a.N + a.K) * 2 + 4.0 * a.N * a.K);
-    const dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+    const dim3 grid((unsigned)tiles, (unsigned)splits);
     if (tile == 128) {
-        if (conv) CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, true, 128>), grid, block, 0, s, a);
-        else CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, false, 128>), grid, block, 0, s, a);
+        if (conv) CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, true, 128, 1>), grid, dim3(256), 0, s, a);
+        else CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, false, 128, 1>), grid, dim3(256), 0, s, a);
     } else {
-        if (conv) CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, true, 64>), grid, block, 0, s, a);
-        else CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, false, 64>), grid, block, 0, s, a);
+        if (conv) CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, true, 64, 2>), grid, dim3(512), 0, s, a);
+        else CFM_LAUNCH((cfm_gemm_tn_dma_kernel<HT, false, 64, 2>), grid, dim3(512), 0, s, a);
     }
     return cfm_launch_status(name);
 }
@@ -486,7 +510,7 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     const bool a32 = d->a_dtype == CFM_F32, b32 = d->b_dtype == CFM_F32;
     // 16-bit operands without a row mask: the LDS-DMA kernel (64-row chunks, several in flight)
     const bool dma = !a32 && !b32 && !d->split && !d->row_mask;
-    const int mch = dma ? 64 : (tile == 64 ? 2 * mch128 : mch128);
+    const int mch = dma ? (tile == 64 ? 128 : 64) : (tile == 64 ? 2 * mch128 : mch128);
     const int chunks = (d->M + mch - 1) / mch;
     const int tiles = ((d->N + tile - 1) / tile) * ((d->K + tile - 1) / tile);
     int splits = d->splits;
