@@ -16,6 +16,9 @@
 //     slab) so that a lane ends up with 16 consecutive channels of its row: two 16-byte LDS writes, conflict-free under the tile's XOR
 //     swizzle (position p of row r holds chunk p ^ ((r >> 1) & 7), as gemm256.hip);
 //   * conv1's weight fragments for all C channels live in an 8 KB LDS table built once per workgroup;
+//   * (measured: a third weight buffer with two K tiles in flight -- asm-issued LDS-DMA, counted waits -- does NOT help the 96-row tail tile: 48 vs
+//     45 us.  Its K step is not waiting for the DMA but paying fixed per-step costs that do not shrink with the tile: the 32 KB weight tile
+//     through the CU's vector-memory path, 8 + 6 fragment reads per wavefront, the barrier; ~1.25 us per step whatever is in flight.)
 //   * FM = 16-row fragments per wavefront along M: tiles of 32 FM rows.  The host runs whole rounds of 256-row tiles and gives the last
 //     partial round to a smaller FM so that it, too, is one workgroup per CU (the two-kernel path did the same with 128 x 128 tiles).
 #include <string>
