@@ -218,7 +218,23 @@ constexpr int DWT = 16;
 constexpr int DWK = 15;                                     // taps (the only kernel size on the path, encoder.py:38 kernel_size=15)
 constexpr int DWW = DWT + DWK - 1;
 
-__global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __restrict__ g, int g_dt, const float* __restrict__ w, const float* __restrict__ bias,
+// The element types of g / dg are TEMPLATE arguments: with a run-time dtype every one of the 30 window loads sits behind a branch, the compiler
+// waits at each join and the loads of a thread go out one memory latency after the other (28 us per launch at a config-3 micro-batch).
+template <int GDT>
+__device__ __forceinline__ float ld_t(const void* p, int64_t i) {
+    if constexpr (GDT == CFM_F32) return ((const float*)p)[i];
+    else if constexpr (GDT == CFM_BF16) return BF16::to_f32(((const u16*)p)[i]);
+    else return F16::to_f32(((const u16*)p)[i]);
+}
+template <int GDT>
+__device__ __forceinline__ void st_t(void* p, int64_t i, float v) {
+    if constexpr (GDT == CFM_F32) ((float*)p)[i] = v;
+    else if constexpr (GDT == CFM_BF16) ((u16*)p)[i] = BF16::from_f32(v);
+    else ((u16*)p)[i] = F16::from_f32(v);
+}
+
+template <int GDT>
+__global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias,
                                                                float* __restrict__ c_out, float* __restrict__ ws, int T, int D) {
     const int b = blockIdx.y, t0 = blockIdx.x * DWT;
     const int nblk_t = gridDim.x;
@@ -228,7 +244,9 @@ __global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __res
 #pragma unroll
         for (int i = 0; i < DWW; ++i) {
             const int t = t0 - (DWK - 1) / 2 + i;
-            win[i] = (t >= 0 && t < T) ? load_as_f32(g, ub + (int64_t)t * D + c, g_dt) : 0.f;
+            const bool in = t >= 0 && t < T;
+            const float gv = ld_t<GDT>(g, ub + (int64_t)(in ? t : 0) * D + c);      // unconditional load, selected afterwards
+            win[i] = in ? gv : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < DWK; ++k) wk[k] = w[c * DWK + k];
@@ -324,20 +342,28 @@ __global__ void cfm_bn_silu_apply_kernel(const float* __restrict__ c, const floa
 
 // dy = ds * silu'(c*scale + shift) -> dy_out (f32); per-workgroup sums over 64 rows of dy and dy * chat -> ws[blk][2][D]
 constexpr int BNB_ROWS = 16;
-__global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __restrict__ ds, int ds_dt, const float* __restrict__ c, const float* __restrict__ stats,
+template <int SDT>
+__global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __restrict__ ds, const float* __restrict__ c, const float* __restrict__ stats,
                                                               float* __restrict__ dy_out, float* __restrict__ ws, int64_t M, int D) {
     const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
     for (int ch = threadIdx.x; ch < D; ch += 256) {
         const float mean = stats[ch], rstd = stats[D + ch], sc = stats[2 * D + ch], sh = stats[3 * D + ch];
         float s1 = 0.f, s2 = 0.f;
+        float cv[BNB_ROWS], dv[BNB_ROWS];
+#pragma unroll
+        for (int r = 0; r < BNB_ROWS; ++r) {                 // all loads first (rows past M: clamped address, zeroed value)
+            const int64_t row = r0 + r < M ? r0 + r : M - 1;
+            cv[r] = c[row * D + ch];
+            dv[r] = ld_t<SDT>(ds, row * D + ch);
+        }
+#pragma unroll
         for (int r = 0; r < BNB_ROWS; ++r) {
-            const int64_t row = r0 + r;
-            if (row >= M) break;
-            const float cv = c[row * D + ch];
-            const float dyv = load_as_f32(ds, row * D + ch, ds_dt) * dsilu_(cv * sc + sh);
-            dy_out[row * D + ch] = dyv;
-            s1 += dyv;
-            s2 += dyv * ((cv - mean) * rstd);
+            if (r0 + r < M) {
+                const float dyv = dv[r] * dsilu_(cv[r] * sc + sh);
+                dy_out[(r0 + r) * D + ch] = dyv;
+                s1 += dyv;
+                s2 += dyv * ((cv[r] - mean) * rstd);
+            }
         }
         ws[((int64_t)blockIdx.x * 2 + 0) * D + ch] = s1;
         ws[((int64_t)blockIdx.x * 2 + 1) * D + ch] = s2;
@@ -346,9 +372,10 @@ __global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __rest
 
 // dc = gamma*rstd * (dy - k1 - chat*k2), then the depthwise conv's backward: dg[t] = sum_k w[k] dc[t-k+7] and per-workgroup partials of
 // dw[k] = sum dc[t] g[t+k-7], db = sum dc  -> ws[blk][16][D]
+template <int GDT, int ODT>
 __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ c, const float* __restrict__ stats,
-                                                             const float* __restrict__ coef, const void* __restrict__ g, int g_dt,
-                                                             const float* __restrict__ w, void* __restrict__ dg_out, int dg_dt, float* __restrict__ ws,
+                                                             const float* __restrict__ coef, const void* __restrict__ g,
+                                                             const float* __restrict__ w, void* __restrict__ dg_out, float* __restrict__ ws,
                                                              int T, int D) {
     const int b = blockIdx.y, t0 = blockIdx.x * DWT;
     const int64_t ub = (int64_t)b * T * D;
@@ -364,7 +391,8 @@ __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __rest
             const int64_t o = ub + (int64_t)(in ? t : 0) * D + ch;
             const float chat = (c[o] - mean) * rstd;
             dcw[i] = in ? sc * (dy[o] - k1 - chat * k2) : 0.f;
-            gw[i] = in ? load_as_f32(g, o, g_dt) : 0.f;
+            const float gv = ld_t<GDT>(g, o);
+            gw[i] = in ? gv : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < DWK; ++k) wk[k] = w[ch * DWK + k];
@@ -375,7 +403,7 @@ __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __rest
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < DWK; ++k) a = fmaf(wk[k], dcw[j + DWK - 1 - k], a);
-                store_from_f32(dg_out, ub + (int64_t)t * D + ch, dg_dt, a);
+                st_t<ODT>(dg_out, ub + (int64_t)t * D + ch, a);
             }
         }
         float db = 0.f;
@@ -715,7 +743,10 @@ extern "C" int cfm_dwconv_bn_train(const void* g, int32_t g_dtype, const float* 
     const int64_t M = (int64_t)B * T;
     {
         CfmProfScope prof("dwconv_stats", s, 2.0 * M * D * DWK, (double)M * D * (cfm_elt_size(g_dtype) + 4.0));
-        CFM_LAUNCH(cfm_dwconv_stats_kernel, dim3((unsigned)nblk_t, (unsigned)B), dim3(256), 0, s, g, g_dtype, w, dw_bias, c_out, ws, T, D);
+        const dim3 grid((unsigned)nblk_t, (unsigned)B);
+        if (g_dtype == CFM_BF16) CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_BF16>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, T, D);
+        else if (g_dtype == CFM_F16) CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_F16>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, T, D);
+        else CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_F32>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, T, D);
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train (conv)")) return rc;
     }
     {
@@ -747,7 +778,9 @@ extern "C" int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, con
     float* coef = ws + (int64_t)nb * 2 * D;                                 // [2][D] behind the BatchNorm partials
     {
         CfmProfScope prof("bn_silu_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(ds_dtype)));
-        CFM_LAUNCH(cfm_bn_silu_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, ds, ds_dtype, c, stats, dy_ws, ws, M, D);
+        if (ds_dtype == CFM_BF16) CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_BF16>), dim3((unsigned)nb), dim3(256), 0, s, ds, c, stats, dy_ws, ws, M, D);
+        else if (ds_dtype == CFM_F16) CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_F16>), dim3((unsigned)nb), dim3(256), 0, s, ds, c, stats, dy_ws, ws, M, D);
+        else CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_F32>), dim3((unsigned)nb), dim3(256), 0, s, ds, c, stats, dy_ws, ws, M, D);
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (silu/bn sums)")) return rc;
     }
     {
@@ -759,8 +792,17 @@ extern "C" int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, con
     float* part = coef + 2 * (int64_t)D;                                    // depthwise partials [blk][16][D] behind coef
     {
         CfmProfScope prof("dwconv_bwd", s, 4.0 * M * D * DWK, (double)M * D * (8.0 + cfm_elt_size(g_dtype) + cfm_elt_size(dg_dtype)));
-        CFM_LAUNCH(cfm_dwconv_bwd_kernel, dim3((unsigned)nblk_t, (unsigned)B), dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, g_dtype, w,
-                   dg_out, dg_dtype, part, T, D);
+        const dim3 grid((unsigned)nblk_t, (unsigned)B);
+#define CFM_DWB(GD, OD) CFM_LAUNCH((cfm_dwconv_bwd_kernel<GD, OD>), grid, dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, w, dg_out, part, T, D)
+        if (g_dtype == CFM_BF16 && dg_dtype == CFM_BF16) CFM_DWB(CFM_BF16, CFM_BF16);
+        else if (g_dtype == CFM_F16 && dg_dtype == CFM_F16) CFM_DWB(CFM_F16, CFM_F16);
+        else if (g_dtype == CFM_F32 && dg_dtype == CFM_F32) CFM_DWB(CFM_F32, CFM_F32);
+        else if (g_dtype == CFM_BF16 && dg_dtype == CFM_F32) CFM_DWB(CFM_BF16, CFM_F32);
+        else if (g_dtype == CFM_F16 && dg_dtype == CFM_F32) CFM_DWB(CFM_F16, CFM_F32);
+        else if (g_dtype == CFM_F32 && dg_dtype == CFM_BF16) CFM_DWB(CFM_F32, CFM_BF16);
+        else if (g_dtype == CFM_F32 && dg_dtype == CFM_F16) CFM_DWB(CFM_F32, CFM_F16);
+        else return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_dwconv_bn_train_bwd: g / dg dtype pair %d / %d", g_dtype, dg_dtype);
+#undef CFM_DWB
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (conv)")) return rc;
     }
     CfmProfScope prof("dwconv_bwd_finalize", s, 0.0, (double)B * nblk_t * 16 * D * 4);
