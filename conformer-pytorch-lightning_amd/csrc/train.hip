@@ -501,7 +501,8 @@ __global__ void cfm_col2im_relu_bwd_kernel(const void* __restrict__ dcol, int dc
 // first convolution: dw1[tap][c] = sum_{b,t1,f1} dh1[b,t1,f1,c] * xin[b,2t1+kt,2f1+kf], db1[c] = sum dh1 -- workgroup = (8 output rows t1 of
 // one utterance), thread = channel; the 3 input rows of each t1 go through LDS (every thread reads the same taps)
 constexpr int C1_TB = 8;
-__global__ __launch_bounds__(256) void cfm_conv1_wgrad_kernel(const void* __restrict__ dh1, int d_dt, const float* __restrict__ x, const float* __restrict__ cm,
+template <int DDT>
+__global__ __launch_bounds__(256) void cfm_conv1_wgrad_kernel(const void* __restrict__ dh1, const float* __restrict__ x, const float* __restrict__ cm,
                                                               const float* __restrict__ ci, float* __restrict__ ws, int T, int F, int T1, int F1, int C) {
     extern __shared__ float xr[];                           // [3][F]
     const int b = blockIdx.y, tb = blockIdx.x * C1_TB;
@@ -521,22 +522,35 @@ __global__ __launch_bounds__(256) void cfm_conv1_wgrad_kernel(const void* __rest
             xr[i] = v;
         }
         __syncthreads();
-        for (int f1 = 0; f1 < F1; ++f1) {
-            float taps[9];
+        // 8 positions per trip, their gradient values requested together and unconditionally (clamped index, selected afterwards): one value
+        // per trip behind a run-time dtype branch made every one of the T1-row's F1 loads wait out its own latency (157 us per launch)
+        const int c0 = (int)threadIdx.x < C ? (int)threadIdx.x : 0, c1 = (int)threadIdx.x + 256 < C ? (int)threadIdx.x + 256 : 0;
+        const bool two = C > 256;
+        for (int fb = 0; fb < F1; fb += 8) {
+            float d0[8], d1[8];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) taps[k] = xr[(k / 3) * F + 2 * f1 + (k % 3)];
-            const int64_t o = (((int64_t)b * T1 + t1) * F1 + f1) * C;
-            if ((int)threadIdx.x < C) {
-                const float d = load_as_f32(dh1, o + threadIdx.x, d_dt);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) acc0[k] = fmaf(d, taps[k], acc0[k]);
-                acc0[9] += d;
+            for (int j = 0; j < 8; ++j) {
+                const int f1 = fb + j < F1 ? fb + j : F1 - 1;
+                const int64_t o = (((int64_t)b * T1 + t1) * F1 + f1) * C;
+                d0[j] = ld_t<DDT>(dh1, o + c0);
+                d1[j] = two ? ld_t<DDT>(dh1, o + c1) : 0.f;
             }
-            if ((int)threadIdx.x + 256 < C) {
-                const float d = load_as_f32(dh1, o + threadIdx.x + 256, d_dt);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) acc1[k] = fmaf(d, taps[k], acc1[k]);
-                acc1[9] += d;
+            for (int j = 0; j < 8; ++j) {
+                if (fb + j < F1) {                           // uniform
+                    const int f1 = fb + j;
+                    float taps[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) taps[k] = xr[(k / 3) * F + 2 * f1 + (k % 3)];
+                    const float e0 = (int)threadIdx.x < C ? d0[j] : 0.f, e1 = (int)threadIdx.x + 256 < C ? d1[j] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        acc0[k] = fmaf(e0, taps[k], acc0[k]);
+                        acc1[k] = fmaf(e1, taps[k], acc1[k]);
+                    }
+                    acc0[9] += e0;
+                    acc1[9] += e1;
+                }
             }
         }
     }
@@ -836,7 +850,11 @@ extern "C" int cfm_conv1_wgrad(const void* dh1, int32_t dh1_dtype, const float* 
     const int nbt = (T1 + C1_TB - 1) / C1_TB;
     {
         CfmProfScope prof("conv1_wgrad", s, 20.0 * B * T1 * F1 * C, (double)B * T1 * F1 * C * cfm_elt_size(dh1_dtype));
-        CFM_LAUNCH(cfm_conv1_wgrad_kernel, dim3((unsigned)nbt, (unsigned)B), dim3(256), (size_t)3 * F * 4, s, dh1, dh1_dtype, x, cmvn_mean, cmvn_istd, ws, T, F, T1, F1, C);
+        const dim3 grid((unsigned)nbt, (unsigned)B);
+        const size_t lds = (size_t)3 * F * 4;
+        if (dh1_dtype == CFM_BF16) CFM_LAUNCH((cfm_conv1_wgrad_kernel<CFM_BF16>), grid, dim3(256), lds, s, dh1, x, cmvn_mean, cmvn_istd, ws, T, F, T1, F1, C);
+        else if (dh1_dtype == CFM_F16) CFM_LAUNCH((cfm_conv1_wgrad_kernel<CFM_F16>), grid, dim3(256), lds, s, dh1, x, cmvn_mean, cmvn_istd, ws, T, F, T1, F1, C);
+        else CFM_LAUNCH((cfm_conv1_wgrad_kernel<CFM_F32>), grid, dim3(256), lds, s, dh1, x, cmvn_mean, cmvn_istd, ws, T, F, T1, F1, C);
         if (int rc = cfm_launch_status("cfm_conv1_wgrad")) return rc;
     }
     return reduce_partials(ws, B * nbt, 10 * C, 9 * C, 1.0f, dw, db, s, "cfm_conv1_wgrad (reduce)");     // dw [9][C] tap-major (the packed layout), db [C]
