@@ -80,6 +80,21 @@ int reduce_partials(const float* part, int nblk, int J, int J1, float alpha, flo
 constexpr int LNB_WAVES = 8;      // 2 rows per wavefront (at M = 2 k rows a 32-row, 4-wavefront workgroup left three quarters of the CUs idle: 12 us -> ~4 us);
 constexpr int LNB_ROWS = 2 * LNB_WAVES;   // 8 wavefronts halve the workgroups that meet in the parameter-gradient sums (atomics of the one-launch form: 10.3 us with 4)
 
+// The element types of g / dg are TEMPLATE arguments: with a run-time dtype every one of the 30 window loads sits behind a branch, the compiler
+// waits at each join and the loads of a thread go out one memory latency after the other (28 us per launch at a config-3 micro-batch).
+template <int GDT>
+__device__ __forceinline__ float ld_t(const void* p, int64_t i) {
+    if constexpr (GDT == CFM_F32) return ((const float*)p)[i];
+    else if constexpr (GDT == CFM_BF16) return BF16::to_f32(((const u16*)p)[i]);
+    else return F16::to_f32(((const u16*)p)[i]);
+}
+template <int GDT>
+__device__ __forceinline__ void st_t(void* p, int64_t i, float v) {
+    if constexpr (GDT == CFM_F32) ((float*)p)[i] = v;
+    else if constexpr (GDT == CFM_BF16) ((u16*)p)[i] = BF16::from_f32(v);
+    else ((u16*)p)[i] = F16::from_f32(v);
+}
+
 // Optional second output (LnBwd2): the NEXT consumer of dx in a conformer block's backward is a residual branch whose gradient enters its
 // GEMMs as dropout-mask * alpha * dx in the activation dtype (cfm_dropout_rows); written here it saves that launch and its read of dx.
 struct LnBwd2 {
@@ -89,7 +104,17 @@ struct LnBwd2 {
     CfmDrop d1, d2;
 };
 
-template <int ITERS>
+template <int DT>
+__device__ __forceinline__ f32x4 ld4_t(const void* p, int64_t i) {
+    if constexpr (DT == CFM_F32) return *(const f32x4*)((const float*)p + i);
+    else {
+        const u32x2 r = *(const u32x2*)((const u16*)p + i);
+        if constexpr (DT == CFM_BF16) return (f32x4){BF16::to_f32((u16)(r.x & 0xffffu)), BF16::to_f32((u16)(r.x >> 16)), BF16::to_f32((u16)(r.y & 0xffffu)), BF16::to_f32((u16)(r.y >> 16))};
+        else return (f32x4){F16::to_f32((u16)(r.x & 0xffffu)), F16::to_f32((u16)(r.x >> 16)), F16::to_f32((u16)(r.y & 0xffffu)), F16::to_f32((u16)(r.y >> 16))};
+    }
+}
+
+template <int ITERS, int DYDT>
 __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy, int dy_dt,
                                                                 const float* __restrict__ gamma, const uint8_t* __restrict__ mask,
                                                                 const float* dres, float* dx, float* __restrict__ ws, float eps, int64_t M, int D,
@@ -104,18 +129,39 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const
         gm[it] = c < D ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float invD = 1.0f / (float)D;
-    for (int r = wave; r < LNB_ROWS; r += LNB_WAVES) {
-        const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + r;
+    // every load of the wavefront's two rows goes out first, unconditionally (clamped addresses, values selected afterwards): x, dy, the residual
+    // gradient (it was read after the row's two reductions, one more exposed latency per row) and the mask byte
+    constexpr int NR = LNB_ROWS / LNB_WAVES;
+    const f32x4 z4f = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 xa[NR][ITERS], da[NR][ITERS], ra[NR][ITERS];
+    bool keep_a[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int64_t row_u = (int64_t)blockIdx.x * LNB_ROWS + wave + rr * LNB_WAVES;
+        const int64_t row_c = row_u < M ? row_u : M - 1;
+        keep_a[rr] = mask ? mask[row_c] != 0 : true;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            const int cc = c < D ? c : 0;
+            xa[rr][it] = *(const f32x4*)(x + row_c * D + cc);
+            da[rr][it] = ld4_t<DYDT>(dy, row_c * D + cc);
+            ra[rr][it] = dres ? *(const f32x4*)(dres + row_c * D + cc) : z4f;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + wave + rr * LNB_WAVES;
         if (row >= M) break;                               // wave-uniform
-        const bool keep = mask ? mask[row] != 0 : true;
+        const bool keep = keep_a[rr];
         f32x4 xv[ITERS], dv[ITERS];
         float s = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = (lane + 64 * it) * 4;
             const bool in = c < D;
-            xv[it] = in ? *(const f32x4*)(x + row * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            dv[it] = (in && keep) ? load4(dy, dy_dt, row * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xv[it] = in ? xa[rr][it] : z4f;
+            dv[it] = (in && keep) ? da[rr][it] : z4f;
             s += (xv[it].x + xv[it].y) + (xv[it].z + xv[it].w);
         }
         const float mean = wave_sum(s) * invD;
@@ -149,7 +195,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const
             const int c = (lane + 64 * it) * 4;
             if (c < D) {
                 f32x4 o = (gm[it] * dv[it] - m1 - xv[it] * m2) * rstd;
-                if (dres) o += *(const f32x4*)(dres + row * D + c);
+                o += ra[rr][it];
                 *(f32x4*)(dx + row * D + c) = o;
                 if (o2.y) {
                     f32x4 t;
@@ -217,21 +263,6 @@ __global__ void cfm_glu_bwd_kernel(const void* __restrict__ u, int u_dt, const v
 constexpr int DWT = 16;
 constexpr int DWK = 15;                                     // taps (the only kernel size on the path, encoder.py:38 kernel_size=15)
 constexpr int DWW = DWT + DWK - 1;
-
-// The element types of g / dg are TEMPLATE arguments: with a run-time dtype every one of the 30 window loads sits behind a branch, the compiler
-// waits at each join and the loads of a thread go out one memory latency after the other (28 us per launch at a config-3 micro-batch).
-template <int GDT>
-__device__ __forceinline__ float ld_t(const void* p, int64_t i) {
-    if constexpr (GDT == CFM_F32) return ((const float*)p)[i];
-    else if constexpr (GDT == CFM_BF16) return BF16::to_f32(((const u16*)p)[i]);
-    else return F16::to_f32(((const u16*)p)[i]);
-}
-template <int GDT>
-__device__ __forceinline__ void st_t(void* p, int64_t i, float v) {
-    if constexpr (GDT == CFM_F32) ((float*)p)[i] = v;
-    else if constexpr (GDT == CFM_BF16) ((u16*)p)[i] = BF16::from_f32(v);
-    else ((u16*)p)[i] = F16::from_f32(v);
-}
 
 template <int GDT>
 __global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias,
@@ -701,9 +732,18 @@ static int layernorm_bwd_impl(const float* x, const void* dy, int32_t dy_dtype, 
     {
         CfmProfScope prof("layernorm_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(dy_dtype) + (dres ? 4 : 0) + (o2.y ? cfm_elt_size(o2.dt) : 0)));
         const dim3 grid((unsigned)nblk), block(64 * LNB_WAVES);
-        if (D <= 256) CFM_LAUNCH((cfm_layernorm_bwd_kernel<1>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
-        else if (D <= 512) CFM_LAUNCH((cfm_layernorm_bwd_kernel<2>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
-        else CFM_LAUNCH((cfm_layernorm_bwd_kernel<4>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2);
+#define CFM_LNB(IT, DT) CFM_LAUNCH((cfm_layernorm_bwd_kernel<IT, DT>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2)
+#define CFM_LNB_DT(IT)                                        \
+    do {                                                      \
+        if (dy_dtype == CFM_F32) CFM_LNB(IT, CFM_F32);        \
+        else if (dy_dtype == CFM_BF16) CFM_LNB(IT, CFM_BF16); \
+        else CFM_LNB(IT, CFM_F16);                            \
+    } while (0)
+        if (D <= 256) CFM_LNB_DT(1);
+        else if (D <= 512) CFM_LNB_DT(2);
+        else CFM_LNB_DT(4);
+#undef CFM_LNB_DT
+#undef CFM_LNB
         if (int rc = cfm_launch_status("cfm_layernorm_bwd")) return rc;
     }
     if (accumulate) return CFM_OK;
