@@ -163,9 +163,12 @@ def conv_module_bwd(mod, pk, saved, dy, ln, B, T, keep, prec, drop_o=None):
     x, xn, u, glu, c, stats, s = saved
     M, D = x.shape
     adt, mma, sp = prec.act_dtype, prec.w_code, prec.split
-    dyb = dy if drop_o is None else cfm.dropout_rows(dy, adt, drop=drop_o)
-    dW2, db2 = cfm.gemm_tn(dyb, s.view(M, D), want_colsum=True, row_mask=keep, mma_code=mma, split=sp)
-    ds = cfm.gemm(dyb, pk.pw2_t, w_lo=pk.pw2_t_lo, row_mask=keep, mask_mode=1, out_dtype=adt)     # masked OUTPUT rows have no gradient
+    # masked OUTPUT rows have no gradient: with the branch gradient materialised (dropout), its padded rows are zeroed there and the two products
+    # run unmasked (the 16-bit weight-gradient kernel without a row mask) -- as csrc/train_layer.cpp does
+    dyb = dy if drop_o is None else cfm.dropout_rows(dy, adt, drop=drop_o, row_mask=keep)
+    km = keep if drop_o is None else None
+    dW2, db2 = cfm.gemm_tn(dyb, s.view(M, D), want_colsum=True, row_mask=km, mma_code=mma, split=sp)
+    ds = cfm.gemm(dyb, pk.pw2_t, w_lo=pk.pw2_t_lo, row_mask=km, mask_mode=1 if km is not None else 0, out_dtype=adt)
     dglu, ddw_w, ddw_b, dgamma, dbeta = cfm.dwconv_bn_train_bwd(ds.view(B, T, D), c, stats, glu.view(B, T, D), pk.dw_w, adt)
     du = cfm.glu_bwd(u, dglu.view(M, D), adt)
     # pointwise-conv-1 saw zeroed padded rows: xn already is (LayerNorm path) or is masked here (bare module)

@@ -285,18 +285,19 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             constexpr int NHALO = (DWROWS * C8 + NT - 1) / NT;
             u32x4 hv[NHALO];
 #pragma unroll
-            for (int i = 0; i < NHALO; ++i) {               // all requests first, then the LDS stores
-                const int id = tid + i * NT;
-                const int64_t grow = row0 - DWH + id / C8;
-                hv[i] = (u32x4){0u, 0u, 0u, 0u};
-                if (id < DWROWS * C8 && grow >= 0 && grow < Mlim) hv[i] = *(const u32x4*)(a.head_a + grow * D + (id % C8) * 8);
+            for (int i = 0; i < NHALO; ++i) {               // all requests first, then the LDS stores.  UNCONDITIONAL loads (clamped address, value
+                const int id = tid + i * NT;                // selected afterwards): behind a branch each load waits out its own latency
+                const int idc = id < DWROWS * C8 ? id : DWROWS * C8 - 1;
+                const int64_t grow = row0 - DWH + idc / C8;
+                const int64_t gc = grow < 0 ? 0 : (grow < Mlim ? grow : Mlim - 1);
+                const u32x4 v = *(const u32x4*)(a.head_a + gc * D + (idc % C8) * 8);
+                hv[i] = (id < DWROWS * C8 && grow >= 0 && grow < Mlim) ? v : (u32x4){0u, 0u, 0u, 0u};
             }
             const bool worker = tid < CP * RG;
             const int cp = worker ? tid % CP : 0, rg = worker ? tid / CP : 0;   // channel pair, frame group (wave-uniform: CP % 64 == 0 or idle tail)
             float* const taps = (float*)(lds_a + DWROWS * D * 2);                // [D][15] as in memory, staged with 16-byte loads
             static_assert((DWK * D) % 4 == 0 && DWK * D / 4 <= NT, "one 16-byte piece of the taps per thread");
-            f32x4 tv = zero4;
-            if (tid < DWK * D / 4) tv = *(const f32x4*)(a.dw_w + 4 * tid);
+            const f32x4 tv = *(const f32x4*)(a.dw_w + 4 * (tid < DWK * D / 4 ? tid : 0));
             const f32x2 pb = *(const f32x2*)(a.dw_b + 2 * cp), ps = *(const f32x2*)(a.dw_scale + 2 * cp), ph = *(const f32x2*)(a.dw_shift + 2 * cp);
 #pragma unroll
             for (int i = 0; i < NHALO; ++i) {

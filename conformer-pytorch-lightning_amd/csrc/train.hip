@@ -102,6 +102,7 @@ struct LnBwd2 {
     int dt;
     float alpha;
     CfmDrop d1, d2;
+    const uint8_t* mask;   // rows with mask == 0 are written as zeros (the consumer's row mask applied here)
 };
 
 template <int DT>
@@ -199,9 +200,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const
                 *(f32x4*)(dx + row * D + c) = o;
                 if (o2.y) {
                     f32x4 t;
+                    const bool live2 = o2.mask ? o2.mask[row] != 0 : true;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float u = o[e] * o2.alpha;
+                        float u = live2 ? o[e] * o2.alpha : 0.f;
                         if (o2.d1.thresh) u = cfm_drop(o2.d1, (unsigned)(row * D + c + e), u);
                         if (o2.d2.thresh) u = cfm_drop(o2.d2, (unsigned)(row * D + c + e), u);
                         t[e] = u;
@@ -765,7 +767,7 @@ extern "C" int cfm_layernorm_bwd_fused(const cfm_ln_bwd_desc* d, cfm_stream_t st
     CFM_CHECK_ARG(d->dy_dtype >= CFM_F32 && d->dy_dtype <= CFM_F16 && (!d->dx2 || (d->dx2_dtype >= CFM_F32 && d->dx2_dtype <= CFM_F16)), "cfm_layernorm_bwd_fused: bad dtype");
     CFM_CHECK_ARG(d->p1 >= 0.f && d->p1 < 1.f && d->p2 >= 0.f && d->p2 < 1.f && d->M * d->D < ((int64_t)1 << 32), "cfm_layernorm_bwd_fused: p in [0,1), fewer than 2^32 elements");
     LnBwd2 o2 = {};
-    if (d->dx2) { o2.y = d->dx2; o2.dt = d->dx2_dtype; o2.alpha = d->alpha2; o2.d1 = cfm_make_drop(d->p1, d->seed1); o2.d2 = cfm_make_drop(d->p2, d->seed2); }
+    if (d->dx2) { o2.y = d->dx2; o2.dt = d->dx2_dtype; o2.alpha = d->alpha2; o2.d1 = cfm_make_drop(d->p1, d->seed1); o2.d2 = cfm_make_drop(d->p2, d->seed2); o2.mask = d->dx2_row_mask; }
     return layernorm_bwd_impl(d->x, d->dy, d->dy_dtype, d->gamma, d->row_mask, d->dres, d->dx, d->dgamma, d->dbeta, d->ws, d->accumulate != 0, o2, d->eps, d->M,
                               d->D, (hipStream_t)stream);
 }

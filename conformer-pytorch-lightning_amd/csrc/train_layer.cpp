@@ -112,6 +112,7 @@ struct Next {
     uint32_t s1;
     float p2;
     uint32_t s2;
+    const uint8_t* mask;   // the consumer's row mask, applied to the operand itself (its GEMMs then take the unmasked, LDS-DMA paths)
 };
 
 // LayerNorm backward of a sub-block: dx = dres + dLN(dy) in place on the residual gradient, parameter gradients into the (zero-filled,
@@ -121,7 +122,7 @@ int ln_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const float* x, cons
     cfm_ln_bwd_desc d = {};
     d.x = x; d.dy = dy; d.dy_dtype = CFM_F32; d.gamma = gamma; d.row_mask = mask; d.dres = dres; d.dx = dx; d.dgamma = gg; d.dbeta = gb; d.ws = t->ln_ws;
     d.accumulate = c.io->deterministic ? 0 : 1;
-    d.dx2 = nx.buf; d.dx2_dtype = c.adt; d.alpha2 = nx.alpha; d.p1 = nx.p1; d.seed1 = nx.s1; d.p2 = nx.p2; d.seed2 = nx.s2;
+    d.dx2 = nx.buf; d.dx2_dtype = c.adt; d.alpha2 = nx.alpha; d.p1 = nx.p1; d.seed1 = nx.s1; d.p2 = nx.p2; d.seed2 = nx.s2; d.dx2_row_mask = nx.mask;
     d.eps = 1e-5f; d.M = c.M; d.D = c.D;
     return cfm_layernorm_bwd_fused(&d, c.st);
 }
@@ -211,11 +212,11 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
     uint32_t sa1 = site_seed(sd, 4), sa2 = site_seed(sd, 5);
     if (pa1 <= 0.f && pa2 > 0.f) { pa1 = pa2; sa1 = sa2; pa2 = 0.f; }
     const bool bra = pa1 > 0.f || c.side;
-    const Next n_ff = {br ? t->dyb : nullptr, 0.5f, io->p_branch, site_seed(sd, 8), 0.f, 0};
-    const Next n_conv = {br ? (c.side ? t->dyb2 : t->dyb) : nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0};
-    const Next n_att = {bra ? (c.side ? t->dyb3 : t->dyb) : nullptr, 1.0f, pa1, sa1, pa2, sa2};
-    const Next n_ffm = {br ? (c.side ? t->dyb4 : t->dyb) : nullptr, 0.5f, io->p_branch, site_seed(sd, 2), 0.f, 0};
-    const Next n_none = {nullptr, 0.f, 0.f, 0, 0.f, 0};
+    const Next n_ff = {br ? t->dyb : nullptr, 0.5f, io->p_branch, site_seed(sd, 8), 0.f, 0, nullptr};
+    const Next n_conv = {br ? (c.side ? t->dyb2 : t->dyb) : nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0, io->pad_valid};
+    const Next n_att = {bra ? (c.side ? t->dyb3 : t->dyb) : nullptr, 1.0f, pa1, sa1, pa2, sa2, nullptr};
+    const Next n_ffm = {br ? (c.side ? t->dyb4 : t->dyb) : nullptr, 0.5f, io->p_branch, site_seed(sd, 2), 0.f, 0, nullptr};
+    const Next n_none = {nullptr, 0.f, 0.f, 0, 0.f, 0, nullptr};
     // (5) norm_final
     CFM_TRY(ln_bwd(c, t, sv->x4, dy, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, n_ff));
     // (4) feed-forward
@@ -225,9 +226,10 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
     {
         const void* dyb = d;
         int dyb_dt = CFM_F32;
-        if (n_conv.buf) { dyb = n_conv.buf; dyb_dt = adt; }
-        CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, io->pad_valid, nullptr, nullptr));
-        CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, io->pad_valid, 1, nullptr, nullptr, 0.f, 0));
+        const uint8_t* pm = io->pad_valid;
+        if (n_conv.buf) { dyb = n_conv.buf; dyb_dt = adt; pm = nullptr; }   // the padded rows of the operand are already zero (Next.mask)
+        CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, pm, nullptr, nullptr));
+        CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, pm, pm ? 1 : 0, nullptr, nullptr, 0.f, 0));
         CFM_TRY(cfm_dwconv_bn_train_bwd_acc(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
                                             io->B, io->T, D, io->ktaps, io->grads_accumulate, stream));
         CFM_TRY(cfm_glu_bwd(sv->u, adt, t->dglu, adt, t->du, adt, M, D, stream));

@@ -518,6 +518,7 @@ typedef struct {
     int32_t D, dy_dtype, dx2_dtype, accumulate;
     float eps, alpha2, p1, p2;
     uint32_t seed1, seed2;
+    const uint8_t* dx2_row_mask; /* optional: rows of dx2 with mask == 0 are written as zeros (cfm_dropout_rows' row_mask) */
 } cfm_ln_bwd_desc;
 int cfm_layernorm_bwd_fused(const cfm_ln_bwd_desc* d, cfm_stream_t stream);
 int cfm_layernorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres,
