@@ -223,20 +223,41 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __res
         }
         __syncthreads();
     }
-    for (int t = len - 2; t >= 0; --t) {
+    // the frame's log-probabilities and alpha values are requested AHEAD frames before they are used (as the alpha recursion does): read in
+    // the step that needs them, every step waited out two L2 round trips (180 us per launch at config 3 against 114 us for alpha)
+    constexpr int AHEAD = 4;
+    float nl[AHEAD][2], na[AHEAD][2];
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int s = tid + i * CTC_NT;
-            if (live[i]) {
-                float a = logaddexp_(beta[cur][s], beta[cur][s + 1]);
-                if (skip[i]) a = logaddexp_(a, beta[cur][s + 2]);
-                const float l = lp[(int64_t)t * SM + s];
-                beta[cur ^ 1][s] = a + l;
-                abp[(int64_t)t * SM + s] = abp[(int64_t)t * SM + s] + a;      // alpha + beta - lp
+            const int t = len - 2 - k, s = tid + i * CTC_NT;
+            const bool ok = live[i] && t >= 0;
+            nl[k][i] = ok ? lp[(int64_t)t * SM + s] : 0.f;
+            na[k][i] = ok ? abp[(int64_t)t * SM + s] : 0.f;
+        }
+    for (int t0 = len - 2; t0 >= 0; t0 -= AHEAD) {
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            const int t = t0 - k;
+            if (t >= 0) {                                  // uniform
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int s = tid + i * CTC_NT;
+                    if (live[i]) {
+                        float a = logaddexp_(beta[cur][s], beta[cur][s + 1]);
+                        if (skip[i]) a = logaddexp_(a, beta[cur][s + 2]);
+                        beta[cur ^ 1][s] = a + nl[k][i];
+                        abp[(int64_t)t * SM + s] = na[k][i] + a;                  // alpha + beta - lp
+                        const int tn = t - AHEAD;
+                        nl[k][i] = tn >= 0 ? lp[(int64_t)tn * SM + s] : 0.f;
+                        na[k][i] = tn >= 0 ? abp[(int64_t)tn * SM + s] : 0.f;
+                    }
+                }
+                __syncthreads();
+                cur ^= 1;
             }
         }
-        __syncthreads();
-        cur ^= 1;
     }
 }
 
