@@ -514,23 +514,59 @@ __global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_fast_kernel(const AttnBw
     }
 }
 
+// delta_i = dO_i . O_i for d_k = 64 16-bit rows: the row's sixteen 16-byte pieces requested together (the general kernel's loads sit behind
+// run-time dtype branches and go out one latency after the other)
+template <typename HT>
+__global__ void cfm_attn_delta_fast_kernel(const AttnBwdArgs a) {
+    const int64_t n = (int64_t)a.B * a.H * a.Tq;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const int i = (int)(id % a.Tq);
+    const int h = (int)((id / a.Tq) % a.H);
+    const int b = (int)(id / ((int64_t)a.Tq * a.H));
+    const int64_t o = ((int64_t)b * a.Tq + i) * ((int64_t)a.H * 64) + (int64_t)h * 64;
+    u32x4 x[8], y[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        x[c] = *(const u32x4*)((const u16*)a.out + o + c * 8);
+        y[c] = *(const u32x4*)((const u16*)a.dout + o + c * 8);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                          // same element order as the general kernel: bit-identical
+        const unsigned xw[4] = {x[c].x, x[c].y, x[c].z, x[c].w}, yw[4] = {y[c].x, y[c].y, y[c].z, y[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s = fmaf(HT::to_f32((u16)(xw[e] & 0xffffu)), HT::to_f32((u16)(yw[e] & 0xffffu)), s);
+            s = fmaf(HT::to_f32((u16)(xw[e] >> 16)), HT::to_f32((u16)(yw[e] >> 16)), s);
+        }
+    }
+    a.delta[id] = s;
+}
+
 static bool g_attn_bwd_general_only = false;      // tests: force the general kernels
 
 template <typename HT, bool SPLIT>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char* n_dkv) {
     const double fl = 2.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
     const double by = (double)a.B * a.H * (a.Tq + a.Tk) * a.dk * cfm_elt_size(a.io_dt) * 3;
-    {
-        CfmProfScope prof("attn_bwd_delta", s, 0.0, 2.0 * a.B * a.Tq * a.H * a.dk * cfm_elt_size(a.io_dt));
-        const int64_t n = (int64_t)a.B * a.H * a.Tq;
-        CFM_LAUNCH(cfm_attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-        if (int rc = cfm_launch_status("cfm_attention_bwd (delta)")) return rc;
-    }
     bool fast = false;
     if constexpr (!SPLIT) {
         const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
         fast = !g_attn_bwd_general_only && a.dk == 64 && a.io_dt == HT::kId && a.do_dt == HT::kId && (!a.mask || a.m_sq == 0) && a.q_st % 8 == 0 &&
-               a.k_st % 8 == 0 && a.v_st % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.dout);
+               a.k_st % 8 == 0 && a.v_st % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.dout) &&
+               al16(a.out);
+    }
+    {
+        CfmProfScope prof("attn_bwd_delta", s, 0.0, 2.0 * a.B * a.Tq * a.H * a.dk * cfm_elt_size(a.io_dt));
+        const int64_t n = (int64_t)a.B * a.H * a.Tq;
+        if constexpr (!SPLIT) {
+            if (fast) CFM_LAUNCH((cfm_attn_delta_fast_kernel<HT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+            else CFM_LAUNCH(cfm_attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        } else {
+            CFM_LAUNCH(cfm_attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        }
+        if (int rc = cfm_launch_status("cfm_attention_bwd (delta)")) return rc;
     }
     {
         CfmProfScope prof(n_dq, s, 3.0 * fl, by);
