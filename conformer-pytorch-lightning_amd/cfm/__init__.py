@@ -143,6 +143,14 @@ class LnBwdDesc(ctypes.Structure):
                 ("seed1", ctypes.c_uint32), ("seed2", ctypes.c_uint32), ("dx2_row_mask", c_p)]
 
 
+class GreedyDesc(ctypes.Structure):
+    _fields_ = [("embed", c_p), ("lstm_w", c_p * 4), ("lstm_b", c_p * 4), ("proj_w", c_p), ("proj_b", c_p), ("pf_w", c_p), ("pf_b", c_p), ("out_w", c_p),
+                ("out_b", c_p), ("enc_proj", c_p), ("token", c_p), ("t", c_p), ("count", c_p), ("frame_count", c_p), ("hyps", c_p), ("lens", c_p),
+                ("h", c_p), ("c", c_p), ("h_new", c_p), ("c_new", c_p), ("pred", c_p), ("act", c_p), ("pmax", c_p), ("pidx", c_p), ("done", c_p),
+                ("n_done", c_p), ("hyp_cap", c_i64), ("hyp_ld", c_i64), ("B", c_i32), ("T", c_i32), ("L", c_i32), ("E", c_i32), ("H", c_i32),
+                ("P", c_i32), ("J", c_i32), ("Vp", c_i32), ("blank", c_i32), ("n_steps", c_i32)]
+
+
 class LayerScratch(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw", "vt")] + [("vt_ld", c_i32)]
 
@@ -190,6 +198,7 @@ def lib():
         L.cfm_conv1_relu_mma.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]
         L.cfm_conv12_supported.argtypes = [c_i32, c_i32]
         L.cfm_pack_matrices.argtypes = [c_p, c_i32, c_i64, c_i32, c_i32, c_p]
+        L.cfm_greedy_step.argtypes = [ctypes.POINTER(GreedyDesc), c_p]
         L.cfm_attention_bwd_force_general.argtypes = [c_i32]
         L.cfm_attention_bwd_force_general.restype = None
         L.cfm_dwconv_bn_train_bwd_acc.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
@@ -243,7 +252,7 @@ def lib():
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
-                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
+                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_greedy_step", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
                      "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L

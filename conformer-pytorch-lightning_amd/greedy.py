@@ -27,11 +27,76 @@ import torch.nn.functional as F
 
 class BatchedGreedySearch:
 
-    def __init__(self, predictor, joint, blank=0, n_steps=64, steps_per_replay=32, use_graph=True):
+    def __init__(self, predictor, joint, blank=0, n_steps=64, steps_per_replay=32, use_graph=True, fused=None):
+        """fused: one step = six HIP launches on f32 weights (csrc/greedy.hip, include/cfm.h cfm_greedy_step) instead of ~45 torch operations;
+        default: on an MI355X when the sizes fit (B <= 64 streams, dimensions multiples of 16), the torch-operation form otherwise (and on CPU)."""
         self.predictor, self.joint = predictor, joint
         self.blank, self.n_steps, self.steps_per_replay, self.use_graph = int(blank), int(n_steps), int(steps_per_replay), bool(use_graph)
+        self.fused = fused
         self._graph = None
         self._key = None
+        self._key_f = None
+        self._fw = None
+
+    # -- fused step -----------------------------------------------------------------------------------------------------------------------
+    def _fused_ok(self, B, dev):
+        pr, jn = self.predictor, self.joint
+        dims = (pr.embed_size, pr.hidden_size, pr.projection.out_features, jn.pred_ffn.out_features)
+        return (dev.type == "cuda" and B <= 64 and pr.num_layers <= 4 and all(d % 16 == 0 for d in dims) and pr.rnn.bias and
+                jn.pred_ffn.in_features == pr.projection.out_features)
+
+    def _fused_weights(self, dev):
+        """f32 packs for cfm_greedy_step, rebuilt when a source parameter changes: [W_ih | W_hh] per layer with rows ordered [unit][gate],
+        b_ih + b_hh likewise, the vocabulary projection padded to a multiple of 16 rows (bias -inf there: never the argmax)."""
+        pr, jn = self.predictor, self.joint
+        srcs = list(pr.parameters()) + list(jn.parameters())
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        if self._fw is not None and self._fw[0] == key:
+            return self._fw[1]
+        H = pr.hidden_size
+        perm = (torch.arange(H, device=dev)[:, None] + H * torch.arange(4, device=dev)[None, :]).reshape(-1)     # row u*4 + gate <- gate*H + u
+        W = {"embed": pr.embed.weight.detach().float().contiguous(), "lstm_w": [], "lstm_b": []}
+        for l in range(pr.num_layers):
+            w = torch.cat([getattr(pr.rnn, "weight_ih_l%d" % l).detach().float(), getattr(pr.rnn, "weight_hh_l%d" % l).detach().float()], 1)
+            b = getattr(pr.rnn, "bias_ih_l%d" % l).detach().float() + getattr(pr.rnn, "bias_hh_l%d" % l).detach().float()
+            W["lstm_w"].append(w[perm].contiguous())
+            W["lstm_b"].append(b[perm].contiguous())
+        V = jn.ffn_out.out_features
+        Vp = (V + 15) // 16 * 16
+        ow = torch.zeros((Vp, jn.ffn_out.in_features), device=dev)
+        ow[:V] = jn.ffn_out.weight.detach().float()
+        ob = torch.full((Vp,), float("-inf"), device=dev)
+        ob[:V] = jn.ffn_out.bias.detach().float()
+        W.update(proj_w=pr.projection.weight.detach().float().contiguous(), proj_b=pr.projection.bias.detach().float().contiguous(),
+                 pf_w=jn.pred_ffn.weight.detach().float().contiguous(), pf_b=jn.pred_ffn.bias.detach().float().contiguous(), out_w=ow, out_b=ob, Vp=Vp)
+        self._fw = (key, W)
+        return W
+
+    def _fused_desc(self, S, W, B, T):
+        import ctypes
+        import cfm
+        pr, jn = self.predictor, self.joint
+        L, H = pr.num_layers, pr.hidden_size
+        dev = S["t"].device
+        for k, shape, dt in (("h_new", (L, B, H), torch.float32), ("c_new", (L, B, H), torch.float32), ("pred", (B, pr.projection.out_features), torch.float32),
+                             ("act", (B, jn.pred_ffn.out_features), torch.float32), ("pmax", (W["Vp"] // 16, B), torch.float32),
+                             ("pidx", (W["Vp"] // 16, B), torch.int32), ("done8", (B,), torch.uint8), ("n_done", (1,), torch.int32)):
+            if k not in S:
+                S[k] = torch.zeros(shape, dtype=dt, device=dev)
+        d = cfm.GreedyDesc()
+        d.embed = W["embed"].data_ptr()
+        for l in range(L):
+            d.lstm_w[l], d.lstm_b[l] = W["lstm_w"][l].data_ptr(), W["lstm_b"][l].data_ptr()
+        for k in ("proj_w", "proj_b", "pf_w", "pf_b", "out_w", "out_b"):
+            setattr(d, k, W[k].data_ptr())
+        d.enc_proj = S["enc_proj"].data_ptr()
+        for k in ("token", "t", "count", "frame_count", "hyps", "lens", "h", "c", "h_new", "c_new", "pred", "act", "pmax", "pidx", "n_done"):
+            setattr(d, k, S[k].data_ptr())
+        d.done = S["done8"].data_ptr()
+        d.hyp_cap, d.hyp_ld = int(S["cap"][0]), S["hyps"].shape[1]
+        d.B, d.T, d.L, d.E, d.H, d.P, d.J, d.Vp = B, T, L, pr.embed_size, H, pr.projection.out_features, jn.pred_ffn.out_features, W["Vp"]
+        d.blank, d.n_steps = self.blank, self.n_steps
+        return d
 
     # -- one LSTM step on (B, E) inputs with nn.LSTM's parameters (eval mode: no inter-layer dropout); torch.nn.LSTM restated for T = 1
     def _lstm_step(self, x, h, c):
@@ -90,7 +155,7 @@ class BatchedGreedySearch:
         dev = enc_out.device
         key = (B, T, str(dev))
         if self._key != key:
-            self._S, self._graph, self._key = self._state(B, T, dev), None, key
+            self._S, self._graph, self._key, self._key_f = self._state(B, T, dev), None, key, None
         S = self._S
         S["enc_proj"].copy_(self.joint.enc_ffn(enc_out.float()))
         S["lens"].copy_(torch.as_tensor(enc_lens, device=dev).to(torch.int64).clamp(0, T))
@@ -102,14 +167,31 @@ class BatchedGreedySearch:
         else:
             S["h"].copy_(state[0]); S["c"].copy_(state[1])
         S["done"].copy_(S["t"] >= S["lens"])
+        fused = self._fused_ok(B, dev) if self.fused is None else bool(self.fused)
+        if fused:
+            import ctypes
+            import cfm
+            if not self._fused_ok(B, dev):
+                raise RuntimeError("the fused greedy step needs a GPU, B <= 64 streams and dimensions that are multiples of 16")
+            W = self._fused_weights(dev)
+            if self._key_f != (key, id(W)):
+                self._desc, self._graph, self._key_f = self._fused_desc(S, W, B, T), None, (key, id(W))
+            S["done8"].copy_(S["done"].to(torch.uint8))
+            S["n_done"].copy_(S["done"].sum().to(torch.int32).reshape(1))
+            desc, lib = self._desc, cfm.lib()
 
         def run_chunk():
+            if fused:
+                for _ in range(self.steps_per_replay):
+                    cfm.check(lib.cfm_greedy_step(ctypes.byref(desc), cfm.stream()), "cfm_greedy_step")
+                S["all_done"].copy_((S["n_done"] >= B).reshape(()))
+                return
             for _ in range(self.steps_per_replay):
                 self._step(S)
             S["all_done"].copy_(S["done"].all())
 
         if self.use_graph and dev.type == "cuda" and self._graph is None:
-            snap = {k: S[k].clone() for k in ("t", "count", "frame_count", "hyps", "token", "h", "c", "done")}
+            snap = {k: S[k].clone() for k in ("t", "count", "frame_count", "hyps", "token", "h", "c", "done") + (("done8", "n_done") if fused else ())}
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):

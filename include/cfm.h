@@ -711,6 +711,33 @@ int cfm_prof_collect(void);                 /* returns number of distinct kernel
 int cfm_prof_entry(int i, char* name, int name_cap, int64_t* calls, double* total_ms, double* flops,
                    double* bytes);
 
+/* ------------------------------------------------------------------------------------------------
+ * One step of the batched RNN-T greedy search (reference src/model.py:215-269: predictor step predictor.py:76-86, joint joint.py:20-38,
+ * argmax and the loop's bookkeeping) for B <= 64 streams, six launches, everything float32 (csrc/greedy.hip).  All state lives in caller
+ * buffers and is updated in place; calling it repeatedly (or replaying a captured graph of calls) runs the search, n_done counts the
+ * streams that have reached their last frame.  Weights are f32 row-major [out, in]:
+ *   embed [vocab, E];  lstm_w[l] [4H, in_l + H] = [W_ih | W_hh] with ROWS ORDERED [unit][gate i,f,g,o] (not torch's [gate][unit]),
+ *   lstm_b[l] [4H] = b_ih + b_hh in the same order;  proj_w [P, H], pf_w [J, P] (pred_ffn), out_w [Vp, J] (ffn_out, rows >= V zero,
+ *   out_b there -inf);  enc_proj [B, T, J] = enc_ffn(encoder output).
+ *   state: token / t / count / frame_count / lens int64 [B], hyps int64 [B, hyp_ld] (at most hyp_cap + 1 entries used), h / c and the
+ *   candidates h_new / c_new f32 [L, B, H], done uint8 [B];  scratch: pred [B, P], act [B, J], pmax / pidx [Vp/16, B]. */
+typedef struct {
+    const float* embed;
+    const float* lstm_w[4];
+    const float* lstm_b[4];
+    const float *proj_w, *proj_b, *pf_w, *pf_b, *out_w, *out_b;
+    const float* enc_proj;
+    int64_t *token, *t, *count, *frame_count, *hyps;
+    const int64_t* lens;
+    float *h, *c, *h_new, *c_new, *pred, *act, *pmax;
+    int32_t* pidx;
+    uint8_t* done;
+    int32_t* n_done;
+    int64_t hyp_cap, hyp_ld;
+    int32_t B, T, L, E, H, P, J, Vp, blank, n_steps;
+} cfm_greedy_desc;
+int cfm_greedy_step(const cfm_greedy_desc* d, cfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

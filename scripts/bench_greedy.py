@@ -59,8 +59,8 @@ def main():
     t_host = time.perf_counter() - t0
     steps = T + len(ref)
     print("host loop, 1 utterance: %d frames, %d symbols, %d steps: %.1f ms = %.0f us per step" % (T, len(ref), steps, t_host * 1e3, t_host / steps * 1e6))
-    for graph in (False, True):
-        gs = greedy.BatchedGreedySearch(pr, jn, n_steps=n_steps, steps_per_replay=32, use_graph=graph)
+    for graph, fused in ((False, False), (True, False), (True, True)):
+        gs = greedy.BatchedGreedySearch(pr, jn, n_steps=n_steps, steps_per_replay=32, use_graph=graph, fused=fused)
         hyps, _ = gs.search(enc, lens)
         assert hyps[0] == ref, "stream 0 differs from the host loop"
         torch.cuda.synchronize()
@@ -71,7 +71,7 @@ def main():
         dt = (time.perf_counter() - t0) / 3
         nsteps = max(T + len(h) for h in hyps)
         print("batched, %2d streams, %s: %.1f ms per batch = %.2f ms per utterance (%d steps, %.0f us per step); x%.1f the host loop's utterances/s" % (
-            B, "HIP graph of 32 steps" if graph else "eager launches   ", dt * 1e3, dt * 1e3 / B, nsteps, dt / nsteps * 1e6, t_host / (dt / B)))
+            B, ("HIP graph of 32 steps" if graph else "eager launches   ") + (", fused HIP step" if fused else ", torch operations"), dt * 1e3, dt * 1e3 / B, nsteps, dt / nsteps * 1e6, t_host / (dt / B)))
 
 
 if __name__ == "__main__":

@@ -73,12 +73,12 @@ def test_predictor_module_state_dict_and_step_semantics():
     assert torch.equal(h2[:, 1], h1[:, 1]) and torch.equal(c2[:, 1], c1[:, 1]) and not torch.equal(h2[:, 0], h1[:, 0])
 
 
-def _batched(c, g, device, use_graph):
+def _batched(c, g, device, use_graph, fused=False):
     import greedy
     pr, jn = _case_modules(c)
     pr, jn = pr.to(device), jn.to(device)
     enc = torch.cat([_enc(c, u) for u in range(3)], 0).to(device)
-    gs = greedy.BatchedGreedySearch(pr, jn, blank=0, n_steps=c["n_steps"], steps_per_replay=8, use_graph=use_graph)
+    gs = greedy.BatchedGreedySearch(pr, jn, blank=0, n_steps=c["n_steps"], steps_per_replay=8, use_graph=use_graph, fused=fused)
     hyps, _ = gs.search(enc, c["lens"])
     for u in range(3):
         assert hyps[u] == g["%s_utt%d" % (c["name"], u)].tolist(), (c["name"], u, len(hyps[u]))
@@ -86,13 +86,13 @@ def _batched(c, g, device, use_graph):
     hyps2, _ = gs.search(enc, c["lens"])
     assert hyps2 == hyps
     half = c["T"] // 2
-    first, (tok, st) = gs_half(greedy, pr, jn, c, enc[:1, :half], [half], use_graph)
-    second, _ = gs_half(greedy, pr, jn, c, enc[:1, half:], [c["T"] - half], use_graph, tok, st)
+    first, (tok, st) = gs_half(greedy, pr, jn, c, enc[:1, :half], [half], use_graph, fused=fused)
+    second, _ = gs_half(greedy, pr, jn, c, enc[:1, half:], [c["T"] - half], use_graph, tok, st, fused=fused)
     assert first[0] == g[c["name"] + "_utt0_first"].tolist() and second[0] == g[c["name"] + "_utt0_second"].tolist()
 
 
-def gs_half(greedy, pr, jn, c, enc, lens, use_graph, tok=None, st=None):
-    gs = greedy.BatchedGreedySearch(pr, jn, blank=0, n_steps=c["n_steps"], steps_per_replay=8, use_graph=use_graph)
+def gs_half(greedy, pr, jn, c, enc, lens, use_graph, tok=None, st=None, fused=False):
+    gs = greedy.BatchedGreedySearch(pr, jn, blank=0, n_steps=c["n_steps"], steps_per_replay=8, use_graph=use_graph, fused=fused)
     return gs.search(enc.contiguous(), lens, token=tok, state=st)
 
 
@@ -105,8 +105,29 @@ def test_batched_search_on_cpu_matches_reference_tokens():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("use_graph", [True, False])
-def test_batched_search_on_gpu_matches_reference_tokens(use_graph):
+def test_batched_search_on_gpu_matches_reference_tokens(use_graph, fused):
+    """fused: one step = six launches of csrc/greedy.hip (f32 MFMA products, LSTM cell / tanh / argmax epilogues, control kernel) instead of
+    the torch-operation form; both must reproduce the reference-module tokens."""
     g, cases = _cases()
     for c in cases:
-        _batched(c, g, torch.device("cuda"), use_graph)
+        _batched(c, g, torch.device("cuda"), use_graph, fused)
+
+
+@pytest.mark.gpu
+def test_fused_search_40_streams_matches_torch_form():
+    """More than one 16-stream tile (B = 40, ragged lengths, some streams empty): the fused step against the torch-operation form."""
+    import greedy
+    g, cases = _cases()
+    c = [x for x in cases if x["name"] == "small"][0]
+    pr, jn = _case_modules(c)
+    pr, jn = pr.cuda(), jn.cuda()
+    B, T = 40, c["T"]
+    enc = torch.cat([torch.from_numpy(synth.normal(700 + b, (1, T, c["E"]), 1.0)) for b in range(B)]).cuda()
+    lens = [(7 * b) % (T + 1) for b in range(B)]
+    res = []
+    for fused in (True, False):
+        gs = greedy.BatchedGreedySearch(pr, jn, blank=0, n_steps=c["n_steps"], steps_per_replay=16, use_graph=True, fused=fused)
+        res.append(gs.search(enc, lens)[0])
+    assert res[0] == res[1] and sum(len(h) for h in res[0]) > 50 and res[0][0] == []
