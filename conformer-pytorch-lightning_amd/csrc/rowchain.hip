@@ -631,6 +631,9 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     auto refill = [&](int pos) {
         if (pos + RING < NPOS) ring[pos % RING] = *frag_ptr(pos + RING);
     };
+    // (SEG2, measured: letting the last RING refills of the first segment fetch the second segment's first W1 fragments -- one weight stream across
+    // the boundary -- shortens the second segment's LayerNorm phase by 1.4 k cycles and lengthens the first segment's phase 2 by 3.7 k: 62.3 vs
+    // 61.0 us per launch; bit-identical, not kept.)
     // parameters of the post norms: requested during the FFN, used after it
     f32x4 pn_b2[VPL], pn_g1[VPL], pn_b1[VPL], pn_g2[VPL], pn_be2[VPL];
     f32x4 v[RPW][VPL];                                     // the rows after the feed-forward (+ LN1)
