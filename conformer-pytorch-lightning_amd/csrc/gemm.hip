@@ -610,6 +610,10 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
             if (tile == 1 && a.K <= 256 && t128 < 512) tile = 5;                   // narrow outputs (N = D) at training batch sizes: 64 x 64 tiles fill under half the CUs
             const long t64 = (long)((a.M - a.m_begin + 63) / 64) * ((a.N + 63) / 64), t32x64 = (long)((a.M - a.m_begin + 31) / 32) * ((a.N + 63) / 64);
             if (tile == 3 && t64 < 192 && t32x64 >= 96) tile = 5;
+            // deep K and about one 64 x 128 workgroup per CU (the front-end Linear: M = 7 968, N = 256, K = 4 864 -> 250 workgroups of 76 K steps,
+            // each alone on its CU and bound by its own load -> LDS -> MFMA chain): two 64 x 64 workgroups per CU overlap; measured 40.8 vs 44.8 us
+            // there and 75.8 vs 83.2 us at M = 3 984, N = 512, K = 9 728 (config 4); 32 x 64 is slower again (L2 bytes per FLOP)
+            if (tile == 2 && a.K >= 4096 && t64x128 < 384 && t64 >= 448) tile = 3;
         }
     }
     switch (tile) {

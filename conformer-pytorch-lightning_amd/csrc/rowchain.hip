@@ -875,7 +875,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 for (int it = 0; it < VPL; ++it) {
                     const int c = (lane + 64 * it) * 4;
                     const int64_t grow = row0 + wave * RPW + rr;
-                    if (c < D && grow < Mlim) *(f32x4*)(seg_out + grow * D + c) = v[rr][it];
+                    if (c < D && grow < Mlim) *(f32x4*)(seg_out + grow * D + c) = v[rr][it];     // (non-temporal here and on the tail: kernel -1 us, step unchanged)
                 }
         }
         if constexpr (SEG2) {

@@ -14,11 +14,14 @@ TILES = {0: "auto", 1: "128x128", 2: "64x128", 3: "64x64", 4: "128x64", 5: "32x6
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 2380
+    shapes = (("N=2048 K=256 (ffn W1 fwd, dz dgrad)", 2048, 256), ("N=256 K=2048 (ffn W2 fwd, dxn dgrad)", 256, 2048), ("N=768 K=256 (qkv)", 768, 256),
+              ("N=256 K=256 (out, pw2)", 256, 256), ("N=512 K=256 (pw1)", 512, 256), ("N=256 K=768 (dqkv dgrad)", 256, 768))
+    if len(sys.argv) > 3:                               # python scripts/bench_gemm_tiles.py M N K: one shape (e.g. 7968 256 4864 = the front-end Linear of config 2)
+        shapes = (("N=%s K=%s" % (sys.argv[2], sys.argv[3]), int(sys.argv[2]), int(sys.argv[3])),)
     dev, bf = "cuda", torch.bfloat16
     lib = cfm.lib()
     print("M = %d; us per call" % M)
-    for name, N, K in (("N=2048 K=256 (ffn W1 fwd, dz dgrad)", 2048, 256), ("N=256 K=2048 (ffn W2 fwd, dxn dgrad)", 256, 2048), ("N=768 K=256 (qkv)", 768, 256),
-                       ("N=256 K=256 (out, pw2)", 256, 256), ("N=512 K=256 (pw1)", 512, 256), ("N=256 K=768 (dqkv dgrad)", 256, 768)):
+    for name, N, K in shapes:
         a = torch.randn((M, K), device=dev).to(bf)
         w = torch.randn((N, K), device=dev).to(bf)
         c = torch.empty((M, N), dtype=bf, device=dev)
