@@ -14,7 +14,10 @@ Besides the headline value the line carries
   roofline      the dominant kernel (largest share of device time) from a second, instrumented pass over the same
                 K steps: every launch carries HIP start/stop events on its own stream (cfm_prof_*: the events are attached to the
                 dispatch, so they read the kernel's own begin/end like rocprofv3 does), algorithmic FLOPs per launch
-                / average launch duration, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+                / average launch duration, against the dense bf16 MFMA peak (2.5 PFLOP/s); roofline.traffic = that kernel's HBM bytes per
+                launch from the PMC counters, MEASURED IN THIS RUN at N=1 (two child passes of this file under rocprofv3 --pmc, FETCH_SIZE and
+                WRITE_SIZE separately, gfx950 correction; roofline.traffic_source says how) -- a committed profile is quoted only as a
+                fallback and only when its source digest matches the library's sources, else null;
   cpu_baseline  the CPU oracle (a port of the reference's PyTorch CPU path, oracle/conformer_oracle.py) timed on the host
                 cores of the same box on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -201,14 +204,24 @@ KERNEL_SYMBOL = {"chain_dwfinal_macaron": "cfm_rowchain_kernel", "chain_macaron"
                  "gemm_conv": "cfm_gemm_kernel", "gemm": "cfm_gemm_kernel", "attn2": "cfm_attn2_kernel", "attn": "cfm_attn_kernel"}
 
 
-def measured_traffic(kernel_name, d_model):
-    """HBM bytes per launch of the dominant kernel from profiles/*_hbm_traffic.json (scripts/collect_traffic.py: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction), or None when no such profile is committed."""
+def source_digest():
+    """sha256 over the library's sources: a committed traffic profile is only quoted for the sources it was collected on."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-    if not files:
-        return None
-    kernels = json.load(open(files[-1]))["kernels"]
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "conformer-pytorch-lightning_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def short_kernel_name(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def pick_traffic(kernels, kernel_name, d_model):
+    """kernels: {short symbol with template arguments: bytes per launch}; the entry of the bench's dominant kernel, or None."""
     # template arguments after <type, D, FF,: head steps, depthwise input stage, feed-forward, tail steps, GLU
     role = {"chain_dwfinal_macaron": "1, true, true, 3, false, false, false, true", "chain_macaron": "0, false, true, 3, false",
             "chain_dwfinal": "1, true, true, 0, false", "chain_final": "1, false, true, 0, false", "chain_convin": "1, false, false, 1, true"}
@@ -217,8 +230,70 @@ def measured_traffic(kernel_name, d_model):
             want = role.get(prefix)
             for k, v in kernels.items():
                 if sym in k and (want is None or (want in k and ("%d," % d_model) in k)):
-                    return round(v["hbm_bytes_per_launch"], 1)
+                    return round(v, 1)
     return None
+
+
+def live_traffic(args, steps=3, warmup=1, timeout=300):
+    """HBM bytes per launch of every kernel of this workload, measured NOW: two child runs of this file under
+    `rocprofv3 --kernel-trace --pmc <counter>` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit the TCC counter slots
+    together), no other trace domain -- with the gfx950 correction bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024
+    (MI355X_MICROARCH.md, HBM traffic).  Children, not exec: this process keeps its GPU context.  Returns ({kernel: bytes}, note)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this run is itself under a profiler"
+    base = tempfile.mkdtemp(prefix="cfm_traffic_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "CFM_BENCH_FORCE_DIST")}
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(base, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(steps), "--warmup", str(warmup), "--batch", str(args.batch), "--frames", str(args.frames), "--precision", args.precision,
+                   "--graph", "0", "--train-steps", "0", "--no-cpu-baseline", "--no-parity", "--no-live-traffic"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+            agg = collections.defaultdict(lambda: [0, 0.0])
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    a = agg[short_kernel_name(row["Kernel_Name"])]
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+            sums[counter] = agg
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return None, "live traffic pass: %s" % (type(e).__name__,)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    out = {}
+    for k in set(sums["FETCH_SIZE"]) | set(sums["WRITE_SIZE"]):
+        f, w = sums["FETCH_SIZE"].get(k, [0, 0.0]), sums["WRITE_SIZE"].get(k, [0, 0.0])
+        n = max(f[0], w[0])
+        if n:
+            out[k] = (2.0 * f[1] * 1024.0 + w[1] * 1024.0) / n
+    return out, "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE: two child passes of this bench inside this run (%d eager steps each), " \
+                "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950 correction)" % steps
+
+
+def committed_traffic():
+    """The newest profiles/*_hbm_traffic.json (scripts/collect_traffic.py), quoted ONLY when it was collected on these very sources."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None, "no live pass and no committed profile"
+    doc = json.load(open(files[-1]))
+    if doc.get("source_sha256_16") != source_digest():
+        return None, "%s predates the library sources (digest mismatch): not quoted" % os.path.relpath(files[-1], ROOT)
+    return {k: v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items()}, "%s (same sources, digest %s)" % (os.path.relpath(files[-1], ROOT), source_digest())
 
 
 def main():
@@ -238,6 +313,7 @@ def main():
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward: the headline encoder-forward metric (BASELINE configs[1]); train: the config-3 training step as the headline line")
     ap.add_argument("--train-steps", type=int, default=6, help="optimizer steps of the short training measurement appended to the forward line (0: skip)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity figure (2 utterances against the CPU oracle)")
     args = ap.parse_args()
     if args.selftest_cpu:
@@ -373,10 +449,17 @@ def main():
             achieved = e["flops"] / e["calls"] / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.precision]
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": measured_traffic(name, CFG2["encoder_dim"]),
+                        "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": None,
                         "launches_per_step": e["calls"] // args.steps, "avg_launch_us": round(avg_ms * 1e3, 2),
                         "share_of_device_time": round(e["ms"] / total_ms, 4),
                         "algorithmic_gflop_per_launch": round(e["flops"] / e["calls"] / 1e9, 3)}
+            tables, note = (None, "--no-live-traffic") if (args.no_live_traffic or world != 1) else live_traffic(args)
+            if tables is None:
+                tables, note2 = committed_traffic()
+                note = "%s; %s" % (note, note2)
+            if tables is not None:
+                roofline["traffic"] = pick_traffic(tables, name, CFG2["encoder_dim"])
+            roofline["traffic_source"] = note
             if name.startswith("chain_macaron") or name.startswith("chain_dwfinal") or name.startswith("chain_final"):
                 # what actually bounds the row chains: every CU streams the block's weights through its own
                 # vector-memory path, 64 B/clk/CU at the 2.4 GHz the MFMA peak is quoted at

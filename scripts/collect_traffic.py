@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_pass(counter, out_dir, steps, warmup, extra=()):
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, *extra, "--output-format", "csv", "-d", out_dir, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--graph", "0", "--train-steps", "0", "--no-parity"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--graph", "0", "--train-steps", "0", "--no-parity", "--no-live-traffic"]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, check=True, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rows = list(csv.DictReader(open(glob.glob(os.path.join(out_dir, "*", "*_counter_collection.csv"))[0])))
@@ -40,6 +40,12 @@ def run_pass(counter, out_dir, steps, warmup, extra=()):
         a[0] += 1
         a[1] += float(r["Counter_Value"])
     return agg
+
+
+def bench_source_digest():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.source_digest()
 
 
 def short(name):
@@ -65,7 +71,7 @@ def main():
     path = os.path.join(ROOT, "profiles", tag + "_hbm_traffic.json")
     json.dump({"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py (eager launches); "
                          "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads)",
-               "kernels": out}, open(path, "w"), indent=1, sort_keys=True)
+               "source_sha256_16": bench_source_digest(), "kernels": out}, open(path, "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
         print("%-90s launches %5d  %10.2f MB/launch" % (k[:90], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
     print("wrote", path)
