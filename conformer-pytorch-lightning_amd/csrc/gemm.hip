@@ -46,8 +46,12 @@ struct GemmArgs {
     int convC, T1, F1, T2, F2;
 };
 
-template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV>
-__global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   // two workgroups per CU: <= 256 registers per wavefront
+// KG = 2: TWO groups of four wavefronts per tile, each walking its own half of K through its own LDS buffers; the halves meet through LDS
+// before the epilogue (group 0 + group 1, a fixed order: deterministic).  For long-K products with few tiles (a feed-forward's second
+// product at a training micro-batch: 300 tiles of 32 serial K steps, one workgroup per CU) -- the K chain of a workgroup is latency-bound,
+// so two chains per tile nearly halve it.
+template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void cfm_gemm_kernel(const GemmArgs g) {   // two workgroups per CU: <= 256 registers per wavefront
     constexpr int CPR = BK / 8;      // 16-byte chunks per LDS row
     constexpr int RPP = 256 / CPR;   // tile rows staged per pass of the 256 threads
     constexpr int ACH = BM / RPP;    // chunks per thread, activation tile
@@ -63,9 +67,13 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     constexpr int BUF = (A_PLANE + W_PLANE) * NPL;
     static_assert(!SPLIT || A_F32, "split mode reads f32 activations");
     static_assert(ACH >= 1 && WCH >= 1 && (FN % 2) == 0, "tile shape");
-    __shared__ u32x4 smem[2 * BUF];
+    static_assert(KG == 1 || ((KG == 2 || KG == 4) && !CONV && !SPLIT && !A_F32), "K groups: plain 16-bit products");
+    static_assert((KG - 1) * FM * FN * 256 <= 2 * BUF * KG, "the exchange area fits the staging buffers");
+    __shared__ u32x4 smem_all[2 * BUF * KG];
 
-    const int tid = threadIdx.x;
+    const int kgrp = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // wave-uniform
+    u32x4* const smem = smem_all + kgrp * 2 * BUF;
+    const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -129,9 +137,12 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
 
+    const int nkt_all = (g.K + BK - 1) / BK;
+    const int nkt = (nkt_all + KG - 1) / KG;              // K tiles per group (both groups run the same count: the barriers are shared;
+    const int kt_base = kgrp * nkt;                       //  a tile past K loads zeros)
     auto gload = [&](int kt, auto slot_c) {
         constexpr int S = decltype(slot_c)::value;
-        const int k0 = kt * BK + kc * 8;
+        const int k0 = (kt + kt_base) * BK + kc * 8;
         const bool kv = k0 < g.K;
         unsigned koff = (unsigned)k0;
         if constexpr (CONV) {
@@ -227,7 +238,6 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
     };
 
     // ---- main loop: 2 LDS buffers, 1 barrier per K tile, PF tiles of global loads in flight ------------------
-    const int nkt = (g.K + BK - 1) / BK;
     auto prologue = [&](auto s) {
         if (decltype(s)::value < nkt) gload(decltype(s)::value, s);
     };
@@ -264,6 +274,25 @@ __global__ __launch_bounds__(256, 2) void cfm_gemm_kernel(const GemmArgs g) {   
         if constexpr (PF > 2) {
             if (kt0 + 2 < nkt) body(kt0 + 2, std::integral_constant<int, 2>{});
         }
+    }
+
+    if constexpr (KG > 1) {                               // the other groups' partial sums -> LDS -> group 0, added in group order
+        __syncthreads();                                  // every wavefront is done reading its last K tile
+        f32x4* const xch = (f32x4*)smem_all;
+        if (kgrp > 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) xch[((kgrp - 1) * FM * FN + i * FN + j) * 256 + tid] = acc[i][j];
+        }
+        __syncthreads();
+        if (kgrp > 0) return;
+#pragma unroll
+        for (int q = 0; q < KG - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] += xch[(q * FM * FN + i * FN + j) * 256 + tid];
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -562,16 +591,16 @@ namespace {
 
 constexpr int CFM_PERSIST_GRID = 512;   // two resident workgroups on each of the 256 CUs (a multiple of 8: XCD round-robin)
 
-template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV>
+template <typename HT, int BM, int BN, int BK, bool A_F32, bool SPLIT, bool CONV, int KG = 1>
 int launch(const GemmArgs& a, hipStream_t s, const char* name) {
     const int tiles = (((a.M - a.m_begin + BM - 1) / BM + 7) / 8) * 8 * ((a.N + BN - 1) / BN);   // M tiles padded to a multiple of 8 (XCD groups)
-    static const std::string nm = std::string(name) + "_" + std::to_string(BM) + "x" + std::to_string(BN);
+    static const std::string nm = std::string(name) + "_" + std::to_string(BM) + "x" + std::to_string(BN) + (KG > 1 ? "_k" + std::to_string(KG) : std::string());
     const double rows = a.M - a.m_begin;
     const double flops = 2.0 * rows * (double)a.N * a.K;  // algorithmic (the 3 passes of SPLIT are not counted)
     const double bytes = rows * a.K * (A_F32 ? 4 : 2) + (double)a.N * a.K * 2 * (SPLIT ? 2 : 1) +
                          rows * a.N * (a.c_dtype == CFM_F32 ? 4 : 2);
     CfmProfScope prof(nm.c_str(), s, flops, bytes);
-    CFM_LAUNCH((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV>), dim3(tiles), dim3(256), 0, s, a);
+    CFM_LAUNCH((cfm_gemm_kernel<HT, BM, BN, BK, A_F32, SPLIT, CONV, KG>), dim3(tiles), dim3(256 * KG), 0, s, a);
     return cfm_launch_status(nm.c_str());
 }
 
@@ -614,6 +643,14 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
             // each alone on its CU and bound by its own load -> LDS -> MFMA chain): two 64 x 64 workgroups per CU overlap; measured 40.8 vs 44.8 us
             // there and 75.8 vs 83.2 us at M = 3 984, N = 512, K = 9 728 (config 4); 32 x 64 is slower again (L2 bytes per FLOP)
             if (tile == 2 && a.K >= 4096 && t64x128 < 384 && t64 >= 448) tile = 3;
+            // short K at a training micro-batch (M ~ 2 400: q|k|v 7.5 -> 6.3 us, pointwise-conv-1 6.5 -> 5.5 us): 32 x 64 tiles up to ~10 per CU
+            if (tile != 5 && a.K <= 768 && t32x64 >= 96 && t32x64 <= 2560) tile = 5;
+            // long K on few tiles (a feed-forward's second product and its input gradient at a training micro-batch: N = 256, K = 2 048):
+            // K groups.  Measured at M = 2 380 (scripts/bench_gemm_tiles.py): 32 x 64 13.7 us, 32 x 64 k2 12.7, 64 x 64 14.8, 64 x 64 k2 11.7,
+            // 64 x 64 k4 11.5, 32 x 64 k4 16.4, 64 x 128 k2 17.5 -- the gain is modest: the K chain is not what bounds these launches
+            if constexpr (!A_F32 && !CONV) {
+                if ((tile == 5 || tile == 3) && a.K >= 1024 && t64 <= 512) tile = 11;
+            }
         }
     }
     switch (tile) {
@@ -623,6 +660,9 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
         case 4: return launch<HT, 128, 64, BK, A_F32, SPLIT, CONV>(a, s, base);
         case 5: if constexpr (!SPLIT) return launch<HT, 32, 64, BK, A_F32, SPLIT, CONV>(a, s, base); else break;
         case 6: if constexpr (!SPLIT) return launch<HT, 32, 128, BK, A_F32, SPLIT, CONV>(a, s, base); else break;
+        case 9: if constexpr (!SPLIT && !A_F32 && !CONV) return launch<HT, 32, 64, BK, false, false, false, 2>(a, s, base); else break;
+        case 10: if constexpr (!SPLIT && !A_F32 && !CONV) return launch<HT, 64, 64, BK, false, false, false, 4>(a, s, base); else break;
+        case 11: if constexpr (!SPLIT && !A_F32 && !CONV) return launch<HT, 64, 64, BK, false, false, false, 2>(a, s, base); else break;
         default: break;
     }
     return cfm_fail(CFM_ERR_ARG, "cfm_gemm: unknown tile id %d", tile);

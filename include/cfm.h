@@ -91,7 +91,10 @@ typedef struct {
     int32_t tile;                                       /* 0 = auto; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64, 5: 32x64, 6: 32x128,
                                                            7: 128x128 persistent workgroups (16-bit plain products, K %% 64 == 0),
                                                            8: 256x256 with LDS-DMA staging (csrc/gemm256.hip: 16-bit operands, K %% 64 == 0, bias / SiLU /
-                                                              ReLU epilogues; auto when a cost model says its whole rounds beat the 128x128 tiles) */
+                                                              ReLU epilogues; auto when a cost model says its whole rounds beat the 128x128 tiles),
+                                                           9 / 11 / 10: 32x64 k2 / 64x64 k2 / 64x64 k4 -- two or four K groups of four wavefronts per tile that meet
+                                                              through LDS (16-bit operands, any epilogue; 11 is auto for K >= 1024 on <= 512 tiles of 64x64: the
+                                                              long-K products of a training micro-batch) */
     int32_t mask_mode;                                  /* 0: row_mask zeroes the OUTPUT row (after act, before residual);
                                                            1: row_mask zeroes the INPUT row (acc = 0, bias/act still apply) */
     /* training: */

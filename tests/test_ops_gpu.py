@@ -153,6 +153,28 @@ def test_gemm_pair_stores(cfm, M, N, K, ldc, tile):
         cfm.gemm(a, rnd((N + 1, K), 64).bfloat16())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(2380, 256, 2048), (77, 132, 1096), (333, 64, 1024), (40, 256, 72)])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+@pytest.mark.parametrize("tile", [9, 10, 11])
+def test_gemm_two_k_groups_matches_one(cfm, M, N, K, wdt, tile):
+    """Tile ids 9 / 10 / 11 (32 x 64 k2, 64 x 64 k4, 64 x 64 k2: K groups per tile that meet through LDS): against the one-group tile with every epilogue family -- K tails,
+    an odd tile count per group, ragged M / N, residual + alpha, SiLU, GLU, row masks; the sums are regrouped (half + half), so f32 close."""
+    torch.manual_seed(M + K)
+    dt = W_DT[wdt]
+    a = torch.randn((M, K), device="cuda").to(dt)
+    w = (torch.randn((N, K), device="cuda") / K ** 0.5).to(dt)
+    bias = torch.randn((N,), device="cuda")
+    res = torch.randn((M, N), device="cuda")
+    mask = (torch.rand((M,), device="cuda") > 0.2).to(torch.uint8)
+    for kw in (dict(), dict(act=cfm.ACT_SILU, out_dtype=dt), dict(residual=res, alpha=0.5), dict(row_mask=mask)) + ((dict(act=cfm.ACT_GLU),) if N % 64 == 0 else ()):
+        ref = cfm.gemm(a, w, bias=bias, tile=5, **kw)
+        out = cfm.gemm(a, w, bias=bias, tile=tile, **kw)
+        assert out.shape == ref.shape and relerr(out, ref) < (2e-6 if out.dtype == torch.float32 else 1e-2), kw.keys()
+    again = cfm.gemm(a, w, bias=bias, tile=tile)
+    assert torch.equal(again, cfm.gemm(a, w, bias=bias, tile=tile))          # fixed merge order: reproducible
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 2304, 192), (20000, 1000, 576), (300, 5002, 512), (70000, 1282, 64), (100, 100, 64)])
 @pytest.mark.parametrize("wdt", ["bf16", "fp16"])
 def test_gemm_persistent_matches_tiled(cfm, M, N, K, wdt):
