@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libconformer_gfx950.so")
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GLU, ACT_DSILU, ACT_DRELU = 0, 1, 2, 3, 4, 5
+TILE_AUTO_TRAIN = -1            # cfm_gemm_desc.tile: automatic choice with the K-group tiles allowed (training paths; cfm.h)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -225,8 +226,8 @@ def lib():
         L.cfm_col2im_relu_bwd.argtypes = [c_p, c_i32, c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_conv1_wgrad_ws.argtypes = [c_i32, c_i32, c_i32]
         L.cfm_conv1_wgrad.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
-        L.cfm_ctc_nll_train.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
-        L.cfm_ctc_grad.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]
+        L.cfm_ctc_nll_train.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+        L.cfm_ctc_grad.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]
         L.cfm_adam_step.argtypes = [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p, c_p]
         L.cfm_sumsq.argtypes = [c_p, c_i64, c_p, c_i32, c_p, c_p]
         L.cfm_dropout_rows.argtypes = [c_p, c_i32, c_p, c_i32, c_p, c_f, c_f, ctypes.c_uint32, c_f, ctypes.c_uint32, c_i64, c_i32, c_p]

@@ -22,6 +22,12 @@ import cfm
 from cfm import packing
 
 
+def _gemm(*args, **kw):
+    """cfm.gemm with the training tile choice (cfm.h CFM_TILE_AUTO_TRAIN: K-group tiles allowed), as csrc/train_layer.cpp launches its products."""
+    kw.setdefault("tile", cfm.TILE_AUTO_TRAIN)
+    return cfm.gemm(*args, **kw)
+
+
 def _f32c(t):
     return (t if t.dtype == torch.float32 else t.float()).contiguous()
 
@@ -47,11 +53,11 @@ def ffn_fwd(pk, x, ln, prec, alpha, act=cfm.ACT_SILU, drop_h=None, drop_o=None):
     FF = pk.w1.shape[0]
     xn = cfm.layernorm(x, ln[0], ln[1], out1_dtype=adt)[0] if ln is not None else (x if x.dtype == adt else cfm.cast(x, adt))
     z = torch.empty((M, FF), dtype=adt, device=x.device)
-    h = cfm.gemm(xn, pk.w1, bias=pk.b1, w_lo=pk.w1_lo, act=act, out_dtype=adt, pre_out=z, drop=drop_h)
+    h = _gemm(xn, pk.w1, bias=pk.b1, w_lo=pk.w1_lo, act=act, out_dtype=adt, pre_out=z, drop=drop_h)
     if ln is not None:
-        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, residual=x, alpha=alpha, drop=drop_o)
+        y = _gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, residual=x, alpha=alpha, drop=drop_o)
     else:
-        y = cfm.gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, out_dtype=torch.float32, drop=drop_o)
+        y = _gemm(h, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, out_dtype=torch.float32, drop=drop_o)
     return y, (x, xn, z, h)
 
 
@@ -66,9 +72,9 @@ def ffn_bwd(pk, saved, dy, ln, prec, alpha, act=cfm.ACT_SILU, drop_h=None, drop_
     if drop_h is not None and dact != cfm.ACT_DSILU:
         raise NotImplementedError("hidden dropout with a ReLU feed-forward in train mode")
     dW2, db2 = cfm.gemm_tn(dyb, h, want_colsum=True, alpha=alpha, mma_code=mma, split=sp)
-    dz = cfm.gemm(dyb, pk.w2t, w_lo=pk.w2t_lo, act=dact, aux=z, alpha=alpha, out_dtype=prec.act_dtype, drop=drop_h)
+    dz = _gemm(dyb, pk.w2t, w_lo=pk.w2t_lo, act=dact, aux=z, alpha=alpha, out_dtype=prec.act_dtype, drop=drop_h)
     dW1, db1 = cfm.gemm_tn(dz, xn, want_colsum=True, mma_code=mma, split=sp)
-    dxn = cfm.gemm(dz, pk.w1t, w_lo=pk.w1t_lo, out_dtype=torch.float32)
+    dxn = _gemm(dz, pk.w1t, w_lo=pk.w1t_lo, out_dtype=torch.float32)
     grads = {"w_1.weight": dW1, "w_1.bias": db1, "w_2.weight": dW2, "w_2.bias": db2}
     if ln is None:
         return dxn, grads, None
@@ -84,7 +90,7 @@ def mhsa_fwd(mod, pk, x, ln, B, T, mask8, m_str, prec, relative, drop_a=None, dr
     M, D = x.shape
     H, dk = mod.num_heads, mod.d_k
     xn = cfm.layernorm(x, ln[0], ln[1], out1_dtype=adt)[0] if ln is not None else (x if x.dtype == adt else cfm.cast(x, adt))
-    qkv = cfm.gemm(xn, pk.qkv_w, bias=pk.qkv_b, w_lo=pk.qkv_w_lo, out_dtype=adt)
+    qkv = _gemm(xn, pk.qkv_w, bias=pk.qkv_b, w_lo=pk.qkv_w_lo, out_dtype=adt)
     ctx = torch.empty((M, D), dtype=adt, device=x.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
     st = (T * 3 * D, 3 * D)
@@ -93,9 +99,9 @@ def mhsa_fwd(mod, pk, x, ln, B, T, mask8, m_str, prec, relative, drop_a=None, dr
     if drop_o is None and drop_o2 is not None:
         drop_o, drop_o2 = drop_o2, None
     if ln is not None:
-        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, residual=x, alpha=1.0, drop=drop_o, drop2=drop_o2)
+        y = _gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, residual=x, alpha=1.0, drop=drop_o, drop2=drop_o2)
     else:
-        y = cfm.gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, out_dtype=torch.float32, drop=drop_o, drop2=drop_o2)
+        y = _gemm(ctx, pk.out_w, bias=pk.out_b, w_lo=pk.out_w_lo, out_dtype=torch.float32, drop=drop_o, drop2=drop_o2)
     return y, (x, xn, qkv, ctx, lse)
 
 
@@ -108,13 +114,13 @@ def mhsa_bwd(mod, pk, saved, dy, ln, B, T, mask8, m_str, prec, relative, drop_a=
         drop_o, drop_o2 = drop_o2, None
     dyb = dy if drop_o is None else cfm.dropout_rows(dy, prec.act_dtype, drop=drop_o, drop2=drop_o2)
     dWo, dbo = cfm.gemm_tn(dyb, ctx, want_colsum=True, mma_code=mma, split=sp)
-    dctx = cfm.gemm(dyb, pk.out_t, w_lo=pk.out_t_lo, out_dtype=prec.act_dtype)
+    dctx = _gemm(dyb, pk.out_t, w_lo=pk.out_t_lo, out_dtype=prec.act_dtype)
     dqkv = torch.empty_like(qkv)
     st = (T * 3 * D, 3 * D)
     cfm.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ctx, dctx, lse, B, H, T, T, dk, st, st, st, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], mask=mask8,
                       mask_str=m_str, mma_code=mma, split=sp, drop=drop_a)
     dWqkv, dbqkv = cfm.gemm_tn(dqkv, xn, want_colsum=True, mma_code=mma, split=sp)
-    dxn = cfm.gemm(dqkv, pk.qkv_t, w_lo=pk.qkv_t_lo, out_dtype=torch.float32)
+    dxn = _gemm(dqkv, pk.qkv_t, w_lo=pk.qkv_t_lo, out_dtype=torch.float32)
     grads = {"linear_q.weight": dWqkv[:D], "linear_k.weight": dWqkv[D:2 * D], "linear_v.weight": dWqkv[2 * D:],
              "linear_q.bias": dbqkv[:D], "linear_k.bias": dbqkv[D:2 * D], "linear_v.bias": dbqkv[2 * D:],
              "linear_out.weight": dWo, "linear_out.bias": dbo}
@@ -143,7 +149,7 @@ def conv_module_fwd(mod, pk, x, ln, B, T, keep, prec, drop_o=None):
         xn = x if x.dtype == adt else cfm.cast(x, adt)
     u = torch.empty((M, 2 * D), dtype=adt, device=x.device)
     # without a LayerNorm in front the padded INPUT rows are zeroed in the GEMM (mask_mode 1: acc = 0, bias kept -- quirk Q5)
-    glu = cfm.gemm(xn, pk.pw1_w, bias=pk.pw1_b, w_lo=pk.pw1_w_lo, act=cfm.ACT_GLU, out_dtype=adt, pre_out=u,
+    glu = _gemm(xn, pk.pw1_w, bias=pk.pw1_b, w_lo=pk.pw1_w_lo, act=cfm.ACT_GLU, out_dtype=adt, pre_out=u,
                    row_mask=keep if ln is None else None, mask_mode=1)
     bn = mod.norm
     momentum = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
@@ -153,9 +159,9 @@ def conv_module_fwd(mod, pk, x, ln, B, T, keep, prec, drop_o=None):
     if bn.track_running_stats:
         bn.num_batches_tracked += 1
     if ln is not None:
-        y = cfm.gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, residual=x, alpha=1.0, drop=drop_o)
+        y = _gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, residual=x, alpha=1.0, drop=drop_o)
     else:
-        y = cfm.gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, out_dtype=torch.float32)
+        y = _gemm(s.view(M, D), pk.pw2_w, bias=pk.pw2_b, w_lo=pk.pw2_w_lo, row_mask=keep, mask_mode=0, out_dtype=torch.float32)
     return y, (x, xn, u, glu, c, stats, s)
 
 
@@ -168,12 +174,12 @@ def conv_module_bwd(mod, pk, saved, dy, ln, B, T, keep, prec, drop_o=None):
     dyb = dy if drop_o is None else cfm.dropout_rows(dy, adt, drop=drop_o, row_mask=keep)
     km = keep if drop_o is None else None
     dW2, db2 = cfm.gemm_tn(dyb, s.view(M, D), want_colsum=True, row_mask=km, mma_code=mma, split=sp)
-    ds = cfm.gemm(dyb, pk.pw2_t, w_lo=pk.pw2_t_lo, row_mask=km, mask_mode=1 if km is not None else 0, out_dtype=adt)
+    ds = _gemm(dyb, pk.pw2_t, w_lo=pk.pw2_t_lo, row_mask=km, mask_mode=1 if km is not None else 0, out_dtype=adt)
     dglu, ddw_w, ddw_b, dgamma, dbeta = cfm.dwconv_bn_train_bwd(ds.view(B, T, D), c, stats, glu.view(B, T, D), pk.dw_w, adt)
     du = cfm.glu_bwd(u, dglu.view(M, D), adt)
     # pointwise-conv-1 saw zeroed padded rows: xn already is (LayerNorm path) or is masked here (bare module)
     dW1i, db1i = cfm.gemm_tn(du, xn, want_colsum=True, mma_code=mma, split=sp) if ln is not None or keep is None else _pw1_wgrad_masked(du, xn, keep, mma, sp)
-    dxn = cfm.gemm(du, pk.pw1_t, w_lo=pk.pw1_t_lo, out_dtype=torch.float32)
+    dxn = _gemm(du, pk.pw1_t, w_lo=pk.pw1_t_lo, out_dtype=torch.float32)
     dW1 = torch.empty_like(dW1i)
     dW1[pk.idx] = dW1i                                            # undo the value / gate row interleave of the pack
     db1 = torch.empty_like(db1i)
@@ -205,8 +211,8 @@ def subsampling_fwd(pk, x, cmvn, prec):
     T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
     T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
     h1 = cfm.conv1_relu(x, pk.w1, pk.b1, adt, cmvn=cmvn, mma=cfm.conv1_relu_mma_supported(C, adt))
-    h2 = cfm.gemm(h1, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2), out_dtype=adt)
-    y = cfm.gemm(h2.view(B * T2, F2 * C), pk.wl, bias=pk.bl, w_lo=pk.wl_lo, out_dtype=torch.float32)
+    h2 = _gemm(h1, pk.w2, bias=pk.b2, w_lo=pk.w2_lo, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2), out_dtype=adt)
+    y = _gemm(h2.view(B * T2, F2 * C), pk.wl, bias=pk.bl, w_lo=pk.wl_lo, out_dtype=torch.float32)
     return y, (x, h1, h2, (B, T, F, C, T1, F1, T2, F2), cmvn)
 
 
@@ -216,9 +222,9 @@ def subsampling_bwd(pk, saved, dy, prec):
     Dout = pk.wl.shape[0]
     h2f = h2.view(B * T2, F2 * C)
     dWl, dbl = cfm.gemm_tn(dy, h2f, want_colsum=True, mma_code=mma, split=sp)
-    dh2 = cfm.gemm(dy, pk.wlt, w_lo=pk.wlt_lo, act=cfm.ACT_DRELU, aux=h2f, alpha=1.0, out_dtype=adt).view(B * T2 * F2, C)
+    dh2 = _gemm(dy, pk.wlt, w_lo=pk.wlt_lo, act=cfm.ACT_DRELU, aux=h2f, alpha=1.0, out_dtype=adt).view(B * T2 * F2, C)
     dW2, db2 = cfm.gemm_tn(dh2, h1, conv=(C, T1, F1, T2, F2), want_colsum=True, mma_code=mma, split=sp)
-    dcol = cfm.gemm(dh2, pk.w2t, w_lo=pk.w2t_lo, out_dtype=adt)
+    dcol = _gemm(dh2, pk.w2t, w_lo=pk.w2t_lo, out_dtype=adt)
     dh1 = cfm.col2im_relu_bwd(dcol, h1, adt)
     dw1, db1 = cfm.conv1_wgrad(dh1, x, cmvn=cmvn)
     return {"conv.0.weight": dw1.t().reshape(C, 1, 3, 3), "conv.0.bias": db1,
@@ -394,6 +400,18 @@ def layer_grad_layout(layer, offsets=None):
 
 
 def _train_weights_struct(layer, pks):
+    hit = layer.__dict__.get("_train_w_struct")
+    if hit is not None and hit[0] is pks:                   # the same pack objects (packing.pack_layer_train returns them until a parameter changes)
+        bn = layer.conv_module.norm
+        if bn.momentum is None:                             # cumulative moving average: the factor follows the batch count
+            hit[1].bn_momentum = 1.0 / float(int(bn.num_batches_tracked) + 1)
+        return hit[1]
+    w = _build_train_weights_struct(layer, pks)
+    layer.__dict__["_train_w_struct"] = (pks, w)
+    return w
+
+
+def _build_train_weights_struct(layer, pks):
     ffm, att, cv, ff = pks
     w = cfm.LayerTrainWeights()
     for short, name in (("ffm", "norm_ff_macaron"), ("mha", "norm_mha"), ("conv", "norm_conv"), ("ff", "norm_ff"), ("final", "norm_final")):
@@ -432,11 +450,13 @@ def _side_stream(dev):
     return st
 
 
-def _composite_ok(layer, x):
+def _composite_ok(layer, x, flat=False):
+    """flat: the block's parameters are views of the trainer's flat f32 leaf (trainer.py) -- contiguous float32 by construction, so the walk over
+    the module tree (~0.1 ms of host time per call, and the training step is host-bound) is skipped."""
     bn = layer.conv_module.norm
     return (USE_COMPOSITE and layer.kernel_size == 15 and bn.weight is not None and bn.bias is not None and
             layer.conv_module.pointwise_conv1.bias is not None and layer.conv_module.depthwise_conv.bias is not None and
-            all(p.dtype == torch.float32 and p.is_contiguous() for p in layer.parameters()))
+            (flat or all(p.dtype == torch.float32 and p.is_contiguous() for p in layer.parameters())))
 
 
 def _layer_composite_forward(ctx, x0, layer, prec, mask8, m_str, keep, pks, B, T, D):
@@ -533,9 +553,10 @@ class EncoderLayerFn(torch.autograd.Function):
         rel = layer.use_relative
         ctx.comp = None
         ctx.flat = len(params) == 1 and params[0] is getattr(layer, "_flat_leaf", None)
-        if ctx.flat and not _composite_ok(layer, x):
+        comp = _composite_ok(layer, x, ctx.flat)
+        if ctx.flat and not comp:
             raise RuntimeError("a block registered with a flat parameter leaf (trainer.py) needs the composite train path")
-        if _composite_ok(layer, x):
+        if comp:
             pks = packing.pack_layer_train(layer, prec, rel) if USE_PACK_KERNEL else (
                 packing.pack_ffn_train(layer.feed_forward_macaron, prec), packing.pack_mhsa_train(layer.self_attn, prec, rel),
                 packing.pack_conv_module_train(layer.conv_module, prec), packing.pack_ffn_train(layer.feed_forward, prec))
@@ -603,7 +624,7 @@ class CTCLossFn(torch.autograd.Function):
         pk = packing.pack_ctc_train(mod, prec)
         B, T, D = enc_out.shape
         x2 = _f32c(enc_out.reshape(B * T, D))
-        logits = cfm.gemm(x2, pk.w, bias=pk.b, w_lo=pk.w_lo, out_dtype=torch.float32).view(B, T, pk.Vp)
+        logits = _gemm(x2, pk.w, bias=pk.b, w_lo=pk.w_lo, out_dtype=torch.float32).view(B, T, pk.Vp)
         nll, state = cfm.ctc_nll_train(logits, pk.V, enc_lens, labels, label_lens)
         ctx.args = (prec, pk, x2, logits, state, enc_lens, labels, label_lens, B, T, D)
         return nll.sum() / labels.size(1)
@@ -614,5 +635,5 @@ class CTCLossFn(torch.autograd.Function):
         gdev = _f32c(gout.reshape(1))
         dlog = cfm.ctc_grad(logits, pk.V, enc_lens, labels, label_lens, state, gscale=1.0 / labels.size(1), gscale_dev=gdev).view(B * T, pk.Vp)
         dW, db = cfm.gemm_tn(dlog, x2, want_colsum=True, mma_code=prec.w_code, split=prec.split)
-        dx = cfm.gemm(dlog, pk.wt, w_lo=pk.wt_lo, out_dtype=torch.float32)
+        dx = _gemm(dlog, pk.wt, w_lo=pk.wt_lo, out_dtype=torch.float32)
         return dx.view(B, T, D), None, None, None, None, None, dW[:pk.V], db[:pk.V]

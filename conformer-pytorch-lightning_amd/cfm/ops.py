@@ -2,6 +2,8 @@
 allocates its output with torch.empty on the same device, and enqueues on the current HIP stream."""
 import ctypes
 
+import os
+
 import torch
 
 import cfm as _c
@@ -610,10 +612,13 @@ def _ctc_args(logits, enc_lens, labels, label_lens):
         raise ValueError("cfm.ctc: batch sizes differ")
 
 
-def ctc_nll_train(logits, V, enc_lens, labels, label_lens):
-    """As ctc_nll, keeping what the backward needs: returns (nll [B], state) with state = (work, alpha, lse, nll_shifted) owned by the caller."""
+def ctc_nll_train(logits, V, enc_lens, labels, label_lens, beta_now=None):
+    """As ctc_nll, keeping what the backward needs: returns (nll [B], state) with state = (work, alpha, lse, nll_shifted, beta | None) owned by the
+    caller.  beta_now: run the backward recursion beside the forward one (one launch of 2 B workgroups) instead of inside ctc_grad."""
     _c.require_hip(logits, enc_lens, labels, label_lens)
     _ctc_args(logits, enc_lens, labels, label_lens)
+    if beta_now is None:
+        beta_now = os.environ.get("CFM_CTC_BETA_NOW", "1") != "0"        # A/B switch (same bits either way)
     B, T = logits.shape[:2]
     SM = 2 * labels.size(1) + 2
     dev = logits.device
@@ -622,23 +627,25 @@ def ctc_nll_train(logits, V, enc_lens, labels, label_lens):
     work = torch.empty((B, T, SM), dtype=torch.float32, device=dev)
     alpha = torch.empty((B, T, SM), dtype=torch.float32, device=dev)
     lse = torch.empty((B, T), dtype=torch.float32, device=dev)
+    beta = torch.empty((B, T, SM), dtype=torch.float32, device=dev) if beta_now else None
     _c.check(_c.lib().cfm_ctc_nll_train(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
-                                        _c.ptr(work), _c.ptr(alpha), _c.ptr(lse), _c.ptr(nll), _c.ptr(nllp), _c.stream()), "cfm_ctc_nll_train")
-    return nll, (work, alpha, lse, nllp)
+                                        _c.ptr(work), _c.ptr(alpha), _c.ptr(lse), _c.ptr(nll), _c.ptr(nllp), _c.ptr(beta), _c.stream()), "cfm_ctc_nll_train")
+    return nll, (work, alpha, lse, nllp, beta)
 
 
 def ctc_grad(logits, V, enc_lens, labels, label_lens, state, gscale=1.0, gscale_dev=None, out=None):
-    """d (sum_b nll_b) / d logits * gscale * (*gscale_dev), f32 [B,T,ld]; consumes state[1] (alpha is overwritten)."""
+    """d (sum_b nll_b) / d logits * gscale * (*gscale_dev), f32 [B,T,ld]; consumes state[1] (alpha is overwritten unless the state carries beta)."""
     _c.require_hip(logits, enc_lens, labels, label_lens, gscale_dev, out)
     _ctc_args(logits, enc_lens, labels, label_lens)
-    work, alpha, lse, nllp = state
+    work, alpha, lse, nllp = state[:4]
+    beta = state[4] if len(state) > 4 else None
     B, T = logits.shape[:2]
     if out is None:
         out = torch.empty_like(logits)
     if out.dtype != torch.float32 or out.shape != logits.shape or out.stride() != logits.stride():
         raise ValueError("cfm.ctc_grad: out must match logits")
     _c.check(_c.lib().cfm_ctc_grad(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
-                                   _c.ptr(work), _c.ptr(alpha), _c.ptr(lse), _c.ptr(nllp), gscale, _c.ptr(gscale_dev), _c.ptr(out), _c.stream()), "cfm_ctc_grad")
+                                   _c.ptr(work), _c.ptr(alpha), _c.ptr(beta), _c.ptr(lse), _c.ptr(nllp), gscale, _c.ptr(gscale_dev), _c.ptr(out), _c.stream()), "cfm_ctc_grad")
     return out
 
 

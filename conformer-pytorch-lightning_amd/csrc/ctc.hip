@@ -96,12 +96,12 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_rows_kernel(const float* __res
 }
 
 // alpha: one workgroup per utterance
-__global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __restrict__ work, int T, int V, const int* __restrict__ enc_lens,
-                                                               const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
-                                                               float* __restrict__ nll, float* __restrict__ alpha_out, float* __restrict__ nllp_out) {
+__device__ __forceinline__ void ctc_alpha_body(const int b, const float* __restrict__ work, int T, int V, const int* __restrict__ enc_lens,
+                                               const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
+                                               float* __restrict__ nll, float* __restrict__ alpha_out, float* __restrict__ nllp_out) {
     __shared__ float alpha[2][CTC_MAXS + 2];
     __shared__ double osum[CTC_NT];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int len = min(max(enc_lens[b], 0), T);
     const int U = min(max(label_lens[b], 0), Umax);
     const int S = 2 * U + 1, SM = 2 * Umax + 2;             // row stride of work / alpha (the last slot of a work row is the frame's offset)
@@ -184,10 +184,14 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __re
 
 // beta recursion, one workgroup per utterance, walking the frames backwards; ab[t][s] = log(alpha_t(s) beta_t(s) / y_t(z_s)) replaces
 // alpha in place (both recursions include the emission at t, as torch's CTC does, hence the division)
-__global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __restrict__ work, float* __restrict__ ab, int T, int V, const int* __restrict__ enc_lens,
-                                                              const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens) {
+// SEP: the recursion does not read alpha; it writes bml[t][s] = log(beta_t(s) / y_t(z_s)) to its own array, so that it can run BESIDE the alpha
+// recursion (one launch of 2 B workgroups, cfm_ctc_nll_train with a beta buffer) and the gradient kernel forms alpha + bml -- the same f32
+// sum the in-place form stores.
+template <bool SEP>
+__device__ __forceinline__ void ctc_beta_body(const int b, const float* __restrict__ work, float* __restrict__ ab, int T, int V, const int* __restrict__ enc_lens,
+                                              const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens) {
     __shared__ float beta[2][CTC_MAXS + 2];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int len = min(max(enc_lens[b], 0), T);
     const int U = min(max(label_lens[b], 0), Umax);
     const int S = 2 * U + 1, SM = 2 * Umax + 2;
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __res
                 const float l = lp[(int64_t)t * SM + s];
                 const float bt = (s >= S - 2) ? l : -INFINITY;
                 beta[0][s] = bt;
-                abp[(int64_t)t * SM + s] = abp[(int64_t)t * SM + s] + bt - l;
+                if constexpr (SEP) abp[(int64_t)t * SM + s] = bt - l;
+                else abp[(int64_t)t * SM + s] = abp[(int64_t)t * SM + s] + (bt - l);      // grouped as the SEP form's sum
             }
         }
         __syncthreads();
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __res
             const int t = len - 2 - k, s = tid + i * CTC_NT;
             const bool ok = live[i] && t >= 0;
             nl[k][i] = ok ? lp[(int64_t)t * SM + s] : 0.f;
-            na[k][i] = ok ? abp[(int64_t)t * SM + s] : 0.f;
+            na[k][i] = (ok && !SEP) ? abp[(int64_t)t * SM + s] : 0.f;
         }
     for (int t0 = len - 2; t0 >= 0; t0 -= AHEAD) {
 #pragma unroll
@@ -248,10 +253,10 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __res
                         float a = logaddexp_(beta[cur][s], beta[cur][s + 1]);
                         if (skip[i]) a = logaddexp_(a, beta[cur][s + 2]);
                         beta[cur ^ 1][s] = a + nl[k][i];
-                        abp[(int64_t)t * SM + s] = na[k][i] + a;                  // alpha + beta - lp
+                        abp[(int64_t)t * SM + s] = SEP ? a : na[k][i] + a;        // (alpha +) beta - lp
                         const int tn = t - AHEAD;
                         nl[k][i] = tn >= 0 ? lp[(int64_t)tn * SM + s] : 0.f;
-                        na[k][i] = tn >= 0 ? abp[(int64_t)tn * SM + s] : 0.f;
+                        if constexpr (!SEP) na[k][i] = tn >= 0 ? abp[(int64_t)tn * SM + s] : 0.f;
                     }
                 }
                 __syncthreads();
@@ -261,13 +266,34 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_kernel(const float* __restrict__ work, int T, int V, const int* __restrict__ enc_lens,
+                                                               const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
+                                                               float* __restrict__ nll, float* __restrict__ alpha_out, float* __restrict__ nllp_out) {
+    ctc_alpha_body(blockIdx.x, work, T, V, enc_lens, labels, Umax, label_lens, nll, alpha_out, nllp_out);
+}
+
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_beta_kernel(const float* __restrict__ work, float* __restrict__ ab, int T, int V, const int* __restrict__ enc_lens,
+                                                              const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens) {
+    ctc_beta_body<false>(blockIdx.x, work, ab, T, V, enc_lens, labels, Umax, label_lens);
+}
+
+// both recursions in ONE launch: workgroups [0, B) walk forwards, [B, 2B) backwards (each is a serial chain of T' steps on one CU; a training
+// micro-batch has 5..40 utterances, so the two launches ran one after the other on a nearly empty chip: 113 + 113 us at config 3)
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_beta_kernel(const float* __restrict__ work, int B, int T, int V, const int* __restrict__ enc_lens,
+                                                                    const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
+                                                                    float* __restrict__ nll, float* __restrict__ alpha_out, float* __restrict__ nllp_out,
+                                                                    float* __restrict__ bml) {
+    if ((int)blockIdx.x < B) ctc_alpha_body(blockIdx.x, work, T, V, enc_lens, labels, Umax, label_lens, nll, alpha_out, nllp_out);
+    else ctc_beta_body<true>((int)blockIdx.x - B, work, bml, T, V, enc_lens, labels, Umax, label_lens);
+}
+
 // d nll / d logits, one wavefront per frame, persistent over frames.  Each wavefront keeps an occupancy table over the vocabulary in LDS:
 // the <= 2U+1 state posteriors exp(ab + nll) of a frame are scattered into it (several states share a class: blank, repeated labels),
 // the row is written as gs * (softmax - occupancy), and the touched entries are cleared again.
 __global__ __launch_bounds__(CTC_NT) void cfm_ctc_grad_kernel(const float* __restrict__ logits, int64_t ld, int B, int T, int V, const int* __restrict__ enc_lens,
                                                               const int* __restrict__ labels, int Umax, const int* __restrict__ label_lens,
-                                                              const float* __restrict__ ab, const float* __restrict__ lse, const float* __restrict__ nll,
-                                                              float gscale, const float* __restrict__ gscale_dev, float* __restrict__ dlogits) {
+                                                              const float* __restrict__ ab, const float* __restrict__ bml, const float* __restrict__ lse,
+                                                              const float* __restrict__ nll, float gscale, const float* __restrict__ gscale_dev, float* __restrict__ dlogits) {
     extern __shared__ float occ_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Vp = (V + 3) & ~3;
@@ -291,7 +317,10 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_grad_kernel(const float* __res
             continue;
         }
         const int S = 2 * min(max(label_lens[b], 0), Umax) + 1;
-        for (int s = lane; s < S; s += 64) atomicAdd(&occ[ext_label(labels, (int64_t)b * Umax, s, V)], __expf(ab[row_id * SM + s] + nl));
+        for (int s = lane; s < S; s += 64) {
+            const float abv = bml ? ab[row_id * SM + s] + bml[row_id * SM + s] : ab[row_id * SM + s];      // alpha + (beta - lp): the in-place form's own sum
+            atomicAdd(&occ[ext_label(labels, (int64_t)b * Umax, s, V)], __expf(abv + nl));
+        }
         __threadfence_block();
         const float l = lse[row_id];
         for (int c = lane * 4; c < (int)ld; c += 256) {
@@ -314,7 +343,7 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_grad_kernel(const float* __res
 }  // namespace
 
 static int ctc_forward(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
-                       const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nllp, cfm_stream_t stream) {
+                       const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nllp, float* beta, cfm_stream_t stream) {
     CFM_CHECK_ARG(logits && enc_lens && labels && label_lens && work && nll, "cfm_ctc_nll: null pointer");
     CFM_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0, "cfm_ctc_nll: bad shape B=%d T=%d V=%d Umax=%d", B, T, V, Umax);
     CFM_CHECK_ARG(2 * Umax + 1 <= CTC_MAXS, "cfm_ctc_nll: Umax=%d labels exceeds %d", Umax, (CTC_MAXS - 1) / 2);
@@ -327,6 +356,11 @@ static int ctc_forward(const float* logits, int64_t ld, int32_t B, int32_t T, in
                    labels, Umax, label_lens, work, lse);
         if (int rc = cfm_launch_status("cfm_ctc_nll (rows)")) return rc;
     }
+    if (beta) {
+        CfmProfScope prof("ctc_alpha_beta", s, 0.0, (double)B * T * (2 * Umax + 1) * 16);
+        CFM_LAUNCH(cfm_ctc_alpha_beta_kernel, dim3(2 * B), dim3(CTC_NT), 0, s, (const float*)work, B, T, V, enc_lens, labels, Umax, label_lens, nll, alpha, nllp, beta);
+        return cfm_launch_status("cfm_ctc_nll (alpha | beta)");
+    }
     CfmProfScope prof("ctc_alpha", s, 0.0, (double)B * T * (2 * Umax + 1) * 4);
     CFM_LAUNCH(cfm_ctc_alpha_kernel, dim3(B), dim3(CTC_NT), 0, s, (const float*)work, T, V, enc_lens, labels, Umax, label_lens, nll, alpha, nllp);
     return cfm_launch_status("cfm_ctc_nll (alpha)");
@@ -334,18 +368,18 @@ static int ctc_forward(const float* logits, int64_t ld, int32_t B, int32_t T, in
 
 extern "C" int cfm_ctc_nll(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens,
                            const int32_t* labels, int32_t Umax, const int32_t* label_lens, float* work, float* nll, cfm_stream_t stream) {
-    return ctc_forward(logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, work, nullptr, nullptr, nll, nullptr, stream);
+    return ctc_forward(logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, work, nullptr, nullptr, nll, nullptr, nullptr, stream);
 }
 
 extern "C" int cfm_ctc_nll_train(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
-                                 const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, cfm_stream_t stream) {
+                                 const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, float* beta, cfm_stream_t stream) {
     CFM_CHECK_ARG(alpha && lse && nll_shifted, "cfm_ctc_nll_train: null pointer");
-    return ctc_forward(logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, work, alpha, lse, nll, nll_shifted, stream);
+    return ctc_forward(logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, work, alpha, lse, nll, nll_shifted, beta, stream);
 }
 
 extern "C" int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
-                            const int32_t* label_lens, const float* work, float* alpha_beta, const float* lse, const float* nll_shifted, float gscale,
-                            const float* gscale_dev, float* dlogits, cfm_stream_t stream) {
+                            const int32_t* label_lens, const float* work, float* alpha_beta, const float* beta, const float* lse, const float* nll_shifted,
+                            float gscale, const float* gscale_dev, float* dlogits, cfm_stream_t stream) {
     const float* nll = nll_shifted;
     CFM_CHECK_ARG(logits && enc_lens && labels && label_lens && work && alpha_beta && lse && nll && dlogits, "cfm_ctc_grad: null pointer");
     CFM_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0 && 2 * Umax + 1 <= CTC_MAXS, "cfm_ctc_grad: bad shape B=%d T=%d V=%d Umax=%d", B, T, V, Umax);
@@ -354,7 +388,7 @@ extern "C" int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t 
     const size_t lds = (size_t)(CTC_NT / 64) * Vp * 4;
     CFM_CHECK_ARG(lds <= 128 * 1024, "cfm_ctc_grad: vocabulary of %d classes exceeds the LDS occupancy tables (<= 8192)", V);
     hipStream_t s = (hipStream_t)stream;
-    {
+    if (!beta) {                                            // the backward recursion has not run beside the forward one: here, in place over alpha
         CfmProfScope prof("ctc_beta", s, 0.0, (double)B * T * (2 * Umax + 1) * 12);
         CFM_LAUNCH(cfm_ctc_beta_kernel, dim3(B), dim3(CTC_NT), 0, s, work, alpha_beta, T, V, enc_lens, labels, Umax, label_lens);
         if (int rc = cfm_launch_status("cfm_ctc_grad (beta)")) return rc;
@@ -369,7 +403,7 @@ extern "C" int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t 
     int64_t nb = (rows + CTC_NT / 64 - 1) / (CTC_NT / 64);
     nb = nb > 512 ? 512 : nb;
     CfmProfScope prof("ctc_grad", s, 0.0, (double)rows * ld * 8);
-    CFM_LAUNCH(cfm_ctc_grad_kernel, dim3((unsigned)nb), dim3(CTC_NT), lds, s, logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, (const float*)alpha_beta, lse, nll,
+    CFM_LAUNCH(cfm_ctc_grad_kernel, dim3((unsigned)nb), dim3(CTC_NT), lds, s, logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, (const float*)alpha_beta, beta, lse, nll,
                gscale, gscale_dev, dlogits);
     return cfm_launch_status("cfm_ctc_grad");
 }

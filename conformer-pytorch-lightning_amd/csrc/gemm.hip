@@ -628,6 +628,8 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
             return launch_persistent<HT>(a, s, base);
         }
     }
+    const bool kgroups_ok = tile < 0;                   // CFM_TILE_AUTO_TRAIN: automatic choice, K-group tiles allowed (see cfm.h)
+    if (tile < 0) tile = 0;
     if (tile == 0) {
         // fill the 256 CUs: prefer the biggest tile that still yields >= ~1 workgroup per CU
         const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
@@ -648,8 +650,10 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
             // long K on few tiles (a feed-forward's second product and its input gradient at a training micro-batch: N = 256, K = 2 048):
             // K groups.  Measured at M = 2 380 (scripts/bench_gemm_tiles.py): 32 x 64 13.7 us, 32 x 64 k2 12.7, 64 x 64 14.8, 64 x 64 k2 11.7,
             // 64 x 64 k4 11.5, 32 x 64 k4 16.4, 64 x 128 k2 17.5 -- the gain is modest: the K chain is not what bounds these launches
+            // -- only on request (tile -1, the training paths): a K-group tile regroups the K sum (half + half), so with it in the plain automatic
+            // choice a batch of 2 would no longer reproduce the first two utterances of a batch of 16 bit for bit (the tile follows M)
             if constexpr (!A_F32 && !CONV) {
-                if ((tile == 5 || tile == 3) && a.K >= 1024 && t64 <= 512) tile = 11;
+                if (kgroups_ok && (tile == 5 || tile == 3) && a.K >= 1024 && t64 <= 512) tile = 11;
             }
         }
     }

@@ -70,6 +70,7 @@ int gemm(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* W, con
     if (pre) { d.C_pre = pre; d.ld_pre = N; d.pre_dtype = c.adt; }
     if (aux) { d.aux = aux; d.ld_aux = N; d.aux_dtype = c.adt; }
     d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop2_p = drop2_p; d.drop2_seed = drop2_seed;
+    d.tile = CFM_TILE_AUTO_TRAIN;
     if (c.split && !Wlo) return cfm_fail(CFM_ERR_ARG, "train layer: split mode needs the *_lo weight planes");
     return cfm_gemm(&d, c.st);
 }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFM_VERSION 201 /* 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
+#define CFM_VERSION 202 /* 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
 
 typedef void* cfm_stream_t;
 
@@ -74,6 +74,7 @@ int cfm_device_ok(void);
  * constraints: K % 8 == 0, lda % 8 == 0 (elements), ldc % 2 == 0, N % 2 == 0 (residual: both % 4; GLU: N % 32 == 0).
  * N or ldc not a multiple of 4 (a vocabulary of 5002 columns) is written with column-pair stores.
  */
+#define CFM_TILE_AUTO_TRAIN (-1) /* cfm_gemm_desc.tile */
 typedef struct {
     const void* A;
     const void* W;
@@ -88,13 +89,14 @@ typedef struct {
     int32_t act;
     float alpha;
     int32_t conv_C, conv_T1, conv_F1, conv_T2, conv_F2; /* conv_C == 0: plain GEMM */
-    int32_t tile;                                       /* 0 = auto; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64, 5: 32x64, 6: 32x128,
+    int32_t tile;                                       /* 0 = auto (every choice keeps the K order: results do not depend on M, a batch shard reproduces the
+                                                           batch bit for bit); -1 = CFM_TILE_AUTO_TRAIN: auto, K-group tiles allowed; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64, 5: 32x64, 6: 32x128,
                                                            7: 128x128 persistent workgroups (16-bit plain products, K %% 64 == 0),
                                                            8: 256x256 with LDS-DMA staging (csrc/gemm256.hip: 16-bit operands, K %% 64 == 0, bias / SiLU /
                                                               ReLU epilogues; auto when a cost model says its whole rounds beat the 128x128 tiles),
                                                            9 / 11 / 10: 32x64 k2 / 64x64 k2 / 64x64 k4 -- two or four K groups of four wavefronts per tile that meet
-                                                              through LDS (16-bit operands, any epilogue; 11 is auto for K >= 1024 on <= 512 tiles of 64x64: the
-                                                              long-K products of a training micro-batch) */
+                                                              through LDS (16-bit operands, any epilogue; 11 is chosen under tile = -1 for K >= 1024 on <= 512 tiles
+                                                              of 64x64: the long-K products of a training micro-batch) */
     int32_t mask_mode;                                  /* 0: row_mask zeroes the OUTPUT row (after act, before residual);
                                                            1: row_mask zeroes the INPUT row (acc = 0, bias/act still apply) */
     /* training: */
@@ -595,12 +597,15 @@ void cfm_attention_bwd_force_general(int32_t on);
  * for t < enc_lens[b] and 0 elsewhere (pad columns V..ld-1 too) -- what autograd gives for nn.CTCLoss(reduction='sum') on
  * log_softmax(logits) (decoder.py:20-21).  The scale is gscale * (gscale_dev ? *gscale_dev : 1): a host factor (1 / padded label length,
  * decoder.py:22) times an optional DEVICE scalar (the upstream gradient).  alpha_beta is cfm_ctc_nll_train's alpha, overwritten.
+ * beta (f32 [B,T,2*Umax+2], may be null in both calls): given to cfm_ctc_nll_train, the backward recursion runs BESIDE the forward one in the same
+ * launch (2 B workgroups) and leaves log(beta / y) there; given to cfm_ctc_grad, that array is used instead of running the recursion (alpha is then
+ * left untouched).  Both forms produce the same bits.
  * An utterance with no valid alignment (nll = inf) gets a zero gradient (torch's is undefined without zero_infinity).  V <= 8192. */
 int cfm_ctc_nll_train(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
-                      const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, cfm_stream_t stream);
+                      const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, float* beta, cfm_stream_t stream);
 int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
-                 const int32_t* label_lens, const float* work, float* alpha_beta, const float* lse, const float* nll_shifted, float gscale,
-                 const float* gscale_dev, float* dlogits, cfm_stream_t stream);
+                 const int32_t* label_lens, const float* work, float* alpha_beta, const float* beta, const float* lse, const float* nll_shifted,
+                 float gscale, const float* gscale_dev, float* dlogits, cfm_stream_t stream);
 
 /* Dropout as an elementwise pass:  y[m,n] = keep(seed, m*N + n) ? alpha * x[m,n] / (1-p) : 0, rows with row_mask == 0 zeroed.  The backward of
  * a residual branch x + alpha * dropout(f(..)) needs d f = alpha * mask/(1-p) * dx as a GEMM operand (encoder_layer.py:58,61,64,69); the

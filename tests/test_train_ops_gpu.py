@@ -295,6 +295,10 @@ def test_ctc_gradient(cfm, B, T, V, Umax):
     assert relerr(grad[:, :, :V].cpu(), lr.grad) < 5e-4          # fp32 recursions vs torch in fp64: grows ~linearly with T (2.4e-4 at T = 249)
     for b in range(B):
         assert float(grad[b, int(enc_lens[b]):].abs().max()) == 0.0 if enc_lens[b] < T else True
+    # the backward recursion inside ctc_grad (in place over alpha) instead of beside the forward one: the same bits
+    nll2, state2 = cfm.ctc_nll_train(logits, V, el, lb, ll, beta_now=False)
+    assert state[4] is not None and state2[4] is None and torch.equal(nll, nll2)
+    assert torch.equal(cfm.ctc_grad(logits, V, el, lb, ll, state2, gscale=0.5 / Umax, gscale_dev=gdev), grad)
 
 
 def test_ctc_gradient_infeasible_is_zero(cfm):
