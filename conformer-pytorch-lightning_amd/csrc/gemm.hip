@@ -649,7 +649,8 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
             if (tile != 5 && a.K <= 768 && t32x64 >= 96 && t32x64 <= 2560) tile = 5;
             // long K on few tiles (a feed-forward's second product and its input gradient at a training micro-batch: N = 256, K = 2 048):
             // K groups.  Measured at M = 2 380 (scripts/bench_gemm_tiles.py): 32 x 64 13.7 us, 32 x 64 k2 12.7, 64 x 64 14.8, 64 x 64 k2 11.7,
-            // 64 x 64 k4 11.5, 32 x 64 k4 16.4, 64 x 128 k2 17.5 -- the gain is modest: the K chain is not what bounds these launches
+            // 64 x 64 k4 11.5, 32 x 64 k4 16.4, 64 x 128 k2 17.5 -- the gain is modest: the K chain is not what bounds these launches, and inside
+            // the config-3 step it does not show at all (13.36 ms with, 13.38 ms without, same box, alternating runs)
             // -- only on request (tile -1, the training paths): a K-group tile regroups the K sum (half + half), so with it in the plain automatic
             // choice a batch of 2 would no longer reproduce the first two utterances of a batch of 16 bit for bit (the tile follows M)
             if constexpr (!A_F32 && !CONV) {
