@@ -24,6 +24,7 @@ _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
+c_f = ctypes.c_float
 
 
 class GemmDesc(ctypes.Structure):
@@ -152,8 +153,14 @@ class GreedyDesc(ctypes.Structure):
                 ("P", c_i32), ("J", c_i32), ("Vp", c_i32), ("blank", c_i32), ("n_steps", c_i32)]
 
 
+class FfnSplitDesc(ctypes.Structure):
+    _fields_ = [("x", c_p), ("psum", c_p), ("psum_b2", c_p), ("psum_splits", c_i32), ("psum_alpha", c_f), ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p),
+                ("ln2_b", c_p), ("rows_out", c_p), ("rows2_out", c_p), ("ln_g", c_p), ("ln_b", c_p), ("w1", c_p), ("b1", c_p), ("N1", c_i32), ("act", c_i32),
+                ("w2", c_p), ("psum_out", c_p), ("out16", c_p), ("ldo", c_i64), ("M", c_i32), ("D", c_i32), ("mode", c_i32), ("w_dtype", c_i32), ("eps", c_f)]
+
+
 class LayerScratch(ctypes.Structure):
-    _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw", "vt")] + [("vt_ld", c_i32)]
+    _fields_ = [(n, c_p) for n in ("xn", "hid", "qkv", "pos", "ctx", "glu", "dw", "vt")] + [("vt_ld", c_i32), ("psum", c_p), ("psum_splits", c_i32)]
 
 
 class LayerIO(ctypes.Structure):
@@ -200,6 +207,8 @@ def lib():
         L.cfm_conv12_supported.argtypes = [c_i32, c_i32]
         L.cfm_pack_matrices.argtypes = [c_p, c_i32, c_i64, c_i32, c_i32, c_p]
         L.cfm_greedy_step.argtypes = [ctypes.POINTER(GreedyDesc), c_p]
+        L.cfm_ffn_split.argtypes = [ctypes.POINTER(FfnSplitDesc), c_p]
+        L.cfm_ffn_split_supported.argtypes = [c_i32, c_i32]
         L.cfm_attention_bwd_force_general.argtypes = [c_i32]
         L.cfm_attention_bwd_force_general.restype = None
         L.cfm_dwconv_bn_train_bwd_acc.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
@@ -253,7 +262,7 @@ def lib():
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
-                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_greedy_step", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
+                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_greedy_step", "cfm_ffn_split", "cfm_ffn_split_supported", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
                      "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L

@@ -9,7 +9,7 @@ import torch
 import cfm as _c
 
 __all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
-           "ctc_nll_train", "ctc_grad", "adam_step", "sumsq", "scratch_stats",
+           "ctc_nll_train", "ctc_grad", "ffn_split", "adam_step", "sumsq", "scratch_stats",
            "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "conv12_relu", "conv12_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
@@ -146,6 +146,32 @@ def ffn_fused(x, w1f, w2f, b1, b2, FF, act=_c.ACT_SILU, ln=None, alpha=1.0, add_
 
 def rowchain_supported(D, FF, prec):
     return (not prec.split) and bool(_c.lib().cfm_rowchain_supported(D, FF))
+
+
+def ffn_split(x, w_code, mode, psum=None, psum_b2=None, psum_alpha=1.0, ln1=None, ln2=None, rows_out=None, rows2_out=None, ln=None, w1=None, b1=None,
+              n1=0, act=_c.ACT_NONE, w2=None, psum_out=None, out16=None, eps=1e-5):
+    """include/cfm.h cfm_ffn_split: the rows stage (optional reduce of partial slabs psum [G,M,D] + residual x, LN1, rows_out) followed by nothing
+    (mode 0: + LN2 -> rows2_out), a projection (mode 1: out16 [M,n1]) or a feed-forward that leaves partial slabs (mode 2: psum_out [n1/256,M,D])."""
+    _c.require_hip(x, psum, psum_b2, rows_out, rows2_out, w1, b1, w2, psum_out, out16)
+    x = _rows2d(x, "ffn_split(x)")
+    M, D = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("cfm.ffn_split: x must be contiguous float32 rows")
+    d = _c.FfnSplitDesc()
+    d.x, d.M, d.D, d.mode, d.w_dtype, d.eps = x.data_ptr(), M, D, mode, w_code, eps
+    if psum is not None:
+        if psum.dtype != torch.float32 or psum.dim() != 3 or tuple(psum.shape[1:]) != (M, D) or not psum.is_contiguous():
+            raise ValueError("cfm.ffn_split: psum must be contiguous float32 [G, M, D]")
+        d.psum, d.psum_b2, d.psum_splits, d.psum_alpha = psum.data_ptr(), _c.ptr(psum_b2), psum.shape[0], psum_alpha
+    for name, pair in (("ln1", ln1), ("ln2", ln2), ("ln", ln)):
+        if pair is not None:
+            setattr(d, name + "_g", pair[0].data_ptr())
+            setattr(d, name + "_b", pair[1].data_ptr())
+    d.rows_out, d.rows2_out = _c.ptr(rows_out), _c.ptr(rows2_out)
+    d.w1, d.b1, d.N1, d.act, d.w2, d.psum_out = _c.ptr(w1), _c.ptr(b1), n1, act, _c.ptr(w2), _c.ptr(psum_out)
+    if out16 is not None:
+        d.out16, d.ldo = out16.data_ptr(), out16.stride(0)
+    _c.check(_c.lib().cfm_ffn_split(ctypes.byref(d), _c.stream()), "cfm_ffn_split")
 
 
 def rowchain(M, D, w_code, x=None, head=None, ln=None, ln_mask=None, ffn=None, alpha=1.0, ln1=None, ln2=None, out_f32=None, out16=None,

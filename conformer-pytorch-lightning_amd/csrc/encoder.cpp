@@ -93,7 +93,26 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     const bool merged = chains && s->vt && s->vt_ld >= 256 && s->vt_ld % 4 == 0 && D == 256 && H == 4 && !ring && Tc == 0 && !io->new_cache &&
                         io->T <= 256 && (!has_pos || P == 1) && (!io->attn_mask || io->am_sq == 0) && !io->macaron_done && !io->next_w;
     CFM_CHECK_ARG(!io->macaron_done || chains, "encoder layer: macaron_done needs the chain path");
-    if (chains && !io->macaron_done) {
+    // few rows (a streaming step): both feed-forwards split over FF / 256 workgroups per 32-row tile (ffnsplit.hip) instead of inside the row
+    // chains, where every tile's workgroup streams all 2 MB of a feed-forward's weights whatever the row count
+    const bool ffsplit = chains && s->psum && M <= CFM_FFSPLIT_MAX_ROWS && cfm_ffn_split_supported(D, FF) && s->psum_splits >= FF / 256 && !merged &&
+                         !io->macaron_done && !io->next_w && w->pw2_w && io->ktaps == 15;
+    auto split_desc = [&](int mode) {
+        cfm_ffn_split_desc f = {};
+        f.M = M; f.D = D; f.mode = mode; f.w_dtype = c.w_dt; f.eps = eps;
+        return f;
+    };
+    if (ffsplit) {
+        // macaron feed-forward as partial slabs; then rows = x + 1/2 (sum + b2) -> x_out, LN_mha, fused q|k|v projection
+        cfm_ffn_split_desc f = split_desc(2);
+        f.x = x_in; f.ln_g = w->ln_ffm_g; f.ln_b = w->ln_ffm_b; f.w1 = w->ffm_w1f; f.b1 = w->ffm_b1; f.N1 = FF; f.act = CFM_ACT_SILU; f.w2 = w->ffm_w2n;
+        f.psum_out = s->psum;
+        CFM_TRY(cfm_ffn_split(&f, stream));
+        cfm_ffn_split_desc q = split_desc(1);
+        q.x = x_in; q.psum = s->psum; q.psum_b2 = w->ffm_b2; q.psum_splits = FF / 256; q.psum_alpha = 0.5f; q.rows_out = x_out;
+        q.ln_g = w->ln_mha_g; q.ln_b = w->ln_mha_b; q.w1 = w->qkv_wf; q.b1 = w->qkv_b; q.N1 = 3 * D; q.act = CFM_ACT_NONE; q.out16 = s->qkv; q.ldo = 3 * D;
+        CFM_TRY(cfm_ffn_split(&q, stream));
+    } else if (chains && !io->macaron_done) {
         cfm_rowchain_desc m = {};
         if (merged) { m.tail_vt = s->vt; m.vt_T = io->T; m.vt_ld = s->vt_ld; }
         m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2n = w->ffm_w2n; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
@@ -183,6 +202,21 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
             if (io->conv_cache) CFM_TRY(cfm_conv_cache_update(s->glu, adt, io->conv_cache, io->B, io->T, D, io->ktaps, stream));
         } else if (!dw_fused)
             CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+        if (ffsplit) {
+            // depthwise + BN + SiLU, pointwise-conv-2 + pad mask + residual (in place on x_out), then the feed-forward as partial slabs and the
+            // reduce with norm_final (+ after_norm)
+            if (dw_fused) CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
+            CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, io->pad_valid));
+            cfm_ffn_split_desc f = split_desc(2);
+            f.x = x_out; f.ln_g = w->ln_ff_g; f.ln_b = w->ln_ff_b; f.w1 = w->ff_w1f; f.b1 = w->ff_b1; f.N1 = FF; f.act = CFM_ACT_SILU; f.w2 = w->ff_w2n;
+            f.psum_out = s->psum;
+            CFM_TRY(cfm_ffn_split(&f, stream));
+            cfm_ffn_split_desc r = split_desc(0);
+            r.x = x_out; r.psum = s->psum; r.psum_b2 = w->ff_b2; r.psum_splits = FF / 256; r.psum_alpha = 0.5f; r.ln1_g = w->ln_final_g; r.ln1_b = w->ln_final_b;
+            r.rows_out = x_out;
+            if (io->after_out) { r.ln2_g = io->after_g; r.ln2_b = io->after_b; r.rows2_out = io->after_out; }
+            return cfm_ffn_split(&r, stream);
+        }
         // final chain: pointwise-conv-2 + pad mask + residual -> LN_ff -> FFN -> +res -> LN_final, in place on x_out
         cfm_rowchain_desc fi = {};
         fi.head_a = dw_fused ? s->glu : s->dw; fi.head_w = w->pw2_wf;

@@ -43,7 +43,7 @@ class ConformerEncoder(nn.Module):
         self.static_chunk_size = static_chunk_size
 
     # ------------------------------------------------------------------------------------------------------------
-    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from, pos_shared=False, proj=None, ring=None, conv=None):
+    def _run_blocks(self, x, attn_mask, pos_embed, pad_mask, caches, keep_from, pos_shared=False, proj=None, ring=None, conv=None, streaming=False):
         """x (B,T',D) f32 -> after_norm(blocks(x)); returns (y, [trimmed per-layer caches] | None).
         ring = (kv f32 [L,B,H,ring_T,2dk], offsets int32 [B]), conv = f32 [L,B,K-1,D] | None: per-stream streaming state (StreamingBatch)."""
         n = len(self.encoders)
@@ -61,9 +61,10 @@ class ConformerEncoder(nn.Module):
         # config-2 width; encoder_layer.CHAIN_BLOCKS)
         import encoder_layer as _el
         e0 = self.encoders[0]
-        chain = (_el.CHAIN_BLOCKS and not _el.MERGE_ATTENTION and fuse_after and caches is None and ring is None and conv is None and self.encoder_dim == 256 and
+        chain = (_el.CHAIN_BLOCKS and not _el.MERGE_ATTENTION and fuse_after and caches is None and conv is None and self.encoder_dim == 256 and
                  e0.hidden_dim == 2048 and e0.kernel_size == 15 and not getattr(e0.conv_module, "causal", False) and
-                 all(b.chain_ready(prec) for b in self.encoders))
+                 all(b.chain_ready(prec) for b in self.encoders) and
+                 not (streaming and _el.SPLIT_FFN_FEW_ROWS and _el.split_rows(x.size(0) * x.size(1), self.encoder_dim, e0.hidden_dim)))   # few rows: the split feed-forward instead
         for i, block in enumerate(self.encoders):
             nxt = self.encoders[i + 1].norm_ff_macaron if i + 1 < n else None
             cache_i = None
@@ -76,7 +77,7 @@ class ConformerEncoder(nn.Module):
                                           out=bufs[i & 1], want_cache=caches is not None, pos_proj=pp, pos_shared=pos_shared,
                                           ring=None if ring is None else (ring[0][i], ring[1]), conv_cache=None if conv is None else conv[i],
                                           chain_next=(self.encoders[i + 1], bufs[(i + 1) & 1]) if chain and i + 1 < n else None,
-                                          macaron_done=chain and i > 0,
+                                          macaron_done=chain and i > 0, split_ffn=streaming,
                                           after=(self.after_norm.weight.detach(), self.after_norm.bias.detach(), y_after)
                                           if fuse_after and i + 1 == n else None)
             if new_caches is not None:
@@ -185,7 +186,7 @@ class ConformerEncoder(nn.Module):
         else:
             keep_from = max(span - required_cache_size, 0)
         caches = attn_cache if have else torch.zeros((0, 0, 0, 0), device=dev)
-        y, new = self._run_blocks(x, inputs_attn_mask, pos_embed, None, caches, keep_from, pos_shared=batched)
+        y, new = self._run_blocks(x, inputs_attn_mask, pos_embed, None, caches, keep_from, pos_shared=batched, streaming=True)
         r_attn = torch.stack(new, dim=0) if batched else torch.cat(new, dim=0)
         r_cnn = torch.zeros((len(self.encoders), 0, 0, 0), dtype=x.dtype, device=dev)
         return y.to(inputs.dtype), r_attn, r_cnn
@@ -374,7 +375,7 @@ class StreamingBatch:
             else:
                 x, _ = enc.position_encoding(x, 0, rows=self.abs_rows)
             proj = enc._project_positions(self.pos_rows, x)
-            y, _ = enc._run_blocks(x, self.slot_mask.view(torch.bool), self.pos_rows, None, None, 0, proj=proj, ring=(self.kv, self.offsets), conv=self.conv)
+            y, _ = enc._run_blocks(x, self.slot_mask.view(torch.bool), self.pos_rows, None, None, 0, proj=proj, ring=(self.kv, self.offsets), conv=self.conv, streaming=True)
             cfm.stream_advance(self.offsets, self.chunk)
         finally:
             for blk in enc.encoders:

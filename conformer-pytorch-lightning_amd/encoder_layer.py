@@ -22,6 +22,16 @@ from convolution import ConvolutionModule
 from feedforward import PositionwiseFeedForwardModule, _inference_only
 
 _ABSENT = torch.ones((0, 0, 0), dtype=torch.bool)
+SPLIT_FFN_FEW_ROWS = True  # STREAMING steps of <= 2048 rows run their feed-forwards split over FF/256 workgroups per row tile (csrc/ffnsplit.hip).  Only
+# the streaming entry points ask for it (split_ffn=True): a whole-utterance forward keeps one algorithm for every batch size, so that a batch shard
+# reproduces the batch bit for bit
+
+
+def split_rows(M, D, FF):
+    """True where cfm_encoder_layer_forward takes the split feed-forward when given the slabs (cfm.h CFM_FFSPLIT_MAX_ROWS)."""
+    return M <= 2048 and D == 256 and FF % 256 == 0 and FF > 0
+
+
 CHAIN_BLOCKS = True        # the final chain of block i also runs the macaron chain of block i+1 (one launch and one residual round trip less)
 MERGE_ATTENTION = False    # attention as the input stage of the conv-in chain (3 launches per block instead of 4): built, parity-tested and
                            # measured SLOWER at config 2 (27.7 us vs 9.7 + 13.1 us, rowchain.hip) -- opt-in
@@ -69,7 +79,7 @@ class ConformerEncoderLayer(nn.Module):
 
     def fused_forward(self, x, attn_mask, pos_embed, pad_mask, attn_cache, xn_ready=False, next_norm=None, out=None,
                       want_cache=True, pos_proj=None, pos_shared=False, after=None, ring=None, conv_cache=None, chain_next=None,
-                      macaron_done=False):
+                      macaron_done=False, split_ffn=False):
         """x (B,T,D) float32 on an MI355X -> (norm_final(block(x)), new_attn_cache | None).  ``x`` is not modified.
         ring = (kv_ring f32 [B,H,ring_T,2dk], offsets int32 [B]): per-stream streaming state (include/cfm.h cfm_layer_io.kv_ring);
         attn_mask is then the (B,1,ring_T) slot mask and pos_embed the B*ring_T positional rows.  conv_cache f32 [B,K-1,D]: the
@@ -127,6 +137,9 @@ class ConformerEncoderLayer(nn.Module):
         if MERGE_ATTENTION and D == 256 and H == 4 and T <= 256 and adt != torch.float32:
             # transposed values for the attention stage of the conv-in chain (cfm.h cfm_layer_scratch.vt); key columns past T are read, never written
             s.vt, s.vt_ld = cfm.scratch("vt", B * D * 256, adt, dev, zero=True).data_ptr(), 256
+        if split_ffn and SPLIT_FFN_FEW_ROWS and split_rows(M, D, FF) and adt != torch.float32 and chain_next is None and not macaron_done:
+            # partial slabs of the feed-forward split over FF (cfm.h cfm_layer_scratch.psum, csrc/ffnsplit.hip): few rows, e.g. a streaming step
+            s.psum, s.psum_splits = cfm.scratch("psum", (FF // 256) * M * D, torch.float32, dev).data_ptr(), FF // 256
         io = cfm.LayerIO()
         io.B, io.T, io.D, io.H, io.FF, io.ktaps = B, T, D, H, FF, self.kernel_size
         io.act_dtype, io.w_dtype = prec.act_code, prec.w_code

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFM_VERSION 202 /* 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
+#define CFM_VERSION 203 /* 0.2.3: cfm_ffn_split, cfm_layer_scratch.psum (the feed-forward split over FF for few rows). 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
 
 typedef void* cfm_stream_t;
 
@@ -420,7 +420,12 @@ typedef struct {
     void* vt;      /* optional [B, D, vt_ld] activation-dtype, ZERO-FILLED ONCE by the caller: transposed values for the attention stage of the
                       conv-in chain (cfm_rowchain_desc.att_*); NULL: attention runs as its own launch */
     int32_t vt_ld; /* elements per row of vt: >= 256, multiple of 4 */
+    float* psum;   /* optional f32 [psum_splits, M, D]: partial slabs of the split feed-forward (cfm_ffn_split).  Given with psum_splits >= FF/256,
+                      blocks of at most CFM_FFSPLIT_MAX_ROWS rows at D = 256 run their two feed-forwards split over FF/256 workgroups per 32-row
+                      tile instead of inside the row chains (few rows: a streaming step); null = never */
+    int32_t psum_splits;
 } cfm_layer_scratch;
+#define CFM_FFSPLIT_MAX_ROWS 2048
 
 typedef struct {
     int32_t B, T, D, H, FF, ktaps;
@@ -591,6 +596,38 @@ int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream);
  * they lie in memory, transposed operands read with ds_read_b64_tr_b16, next tile prefetched) -- bit-identical to the general ones, which
  * this switch forces (tests). */
 void cfm_attention_bwd_force_general(int32_t on);
+
+/* Feed-forward for FEW rows, the hidden dimension split across workgroups (csrc/ffnsplit.hip; feedforward.py:17-20 inside encoder_layer.py:55-58,
+ * 67-70 when B*T' is a few hundred rows: a streaming step, BASELINE config 5).  One launch = the row-reduce input stage + (by mode) nothing, a
+ * projection, or a feed-forward that leaves PARTIAL sums:
+ *   rows      x = psum ? x + psum_alpha * (sum_{g < psum_splits} psum[g] + psum_b2) : x;   if ln1: x = LN1(x);   rows_out = x (optional)
+ *   mode 0    rows2_out = LN2(x) (optional)
+ *   mode 1    out16[:, n] = act(LN(x) . w1[n,:] + b1[n]),  n < N1                       grid = (ceil(M/32), N1/256)
+ *   mode 2    psum_out[g] = act(LN(x) . w1[256 g .. 256 g + 255,:]^T + b1) . w2[:, 256 g ..]^T,  g < N1/256 (N1 = FF), to be reduced -- with b2, alpha,
+ *             the residual and the next norm(s) -- by the rows stage of the next cfm_ffn_split call (fixed order g = 0,1,..: reproducible)
+ * w1: fragment-major [N1/16][D/32][64][8] (packing.pack_frag_major / pack_ffn_fragments' w1f), w2: fragment-major [D/16][FF/32][64][8] (w2n);
+ * 16-bit `w_dtype`; f32 rows [M,D]; psum / psum_out f32 [splits][M][D]; rows_out may alias x only when one slice runs (mode 0, or N1 == 256).  D = 256. */
+typedef struct {
+    const float* x;
+    const float* psum;
+    const float* psum_b2;
+    int32_t psum_splits;
+    float psum_alpha;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float *rows_out, *rows2_out;
+    const float *ln_g, *ln_b;
+    const void* w1;
+    const float* b1;
+    int32_t N1, act;
+    const void* w2;
+    float* psum_out;
+    void* out16;
+    int64_t ldo;
+    int32_t M, D, mode, w_dtype;
+    float eps;
+} cfm_ffn_split_desc;
+int cfm_ffn_split(const cfm_ffn_split_desc* d, cfm_stream_t stream);
+int cfm_ffn_split_supported(int32_t D, int32_t FF);
 
 /* CTC backward (csrc/ctc.hip): cfm_ctc_nll_train is cfm_ctc_nll that also keeps log alpha (alpha f32 [B,T,2*Umax+2]), the per-frame
  * log-sum-exp (lse f32 [B,T]) and nll_shifted f32 [B] (-log P of the per-frame-shifted recursion: the posteriors' normaliser); cfm_ctc_grad runs the beta recursion and writes d loss / d logits [B,T,ld] = gscale[b] * (softmax - occupancy)

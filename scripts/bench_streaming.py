@@ -54,3 +54,21 @@ steady = sorted(times[12:])
 ms = 1e3 * steady[len(steady) // 2]
 print("streams %d  StreamingBatch (ring KV, per-stream offsets, one graph): %.3f ms per step = %.0f input frames/s over all streams (%.1f x real time per stream)"
       % (B, ms, B * hop / (ms * 1e-3), hop * 10.0 / ms))
+
+# ---- per-kernel table of one StreamingBatch step (eager launches, HIP events attached to every dispatch)
+if os.environ.get("KERNEL_TABLE", "1") != "0":
+    sb2 = enc_mod.StreamingBatch(enc, B, chunk, left, graph=False)
+    with torch.no_grad():
+        for step in range(8):
+            sb2.step(x[:, step * hop: step * hop + window].contiguous())
+        torch.cuda.synchronize()
+        cfm.prof_reset(); cfm.prof_enable(True)
+        n = 20
+        for step in range(8, 8 + n):
+            sb2.step(x[:, step * hop: step * hop + window].contiguous())
+        torch.cuda.synchronize(); cfm.prof_enable(False)
+    tab = cfm.prof_table()
+    tot = sum(e["ms"] for e in tab.values())
+    print("StreamingBatch step, kernels (eager, %d steps): device time %.3f ms per step" % (n, tot / n))
+    for k, e in sorted(tab.items(), key=lambda kv: -kv[1]["ms"]):
+        print("  %-34s calls/step %5.1f  avg %7.2f us  share %5.1f%%" % (k, e["calls"] / n, e["ms"] / e["calls"] * 1e3, 100 * e["ms"] / tot))

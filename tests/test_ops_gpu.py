@@ -628,3 +628,49 @@ def test_rowchain_depthwise_input_stage(cfm, B, T, D, FF, wdt):
         cfm.rowchain(M, D, code, x=x, ln=lns[0], out_f32=out, dw=(taps, tb, sc, sh, T))
 
 
+
+
+# ------------------------------------------------------------------------------------------------------------ feed-forward split over FF
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 16, 45, 1024])
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+def test_ffn_split_modes(cfm, M, wdt):
+    """cfm_ffn_split (csrc/ffnsplit.hip) against plain torch math on the same 16-bit-rounded operands: the feed-forward as partial slabs, the reduce
+    with residual / bias / alpha / LayerNorms, and the projection mode; ragged last tile, a single row."""
+    from cfm import packing
+    torch.manual_seed(M)
+    D, FF, dt, code = 256, 2048, W_DT[wdt], (cfm.BF16 if wdt == "bf16" else cfm.F16)
+    x = torch.randn((M, D), device="cuda")
+    w1 = torch.randn((FF, D), device="cuda") / D ** 0.5
+    w2 = torch.randn((D, FF), device="cuda") / FF ** 0.5
+    b1, b2 = 0.1 * torch.randn((FF,), device="cuda"), 0.1 * torch.randn((D,), device="cuda")
+    lng = [(1 + 0.1 * torch.randn((D,), device="cuda"), 0.1 * torch.randn((D,), device="cuda")) for _ in range(4)]
+    w1f, w2n = packing.pack_frag_major(w1, dt), packing.pack_frag_major(w2, dt)
+    ln = lambda t, p: torch.nn.functional.layer_norm(t, (D,), p[0], p[1], 1e-5)
+    r16 = lambda t: t.to(dt).float()
+    # mode 2: partial slabs; their sum is the second product (without b2)
+    slabs = torch.full((FF // 256, M, D), float("nan"), device="cuda")
+    cfm.ffn_split(x, code, 2, ln=lng[0], w1=w1f, b1=b1, n1=FF, act=cfm.ACT_SILU, w2=w2n, psum_out=slabs)
+    h = r16(torch.nn.functional.silu(r16(ln(x, lng[0])) @ r16(w1).t() + b1))
+    ref = h @ r16(w2).t()
+    assert relerr(slabs.sum(0), ref) < 2e-3
+    per = torch.stack([h[:, g * 256:(g + 1) * 256] @ r16(w2)[:, g * 256:(g + 1) * 256].t() for g in range(FF // 256)])
+    assert relerr(slabs, per) < 2e-3
+    # mode 0: x + 0.5 (sum + b2) -> LN1 -> rows_out -> LN2 -> rows2_out; in place over x is allowed
+    y, y2, xin = torch.empty_like(x), torch.empty_like(x), x.clone()
+    cfm.ffn_split(xin, code, 0, psum=slabs, psum_b2=b2, psum_alpha=0.5, ln1=lng[1], ln2=lng[2], rows_out=y, rows2_out=y2)
+    want = ln(x + 0.5 * (slabs.sum(0) + b2), lng[1])
+    assert relerr(y, want) < 1e-5 and relerr(y2, ln(want, lng[2])) < 1e-5
+    cfm.ffn_split(xin, code, 0, psum=slabs, psum_b2=b2, psum_alpha=0.5, ln1=lng[1], rows_out=xin)
+    assert torch.equal(xin, y)
+    # mode 1: rows (reduced, no LN1) written once, LN -> projection with bias, three slices
+    wq, bq = torch.randn((3 * D, D), device="cuda") / D ** 0.5, 0.1 * torch.randn((3 * D,), device="cuda")
+    rows, qkv = torch.empty_like(x), torch.full((M, 3 * D), float("nan"), device="cuda").to(dt)
+    cfm.ffn_split(x, code, 1, psum=slabs, psum_b2=b2, psum_alpha=0.5, rows_out=rows, ln=lng[3], w1=packing.pack_frag_major(wq, dt), b1=bq, n1=3 * D, out16=qkv)
+    x1 = x + 0.5 * (slabs.sum(0) + b2)
+    assert relerr(rows, x1) < 1e-6
+    assert relerr(qkv.float(), r16(ln(x1, lng[3])) @ r16(wq).t() + bq) < (1.2e-2 if wdt == "bf16" else 2e-3)
+    # reproducible
+    again = torch.empty_like(slabs)
+    cfm.ffn_split(x, code, 2, ln=lng[0], w1=w1f, b1=b1, n1=FF, act=cfm.ACT_SILU, w2=w2n, psum_out=again)
+    assert torch.equal(again, slabs)
