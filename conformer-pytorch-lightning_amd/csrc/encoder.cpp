@@ -205,8 +205,15 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         if (ffsplit) {
             // depthwise + BN + SiLU, pointwise-conv-2 + pad mask + residual (in place on x_out), then the feed-forward as partial slabs and the
             // reduce with norm_final (+ after_norm)
-            if (dw_fused) CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
-            CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, io->pad_valid));
+            if (dw_fused) {                                  // one launch: the depthwise stage as the input stage of the pointwise-conv-2 head
+                cfm_rowchain_desc dh = {};
+                dh.head_a = s->glu; dh.head_w = w->pw2_wf; dh.head_b = w->pw2_b; dh.head_res = x_out; dh.head_mask = io->pad_valid;
+                dh.dw_w = w->dw_w; dh.dw_b = w->dw_b; dh.dw_scale = w->bn_scale; dh.dw_shift = w->bn_shift; dh.dw_T = io->T; dh.dw_K = 15;
+                dh.out_f32 = x_out; dh.M = M; dh.D = D; dh.FF = FF; dh.w_dtype = c.w_dt; dh.alpha = 1.0f; dh.eps = eps;
+                CFM_TRY(cfm_rowchain(&dh, stream));
+            } else {
+                CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, x_out, 1.0f, io->pad_valid));
+            }
             cfm_ffn_split_desc f = split_desc(2);
             f.x = x_out; f.ln_g = w->ln_ff_g; f.ln_b = w->ln_ff_b; f.w1 = w->ff_w1f; f.b1 = w->ff_b1; f.N1 = FF; f.act = CFM_ACT_SILU; f.w2 = w->ff_w2n;
             f.psum_out = s->psum;

@@ -19,6 +19,9 @@
 // product are requested before its first MFMA, and product 2's before the hidden tile is written: a workgroup is a short latency
 // chain (rows -> LN -> 32 MFMAs -> SiLU -> 32 MFMAs), so everything that does not depend on the chain is in flight from the start.
 // D = 256 only (the config-2 / config-5 width).
+// (Measured and dropped: letting a block's reduce + norm_final ride in the NEXT block's macaron feed-forward launch -- one launch less per block.
+// All 8 slices then repeat the reduce (8 slabs x 32 KB each) in front of their LayerNorm: that launch went 8.9 -> 16.8 us against the 5.7 us of
+// the rows launch it saved; config-5 step 1.011 -> 1.052 ms.  The reduce belongs where one workgroup per tile does it: modes 0 and 1.)
 #include <string>
 #include <type_traits>
 

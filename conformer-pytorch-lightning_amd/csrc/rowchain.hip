@@ -989,8 +989,8 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     const bool seg2 = d->s2_w1f != nullptr;
     CFM_CHECK_ARG(!seg2 || (mid && d->s2_w2n && d->s2_b1 && d->s2_b2 && d->s2_ln_g && d->s2_ln_b && d->s2_out_f32 && d->ln2_g),
                   "cfm_rowchain: a second segment needs a first feed-forward, its own weights / biases / input norm / output and ln2");
-    CFM_CHECK_ARG(!dw || (head && mid && (!tail || seg2) && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
-                  "cfm_rowchain: the depthwise input stage needs a head + feed-forward chain, bias/scale/shift, 15 taps and M %% dw_T == 0");
+    CFM_CHECK_ARG(!dw || (head && (mid ? (!tail || seg2) : !tail) && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
+                  "cfm_rowchain: the depthwise input stage needs a head (+ feed-forward) chain without a tail, bias/scale/shift, 15 taps and M %% dw_T == 0");
     CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256), "cfm_rowchain: D=%d has no instance (144, 256)", d->D);
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_rowchain: w_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(head || d->x, "cfm_rowchain: need x or a head input");
@@ -1032,6 +1032,8 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
         if (!head && mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 2048, 0, true, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 2048, 0, true, 3, false, "chain_macaron_f16_d256"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 1) { if (bf) CFM_RC(BF16, 256, 64, 1, false, 1, true, "chain_convin_bf16_d256"); else CFM_RC(F16, 256, 64, 1, false, 1, true, "chain_convin_f16_d256"); }
         if (head && mid && !tail && dw) { if (bf) CFM_RCDW(BF16, 256, 2048, "chain_dwfinal_bf16_d256"); else CFM_RCDW(F16, 256, 2048, "chain_dwfinal_f16_d256"); }
+        // depthwise + BatchNorm + SiLU -> pointwise-conv-2 + pad mask + residual only (the split feed-forward path runs the rest: ffnsplit.hip)
+        if (head && !mid && !tail && dw) { if (bf) return launch_chain<BF16, 256, 64, 1, true, false, 0, false>(a, s, "chain_dwhead_bf16_d256", fl); else return launch_chain<F16, 256, 64, 1, true, false, 0, false>(a, s, "chain_dwhead_f16_d256", fl); }
         if (head && mid && !tail) { if (bf) CFM_RC(BF16, 256, 2048, 1, true, 0, false, "chain_final_bf16_d256"); else CFM_RC(F16, 256, 2048, 1, true, 0, false, "chain_final_f16_d256"); }
         if (!head && !mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 64, 0, false, 3, false, "chain_qkv_bf16_d256"); else CFM_RC(F16, 256, 64, 0, false, 3, false, "chain_qkv_f16_d256"); }
         if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 256, 64, 0, false, 0, false, "chain_rows_bf16_d256"); else CFM_RC(F16, 256, 64, 0, false, 0, false, "chain_rows_f16_d256"); }
