@@ -156,7 +156,8 @@ class GreedyDesc(ctypes.Structure):
 class FfnSplitDesc(ctypes.Structure):
     _fields_ = [("x", c_p), ("psum", c_p), ("psum_b2", c_p), ("psum_splits", c_i32), ("psum_alpha", c_f), ("ln1_g", c_p), ("ln1_b", c_p), ("ln2_g", c_p),
                 ("ln2_b", c_p), ("rows_out", c_p), ("rows2_out", c_p), ("ln_g", c_p), ("ln_b", c_p), ("w1", c_p), ("b1", c_p), ("N1", c_i32), ("act", c_i32),
-                ("w2", c_p), ("psum_out", c_p), ("out16", c_p), ("ldo", c_i64), ("M", c_i32), ("D", c_i32), ("mode", c_i32), ("w_dtype", c_i32), ("eps", c_f)]
+                ("w2", c_p), ("psum_out", c_p), ("out16", c_p), ("ldo", c_i64), ("M", c_i32), ("D", c_i32), ("mode", c_i32), ("w_dtype", c_i32), ("eps", c_f),
+                ("kv_ring", c_p), ("ring_offsets", c_p), ("ring_T", c_i32), ("ring_H", c_i32), ("ring_Tq", c_i32)]
 
 
 class LayerScratch(ctypes.Structure):

@@ -149,7 +149,7 @@ def rowchain_supported(D, FF, prec):
 
 
 def ffn_split(x, w_code, mode, psum=None, psum_b2=None, psum_alpha=1.0, ln1=None, ln2=None, rows_out=None, rows2_out=None, ln=None, w1=None, b1=None,
-              n1=0, act=_c.ACT_NONE, w2=None, psum_out=None, out16=None, eps=1e-5):
+              n1=0, act=_c.ACT_NONE, w2=None, psum_out=None, out16=None, eps=1e-5, ring=None):
     """include/cfm.h cfm_ffn_split: the rows stage (optional reduce of partial slabs psum [G,M,D] + residual x, LN1, rows_out) followed by nothing
     (mode 0: + LN2 -> rows2_out), a projection (mode 1: out16 [M,n1]) or a feed-forward that leaves partial slabs (mode 2: psum_out [n1/256,M,D])."""
     _c.require_hip(x, psum, psum_b2, rows_out, rows2_out, w1, b1, w2, psum_out, out16)
@@ -171,6 +171,10 @@ def ffn_split(x, w_code, mode, psum=None, psum_b2=None, psum_alpha=1.0, ln1=None
     d.w1, d.b1, d.N1, d.act, d.w2, d.psum_out = _c.ptr(w1), _c.ptr(b1), n1, act, _c.ptr(w2), _c.ptr(psum_out)
     if out16 is not None:
         d.out16, d.ldo = out16.data_ptr(), out16.stride(0)
+    if ring is not None:                                  # (kv f32 [B,H,ring_T,2dk], offsets int32 [B], frames per stream): mode 1 as the q|k|v projection
+        kv, offs, tq = ring
+        _c.require_hip(kv, offs)
+        d.kv_ring, d.ring_offsets, d.ring_T, d.ring_H, d.ring_Tq = kv.data_ptr(), offs.data_ptr(), kv.shape[2], kv.shape[1], tq
     _c.check(_c.lib().cfm_ffn_split(ctypes.byref(d), _c.stream()), "cfm_ffn_split")
 
 

@@ -95,6 +95,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     CFM_CHECK_ARG(!io->macaron_done || chains, "encoder layer: macaron_done needs the chain path");
     // few rows (a streaming step): both feed-forwards split over FF / 256 workgroups per 32-row tile (ffnsplit.hip) instead of inside the row
     // chains, where every tile's workgroup streams all 2 MB of a feed-forward's weights whatever the row count
+    bool ring_written = false;                            // the split path's q|k|v launch also filled the K/V ring
     const bool ffsplit = chains && s->psum && M <= CFM_FFSPLIT_MAX_ROWS && cfm_ffn_split_supported(D, FF) && s->psum_splits >= FF / 256 && !merged &&
                          !io->macaron_done && !io->next_w && w->pw2_w && io->ktaps == 15;
     auto split_desc = [&](int mode) {
@@ -111,6 +112,8 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         cfm_ffn_split_desc q = split_desc(1);
         q.x = x_in; q.psum = s->psum; q.psum_b2 = w->ffm_b2; q.psum_splits = FF / 256; q.psum_alpha = 0.5f; q.rows_out = x_out;
         q.ln_g = w->ln_mha_g; q.ln_b = w->ln_mha_b; q.w1 = w->qkv_wf; q.b1 = w->qkv_b; q.N1 = 3 * D; q.act = CFM_ACT_NONE; q.out16 = s->qkv; q.ldo = 3 * D;
+        ring_written = ring && dk % 4 == 0;
+        if (ring_written) { q.kv_ring = io->kv_ring; q.ring_offsets = io->stream_offset; q.ring_T = io->ring_T; q.ring_H = H; q.ring_Tq = io->T; }
         CFM_TRY(cfm_ffn_split(&q, stream));
     } else if (chains && !io->macaron_done) {
         cfm_rowchain_desc m = {};
@@ -163,7 +166,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
     if (io->new_cache)
         CFM_TRY(cfm_kv_cache_pack(io->attn_cache, Tc, kq, vq, adt, sb, stt, sb, stt, io->new_cache, io->B, H, io->T, dk, stream));
-    if (ring)
+    if (ring && !ring_written)
         CFM_TRY(cfm_kv_ring_write(kq, vq, adt, sb, stt, sb, stt, io->kv_ring, io->stream_offset, io->B, H, io->T, dk, io->ring_T, stream));
     cfm_attn_desc a = {};
     a.q = s->qkv; a.q_sb = sb; a.q_st = stt; a.q_dtype = adt;

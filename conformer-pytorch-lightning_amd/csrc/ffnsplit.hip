@@ -48,6 +48,11 @@ struct FfnSplitArgs {
     int64_t ldo;
     int M, g_in, act, FF;
     float palpha, eps;
+    // PROJ as the fused q|k|v projection of a streaming step: columns [D, 3D) also go, rounded to the 16-bit type and widened again (the very
+    // values cfm_kv_ring_write would copy), into the K/V ring f32 [B, H, ring_T, 2 dk] at slot (offsets[b] + t) mod ring_T
+    float* ring;
+    const int* ring_off;
+    int ring_T, ring_H, ring_dk, ring_Tq;
 };
 
 __device__ __forceinline__ int fs_swz(int row, int chunk) { return row * 32 + (chunk ^ (row & 15)); }   // 16-byte chunk index in a [32][256] 16-bit tile
@@ -172,7 +177,16 @@ __global__ __launch_bounds__(FS_NW * 64) void cfm_ffn_split_kernel(const FfnSpli
                 const u32x2 pk = (u32x2){pack2<HT>(h.x, h.y), pack2<HT>(h.z, h.w)};
                 const int row = mf * 16 + l15, col = wave * 32 + f * 16 + 4 * g4;
                 if constexpr (MODE == 1) {
-                    if (row0 + row < a.M) *(u32x2*)(a.out16 + (int64_t)(row0 + row) * a.ldo + slice * FS_SL + col) = pk;
+                    if (row0 + row < a.M) {
+                        *(u32x2*)(a.out16 + (int64_t)(row0 + row) * a.ldo + slice * FS_SL + col) = pk;
+                        if (a.ring && slice > 0) {                      // uniform: slice 1 = keys, slice 2 = values (D = 256 = one slice each)
+                            const int m = row0 + row, b = m / a.ring_Tq, t = m - b * a.ring_Tq;
+                            const int slot = (a.ring_off[b] + t) % a.ring_T;
+                            const int hh = col / a.ring_dk, e = col - hh * a.ring_dk + (slice == 2 ? a.ring_dk : 0);
+                            const f32x4 rv = (f32x4){HT::to_f32((u16)(pk.x & 0xffffu)), HT::to_f32((u16)(pk.x >> 16)), HT::to_f32((u16)(pk.y & 0xffffu)), HT::to_f32((u16)(pk.y >> 16))};
+                            *(f32x4*)(a.ring + (((int64_t)b * a.ring_H + hh) * a.ring_T + slot) * (2 * a.ring_dk) + e) = rv;
+                        }
+                    }
                 } else {
                     *((u32x2*)(h_s + fs_swz(row, col >> 3)) + ((col >> 2) & 1)) = pk;
                 }
@@ -246,6 +260,12 @@ extern "C" int cfm_ffn_split(const cfm_ffn_split_desc* d, cfm_stream_t stream) {
         if (d->mode == 1) {
             CFM_CHECK_ARG(d->out16 && d->ldo >= d->N1 && d->ldo % 4 == 0, "cfm_ffn_split: the projection needs out16 with a row stride >= N1, multiple of 4");
             a.out16 = (u16*)d->out16; a.ldo = d->ldo;
+            if (d->kv_ring) {
+                CFM_CHECK_ARG(d->N1 == 3 * FS_D && d->ring_offsets && d->ring_H > 0 && FS_D % d->ring_H == 0 && (FS_D / d->ring_H) % 4 == 0 && d->ring_Tq > 0 &&
+                              d->M % d->ring_Tq == 0 && d->ring_T >= d->ring_Tq,
+                              "cfm_ffn_split: the K/V ring needs the fused q|k|v projection (N1 = 3 D), offsets, H | D with dk %% 4 == 0, M %% T == 0 and ring_T >= T");
+                a.ring = d->kv_ring; a.ring_off = d->ring_offsets; a.ring_T = d->ring_T; a.ring_H = d->ring_H; a.ring_dk = FS_D / d->ring_H; a.ring_Tq = d->ring_Tq;
+            }
         } else {
             CFM_CHECK_ARG(d->w2 && d->psum_out && d->psum_out != d->psum, "cfm_ffn_split: the feed-forward needs w2 and its own partial slabs");
             a.w2 = (const u16*)d->w2; a.psum_out = d->psum_out; a.FF = d->N1;

@@ -625,6 +625,12 @@ typedef struct {
     int64_t ldo;
     int32_t M, D, mode, w_dtype;
     float eps;
+    /* mode 1 as the fused q|k|v projection of a batched streaming step (N1 = 3 D): when kv_ring is given, the key and value columns are ALSO written,
+     * as the 16-bit values widened to f32, into the per-stream ring f32 [B, ring_H, ring_T, 2 dk] at slot (ring_offsets[b] + t) mod ring_T, row
+     * m = b * ring_Tq + t -- what cfm_kv_ring_write would copy from out16, without its launch */
+    float* kv_ring;
+    const int32_t* ring_offsets;
+    int32_t ring_T, ring_H, ring_Tq;
 } cfm_ffn_split_desc;
 int cfm_ffn_split(const cfm_ffn_split_desc* d, cfm_stream_t stream);
 int cfm_ffn_split_supported(int32_t D, int32_t FF);

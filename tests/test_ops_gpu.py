@@ -670,6 +670,19 @@ def test_ffn_split_modes(cfm, M, wdt):
     x1 = x + 0.5 * (slabs.sum(0) + b2)
     assert relerr(rows, x1) < 1e-6
     assert relerr(qkv.float(), r16(ln(x1, lng[3])) @ r16(wq).t() + bq) < (1.2e-2 if wdt == "bf16" else 2e-3)
+    # ... and with a K/V ring: the key / value columns land in each stream's ring slots exactly as cfm_kv_ring_write puts them
+    if M % 16 == 0:
+        Bs, Tq, H, dk, ring_T = M // 16, 16, 4, 64, 40
+        offs = torch.randint(0, 1000, (Bs,), dtype=torch.int32, device="cuda")
+        kv, kv_ref = torch.zeros((Bs, H, ring_T, 2 * dk), device="cuda"), torch.zeros((Bs, H, ring_T, 2 * dk), device="cuda")
+        qkv2 = torch.empty_like(qkv)
+        cfm.ffn_split(x, code, 1, psum=slabs, psum_b2=b2, psum_alpha=0.5, ln=lng[3], w1=packing.pack_frag_major(wq, dt), b1=bq, n1=3 * D, out16=qkv2,
+                      ring=(kv, offs, Tq))
+        q3 = qkv2.view(Bs, Tq, 3 * D)
+        kq, vq = q3[:, :, D:2 * D], q3[:, :, 2 * D:]
+        cfm.check(cfm.lib().cfm_kv_ring_write(kq.data_ptr(), vq.data_ptr(), code, Tq * 3 * D, 3 * D, Tq * 3 * D, 3 * D, kv_ref.data_ptr(), offs.data_ptr(),
+                                              Bs, H, Tq, dk, ring_T, cfm.stream()), "cfm_kv_ring_write")
+        assert torch.equal(qkv2, qkv) and torch.equal(kv, kv_ref)
     # reproducible
     again = torch.empty_like(slabs)
     cfm.ffn_split(x, code, 2, ln=lng[0], w1=w1f, b1=b1, n1=FF, act=cfm.ACT_SILU, w2=w2n, psum_out=again)
