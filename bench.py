@@ -10,6 +10,10 @@ synthetic fbank already resident in HBM.  Utterances are independent, so N GPUs 
 data-path collective ("weak" scaling: per-GPU batch fixed); the only collectives are the barrier that brackets the
 timed region and the MAX-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
 
+Setup before the W warm-up steps (outside the timed region, stated here so that nobody has to find it): the weights are packed, the step is
+captured as a HIP graph, and the graph is replayed for --ramp-ms (150 ms) to bring the GPU out of idle -- from a cold start the first ~20
+replays run 10 % slower (scripts/probe_clock_ramp.py), and a 20-step region behind 5 warm-up steps would time that ramp, not the kernels.
+
 Besides the headline value the line carries
   roofline      the dominant kernel (largest share of device time) from a second, instrumented pass over the same
                 K steps: every launch carries HIP start/stop events on its own stream (cfm_prof_*: the events are attached to the
@@ -314,6 +318,7 @@ def main():
                     help="forward: the headline encoder-forward metric (BASELINE configs[1]); train: the config-3 training step as the headline line")
     ap.add_argument("--train-steps", type=int, default=6, help="optimizer steps of the short training measurement appended to the forward line (0: skip)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
+    ap.add_argument("--ramp-ms", type=float, default=150.0, help="setup: replay the step for this long before the W warm-up steps (GPU clock ramp out of idle; 0: off)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity figure (2 utterances against the CPU oracle)")
     args = ap.parse_args()
     if args.selftest_cpu:
@@ -383,6 +388,15 @@ def main():
                 graph.replay()
             else:
                 enc(x, lens)
+
+        # setup, before the W warm-up steps: bring the GPU out of idle.  From a cold start the first ~20 replays run 10 % slower (consecutive windows of
+        # 20 replays: 1.378, 1.261, 1.253, 1.252 ... ms per step, scripts/probe_clock_ramp.py), so a region of 20 steps after 5 warm-up steps would
+        # time the clock ramp, not the kernels; the ramp is taken here, outside the timed region, whatever W the caller passes
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < args.ramp_ms * 1e-3:
+            for _ in range(10):
+                step()
+            stream.synchronize()
 
         elapsed = timed_region(step, args.steps, args.warmup, dist, lambda: torch.cuda.synchronize(device))
 
