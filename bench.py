@@ -238,7 +238,7 @@ def pick_traffic(kernels, kernel_name, d_model):
     return None
 
 
-def live_traffic(args, steps=3, warmup=1, timeout=300):
+def live_traffic(args, steps=3, warmup=1, timeout=120):
     """HBM bytes per launch of every kernel of this workload, measured NOW: two child runs of this file under
     `rocprofv3 --kernel-trace --pmc <counter>` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit the TCC counter slots
     together), no other trace domain -- with the gfx950 correction bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024
