@@ -18,6 +18,10 @@ echo "train stats done"
 cd $ROOT
 timeout -k 10 400 python scripts/collect_traffic.py $TAG > $OUT/collect_traffic.log 2>&1
 cp profiles/${TAG}_hbm_traffic.json profiles/${TAG}_mfma_util.json $OUT/ 2>/dev/null || true
+timeout -k 10 200 python scripts/bench_streaming.py 2>/dev/null > $OUT/${TAG}_streaming_config5.txt
+echo "streaming done"
+timeout -k 10 300 python scripts/bench_config4.py 2>/dev/null > $OUT/${TAG}_config4_bench.txt
+echo "config 4 done"
 rm -rf $OUT/prof_fwd $OUT/prof_train gpurun_out/traffic
 echo "traffic done"
 tail -c 600 $OUT/${TAG}_bench_default.json
