@@ -148,7 +148,10 @@ class ConformerEncoder(nn.Module):
         # than the ~11 us it hides and the concurrent kernels slow the first convolution: 1.697 vs 1.668 ms per step.)
         attn_mask = make_attn_mask(x, pad_mask, self.use_dynamic_chunk_size, self.use_dynamic_left_chunk,
                                    decoding_chunk_size, self.static_chunk_size, num_decoding_chunk_size)
-        y, _ = self._run_blocks(x, attn_mask, pos_embed, pad_mask, None, 0)
+        # split_small_batches (attribute, default False): a whole-utterance forward of <= 1536 rows (up to 6 x 1000 frames) takes the split
+        # feed-forward path of the streaming steps (csrc/ffnsplit.hip) -- lower latency for a small batch; off by default because the result then
+        # depends on which side of 1536 rows the batch falls (to rounding, 1e-3 of the output), and a batch shard no longer reproduces the batch bit for bit
+        y, _ = self._run_blocks(x, attn_mask, pos_embed, pad_mask, None, 0, streaming=bool(getattr(self, "split_small_batches", False)))
         return y.to(inputs.dtype), pad_mask
 
     def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None, abs_rows=None):

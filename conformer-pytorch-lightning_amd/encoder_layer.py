@@ -22,14 +22,14 @@ from convolution import ConvolutionModule
 from feedforward import PositionwiseFeedForwardModule, _inference_only
 
 _ABSENT = torch.ones((0, 0, 0), dtype=torch.bool)
-SPLIT_FFN_FEW_ROWS = True  # STREAMING steps of <= 2048 rows run their feed-forwards split over FF/256 workgroups per row tile (csrc/ffnsplit.hip).  Only
+SPLIT_FFN_FEW_ROWS = True  # STREAMING steps of <= 1536 rows run their feed-forwards split over FF/256 workgroups per row tile (csrc/ffnsplit.hip).  Only
 # the streaming entry points ask for it (split_ffn=True): a whole-utterance forward keeps one algorithm for every batch size, so that a batch shard
 # reproduces the batch bit for bit
 
 
 def split_rows(M, D, FF):
     """True where cfm_encoder_layer_forward takes the split feed-forward when given the slabs (cfm.h CFM_FFSPLIT_MAX_ROWS)."""
-    return M <= 2048 and D == 256 and FF % 256 == 0 and FF > 0
+    return M <= 1536 and D == 256 and FF % 256 == 0 and FF > 0        # measured crossover (scripts/bench_small_batch.py): 996 rows -21 %, 1992 rows +4 %
 
 
 CHAIN_BLOCKS = True        # the final chain of block i also runs the macaron chain of block i+1 (one launch and one residual round trip less)

@@ -425,7 +425,7 @@ typedef struct {
                       tile instead of inside the row chains (few rows: a streaming step); null = never */
     int32_t psum_splits;
 } cfm_layer_scratch;
-#define CFM_FFSPLIT_MAX_ROWS 2048
+#define CFM_FFSPLIT_MAX_ROWS 1536 /* measured crossover against the row chains: 996 rows -21 %, 1992 rows +4 % (scripts/bench_small_batch.py) */
 
 typedef struct {
     int32_t B, T, D, H, FF, ktaps;

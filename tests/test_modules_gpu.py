@@ -231,6 +231,35 @@ def test_encoder_cfg2_arch_matches_reference(pkg, mode):
     check("enc_cfg2s (12 layers)", y, g["y"], mode)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_small_batch_split_feedforward_matches_reference(pkg, mode):
+    """ConformerEncoder.split_small_batches (opt-in): a whole-utterance forward of few rows on the split feed-forward path (csrc/ffnsplit.hip) -- the
+    same reference fixture and gates as the row-chain path; it must really take the other path (different bits), and switching it off restores the
+    row chains' bits."""
+    g, meta = load_golden("enc_cfg2s")
+    pkg.cfm.set_precision(mode)
+    enc = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    x = dev(synth.fbank(meta["xseed"], meta["batch"], meta["frames"]))
+    lens = torch.tensor(meta["lens"], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        y0, _ = enc(x, lens)
+        enc.split_small_batches = True
+        y1, m = enc(x, lens)
+        pkg.cfm.prof_reset()
+        pkg.cfm.prof_enable(True)
+        enc(x, lens)
+        torch.cuda.synchronize()
+        pkg.cfm.prof_enable(False)
+        names = set(pkg.cfm.prof_table())
+        pkg.cfm.prof_reset()
+        enc.split_small_batches = False
+        y2, _ = enc(x, lens)
+    assert np.array_equal(m.cpu().numpy().astype(np.uint8), g["mask"])
+    check("enc_cfg2s (12 layers), split feed-forward", y1, g["y"], mode)
+    assert any(n.startswith("ffnsplit_ffn") for n in names) and not any(n.startswith("chain_macaron") or n.startswith("chain_dwfinal") for n in names)
+    assert not torch.equal(y0, y1) and torch.equal(y0, y2)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_streaming_matches_reference(pkg, mode):
     g, meta = load_golden("enc_cfg1_stream")
