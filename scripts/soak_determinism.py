@@ -30,3 +30,35 @@ for mode in ("bf16", "fp16", "fp32"):
     print("%s: %d mismatching runs out of %d (eager + graph), output finite: %s" % (mode, bad, 2 * (N if mode != "fp32" else N // 4), bool(torch.isfinite(ref).all())), flush=True)
     assert bad == 0
 print("soak ok")
+
+# ---- round 2 additions: the split feed-forward path (a small batch and a batched streaming step) and the K-group GEMM tiles
+import encoder as enc_mod
+cfm.set_precision("bf16")
+enc = bench.build_encoder(dev)
+enc.split_small_batches = True
+xs = torch.from_numpy(np.random.RandomState(11).standard_normal((3, 1000, 80)).astype(np.float32)).to(dev)
+ls = torch.tensor([1000, 873, 640], dtype=torch.int32, device=dev)
+with torch.no_grad():
+    ref, _ = enc(xs, ls)
+    bad = sum(int(not torch.equal(enc(xs, ls)[0], ref)) for _ in range(N))
+print("split feed-forward, batch 3 x 1000 frames: %d mismatching runs out of %d" % (bad, N), flush=True)
+enc.split_small_batches = False
+B, chunk, left = 64, 16, 4
+window, hop = (chunk - 1) * 4 + 7, 4 * chunk
+xw = torch.from_numpy(np.random.RandomState(5).standard_normal((B, window + 30 * hop, 80)).astype(np.float32)).to(dev)
+outs = []
+for rep in range(4):
+    sb = enc_mod.StreamingBatch(enc, B, chunk, left)
+    ys = []
+    with torch.no_grad():
+        for step in range(30):
+            ys.append(sb.step(xw[:, step * hop: step * hop + window].contiguous()).clone())
+    outs.append(torch.stack(ys))
+bad = sum(int(not torch.equal(o, outs[0])) for o in outs[1:])
+print("StreamingBatch 64 streams x 30 steps (graph replay), 4 sessions: %d differ from the first" % bad, flush=True)
+a = torch.randn((2380, 2048), device=dev).to(torch.bfloat16)
+w = torch.randn((256, 2048), device=dev).to(torch.bfloat16)
+for tile in (9, 10, 11):
+    ref = cfm.gemm(a, w, tile=tile)
+    bad = sum(int(not torch.equal(cfm.gemm(a, w, tile=tile), ref)) for _ in range(N))
+    print("gemm tile %d (K groups): %d mismatching runs out of %d" % (tile, bad, N), flush=True)
