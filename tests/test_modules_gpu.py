@@ -736,11 +736,14 @@ def test_streaming_batch_per_stream_offsets(pkg, mode, graph):
     assert worst < TOL[mode] * 2.0, worst
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp32"])
-def test_config5_64_streams_against_oracle(pkg, mode):
+@pytest.mark.parametrize("mode,split", [("bf16", True), ("bf16", False), ("fp32", True)])
+def test_config5_64_streams_against_oracle(pkg, mode, split, monkeypatch):
     """BASELINE config 5 at its real size: 64 streams x chunk 16 (67-frame windows) x 4 cached chunks on the 12-layer d=256 model, one
-    captured step; streams checked against the CPU oracle's batch-1 forward_chunk loop (reference semantics, encoder.py:78-123)."""
+    captured step; streams checked against the CPU oracle's batch-1 forward_chunk loop (reference semantics, encoder.py:78-123).
+    split: the feed-forwards split over FF (csrc/ffnsplit.hip, the default for a step of this size) / the row chains with consecutive
+    blocks chained over the K/V ring (what a step of more than 1536 rows runs)."""
     from oracle import conformer_oracle as O
+    monkeypatch.setattr(pkg.encoder_layer, "SPLIT_FFN_FEW_ROWS", split)
     pkg.cfm.set_precision(mode)
     enc = build_encoder(pkg, CFG2, 12)
     B, chunk, left, steps = 64, 16, 4, 7
@@ -752,6 +755,17 @@ def test_config5_64_streams_against_oracle(pkg, mode):
         for s in range(steps):
             outs.append(sb.step(feats[:, s * hop: s * hop + window].contiguous()).clone())
     assert sb.graph is not None and sb.offsets.tolist() == [steps * chunk] * B
+    if mode != "fp32":                                         # the path really is the one the parameter names
+        sb2 = pkg.encoder.StreamingBatch(enc, B, chunk, left, graph=False)
+        pkg.cfm.prof_reset()
+        pkg.cfm.prof_enable(True)
+        with torch.no_grad():
+            sb2.step(feats[:, 0:window].contiguous())
+        torch.cuda.synchronize()
+        pkg.cfm.prof_enable(False)
+        names = set(pkg.cfm.prof_table())
+        pkg.cfm.prof_reset()
+        assert any(n.startswith("ffnsplit_ffn") for n in names) == split and any(n.startswith("chain_dwfinal_macaron") for n in names) == (not split), names
     P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
     cfg = O.Config(**CFG2)
     worst = 0.0
