@@ -151,6 +151,22 @@ def train_measure(args, dist, world, rank, device, steps, warmup, precision=None
                         "(B*T_max <= 8000 frames, lengths U{200..1650}, seed 1234+rank), accum_grad 2, clip 4, Adam + WarmupLR, dropout 0.1"}
 
 
+def rank_devices(dist, world, rank, device):
+    """One string per rank: which physical GPU it runs on (index, name, PCI address / uuid).  N ranks must sit on N DIFFERENT GPUs --
+    two ranks sharing a card would still print n_gpus = N -- so a duplicate aborts the run on every rank."""
+    pr = torch.cuda.get_device_properties(device)
+    ident = str(getattr(pr, "uuid", "")) or "%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))
+    mine = "rank%d=cuda:%d %s [%s]" % (rank, device.index, pr.name, ident)
+    if dist is None:
+        return [mine]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, (mine, ident))
+    idents = [g[1] for g in got]
+    if len(set(idents)) != len(idents):
+        raise SystemExit("bench.py: ranks share a GPU: %s" % ([g[0] for g in got],))
+    return [g[0] for g in got]
+
+
 def timed_region(step, steps, warmup, dist, sync):
     """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides; MAX over ranks."""
     def barrier():
@@ -195,7 +211,7 @@ def selftest_cpu(args):
     elapsed = timed_region(step, args.steps, args.warmup, dist, lambda: None)
     if rank == 0:
         print(json.dumps({"metric": "selftest", "value": world * args.batch * args.frames * args.steps / elapsed, "unit": "frames/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "n_gpus": world, "ranks": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "selftest",
                           "config": {"workload": "cpu selftest of the launch/timing harness"}}), flush=True)
     if dist is not None:
@@ -300,6 +316,43 @@ def committed_traffic():
     return {k: v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items()}, "%s (same sources, digest %s)" % (os.path.relpath(files[-1], ROOT), source_digest())
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 outside torchrun: start the N ranks OURSELVES, as the reference's `pl.Trainer(devices=N)` does
+    (src/executor.py:137-139) -- a child `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, BEFORE this process
+    makes any HIP call (a process that has initialised the GPU must not fork / exec workers on this pool).  The child's stdout (rank 0's ONE
+    JSON line) and exit code are relayed; this process never touches the GPU."""
+    import subprocess
+    if not args.selftest_cpu:
+        n_dev = torch.cuda.device_count()                # counts devices without creating a HIP context
+        if n_dev < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
+def check_world(args):
+    """The rank count the launcher gave us must be the one the caller asked for: `--gpus 8` may never silently measure one GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args, sys.argv[1:])                 # does not return
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; pass --gpus %d (or start %d ranks)"
+                         % (args.gpus, world, world, args.gpus))
+    return world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,10 +374,10 @@ def main():
     ap.add_argument("--ramp-ms", type=float, default=150.0, help="setup: replay the step for this long before the W warm-up steps (GPU clock ramp out of idle; 0: off)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity figure (2 utterances against the CPU oracle)")
     args = ap.parse_args()
+    world = check_world(args)                            # N > 1 outside a launcher: spawns the ranks and exits with their code
     if args.selftest_cpu:
         return selftest_cpu(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # CFM_BENCH_FORCE_DIST=1: take the RCCL path (init, barrier, MAX all-reduce) even with one rank -- lets a 1-GPU box rehearse it
@@ -347,6 +400,11 @@ def main():
         raise SystemExit("bench.py: " + cfm.lib().cfm_last_error().decode())
     cfm.set_precision(args.precision)
 
+    devices = rank_devices(dist, world, rank, device)
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
+    if rccl_ranks != world and dist is not None:
+        raise SystemExit("bench.py: process group has %d ranks, WORLD_SIZE says %d" % (rccl_ranks, world))
+
     if args.mode == "train":
         rec = train_measure(args, dist, world, rank, device, args.steps, args.warmup, args.precision)
         if rank == 0:
@@ -355,6 +413,7 @@ def main():
                     "data": "synthetic", "config": {k: v for k, v in rec.items() if k not in ("metric", "value", "unit", "ms_per_step", "steps", "warmup")},
                     "roofline": None, "cpu_baseline": None}
             line["config"]["parallelism"] = "dp%d (RCCL gradient all-reduce, 25 MB buckets overlapped with backward)" % world
+            line["config"].update(rccl_ranks=rccl_ranks, devices=devices)
             print(json.dumps(line), flush=True)
         if dist is not None:
             dist.barrier()
@@ -518,7 +577,10 @@ def main():
                                    "batch %d x (80 x %d) synthetic fbank per GPU, random-init weights" % (B, T),
                        "batch_per_gpu": B, "frames": T, "frames_per_s_per_gpu": round(frames_per_s / world, 1),
                        "parallelism": "replicas x%d (batch-sharded, no data-path collective)" % world,
+                       "rccl_ranks": rccl_ranks, "devices": devices,
                        "launch": "hip graph replay" if graph is not None else "eager",
+                       "ramp_ms": args.ramp_ms, "ramp_note": "setup: the captured step is replayed for ramp_ms before the W warm-up steps (GPU clock ramp "
+                                                             "out of idle), outside the timed region",
                        "whole_encoder_tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
                        "whole_encoder_frac_of_mfma_peak": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4),
                        "max_rel_err_vs_oracle": None if parity is None else round(parity[args.precision], 6),

@@ -16,7 +16,18 @@ clip-by-global-norm after the reduce, Adam.  The MI355X-first restatement:
   * after the last bucket: sum of squares of the flat gradient (one kernel), clip coefficient computed ON THE DEVICE, fused
     clip-scale + average + Adam over the flat buffers (one kernel, cfm_adam_step), gradient buffer zeroed.  No host synchronisation
     anywhere in the step; the learning rate is host scalar math (WarmupLR, src/scheduler.py:36-52).
-  * BatchNorm statistics stay per rank (the reference uses no SyncBatchNorm: SURVEY quirk Q6).
+  * replicas start EQUAL: the constructor broadcasts rank 0's flat parameter buffer and every module buffer (BatchNorm running
+    statistics, num_batches_tracked) -- DDP's construction-time `_sync_module_states`, which the reference gets from Lightning's
+    DDPStrategy (src/executor.py:137-139,153: one process per GPU, each building its own model at :60-100) -- and then asserts, with
+    a MIN/MAX all-reduce of a checksum, that every rank holds the same bits.  Ranks seeded differently, or a checkpoint loaded on
+    rank 0 only, therefore cannot diverge silently.
+  * BatchNorm batch statistics are per rank (the reference uses no SyncBatchNorm: SURVEY quirk Q6); the RUNNING statistics follow
+    DDP's default `broadcast_buffers=True`: float buffers live in one flat buffer that rank 0 broadcasts before the first forward of
+    every optimizer step (DDP syncs buffers in the forward that follows a gradient sync: once per optimizer step under accumulation),
+    so every rank evaluates / checkpoints rank 0's statistics, as under Lightning.  `broadcast_buffers=False` keeps them per rank.
+  * optional 16-bit gradient buckets (`grad_comm_dtype=torch.bfloat16`): a bucket is rounded to bf16 into a staging buffer, all-reduced
+    (half the xGMI bytes: 69.5 MB instead of 139 MB per step at config 3) and widened back into the f32 gradient buffer; the sum over
+    ranks is then rounded per hop by the collective, so it is opt-in and tested against the f32 path with a stated tolerance.
 
 The elementwise kernels come from a small `kernels` object (default: the HIP ones, no fallback); the gloo/CPU tests of the bucket /
 accumulate / clip logic inject a torch implementation from tests/.
@@ -54,9 +65,12 @@ def warmup_lr(base_lr, warmup_steps, step_num):
 
 class DataParallelTrainer:
     def __init__(self, modules, loss_fn, lr=1e-3, warmup_steps=25000, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, accum_grad=2,
-                 grad_clip=4.0, bucket_mb=25.0, process_group=None, kernels=None, always_reduce=False):
+                 grad_clip=4.0, bucket_mb=25.0, process_group=None, kernels=None, always_reduce=False, broadcast_buffers=True,
+                 grad_comm_dtype=None):
         """modules: nn.Modules in FORWARD order (their parameters are flattened in reverse); loss_fn(batch) -> scalar loss tensor.
-        always_reduce: issue the bucket all-reduces even with one rank (lets a 1-GPU box rehearse the RCCL path)."""
+        always_reduce: issue the collectives even with one rank (lets a 1-GPU box rehearse the RCCL path).
+        broadcast_buffers: rank 0's float buffers overwrite every rank's before each optimizer step's first forward (DDP's default).
+        grad_comm_dtype: None (f32 all-reduce) or torch.bfloat16 / torch.float16 (16-bit bucket payloads)."""
         self.modules = list(modules)
         self.loss_fn = loss_fn
         self.base_lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
@@ -66,6 +80,10 @@ class DataParallelTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.always_reduce = bool(always_reduce) and dist.is_available() and dist.is_initialized()
         self.step_count = 0
+        self.broadcast_buffers = bool(broadcast_buffers)
+        if grad_comm_dtype not in (None, torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("grad_comm_dtype must be None, float32, bfloat16 or float16")
+        self.grad_comm_dtype = None if grad_comm_dtype in (None, torch.float32) else grad_comm_dtype
 
         forward_order = []
         seen = set()
@@ -96,6 +114,8 @@ class DataParallelTrainer:
                 self.flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + p.numel()].view(p.shape)
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self._flatten_buffers(dev)
+        self.sync_module_states()
         self.kernels.weights_changed()
 
         # Autograd UNITS.  A conformer block whose backward writes all its parameter gradients into one contiguous slab (cfm/autograd.py
@@ -148,10 +168,76 @@ class DataParallelTrainer:
         self._ready = [0] * len(self.buckets)
         self._next = 0
         self._works = []
+        self._stage, self._tmpbuf = None, None
         self._sync = False
         self.reduce_log = []                                                # bucket indices in launch order of the last step (tests)
         for t, _, _ in units:
             t.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _flatten_buffers(self, dev):
+        """Float buffers (BatchNorm running_mean / running_var) become views into ONE flat buffer -- one broadcast per optimizer step instead
+        of one per tensor; integer buffers (num_batches_tracked) advance identically on every rank and are broadcast at construction only."""
+        fl, other, seen = [], [], set()
+        for m in self.modules:
+            for b in m.buffers():
+                if id(b) in seen or b.numel() == 0:
+                    continue
+                seen.add(id(b))
+                (fl if (b.dtype == torch.float32 and b.device == dev) else other).append(b)
+        self.float_buffers, self.other_buffers = fl, other
+        n = sum((b.numel() + 3) // 4 * 4 for b in fl)
+        self.flat_b = torch.zeros(n, dtype=torch.float32, device=dev)
+        o = 0
+        with torch.no_grad():
+            for b in fl:
+                self.flat_b[o:o + b.numel()].copy_(b.reshape(-1))
+                b.data = self.flat_b[o:o + b.numel()].view(b.shape)       # in-place updates (the BatchNorm kernels) land in the flat buffer
+                o += (b.numel() + 3) // 4 * 4
+
+    def _collective(self):
+        return self.world > 1 or self.always_reduce
+
+    def sync_module_states(self):
+        """Rank 0's parameters and buffers overwrite every rank's (DDP's `_sync_module_states` at construction; executor.py:137-139), then
+        every rank checks that the job holds ONE model: a bit-level checksum of the flat parameter and buffer images, MIN == MAX over ranks."""
+        if not self._collective():
+            return
+        dist.broadcast(self.flat_p, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+        self._broadcast_buffers(initial=True)
+        self.assert_replicas_equal()
+
+    def _broadcast_buffers(self, initial=False):
+        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+        if self.flat_b.numel():
+            dist.broadcast(self.flat_b, src=src, group=self.pg)
+        if initial:
+            for b in self.other_buffers:
+                dist.broadcast(b, src=src, group=self.pg)
+
+    def replica_checksum(self):
+        """4 int64 words over the BITS of the flat parameter and float-buffer images (sum and position-weighted sum of the int32 view)."""
+        words = []
+        for t in (self.flat_p, self.flat_b):
+            if t.numel() == 0:
+                words += [torch.zeros((), dtype=torch.int64, device=t.device)] * 2
+                continue
+            bits = t.view(torch.int32).to(torch.int64)
+            idx = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=t.device) % 65521
+            words += [bits.sum(), (bits * idx).sum()]
+        return torch.stack(words)
+
+    def assert_replicas_equal(self):
+        """Raises on EVERY rank (the MIN / MAX all-reduces are collectives all ranks see) when any rank's parameters or float buffers differ."""
+        if not self._collective():
+            return
+        c = self.replica_checksum()
+        lo, hi = c.clone(), c.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("DataParallelTrainer: replicas hold different parameters / buffers (checksum min %s max %s)"
+                               % (lo.tolist(), hi.tolist()))
 
     # ------------------------------------------------------------------------------------------------------------
     def _on_grad(self, p):
@@ -167,9 +253,24 @@ class DataParallelTrainer:
 
     def _launch(self, b):
         self.reduce_log.append(b)
-        if self.world > 1 or self.always_reduce:
+        if self._collective():
             s, e, _ = self.buckets[b]
-            self._works.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if self.grad_comm_dtype is None:
+                self._works.append((dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None))
+            else:
+                # 16-bit payload: round the bucket into its staging slice, reduce that, widen back after the wait.  Pre-divided by the world
+                # size so the running sum stays in range of fp16 as well (finish() then skips its own division)
+                if self._stage is None:
+                    self._stage = torch.empty(self.numel, dtype=self.grad_comm_dtype, device=self.flat_g.device)
+                st = self._stage[s:e]
+                torch.mul(self.flat_g[s:e], 1.0 / self.world, out=self._tmp(e - s))
+                st.copy_(self._tmp(e - s))
+                self._works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), (s, e, st)))
+
+    def _tmp(self, n):
+        if self._tmpbuf is None or self._tmpbuf.numel() < n:
+            self._tmpbuf = torch.empty(max(e - s for s, e, _ in self.buckets), dtype=torch.float32, device=self.flat_g.device)
+        return self._tmpbuf[:n]
 
     # ------------------------------------------------------------------------------------------------------------
     def lr(self):
@@ -181,6 +282,8 @@ class DataParallelTrainer:
             raise ValueError("step() wants %d micro-batches (accum_grad), got %d" % (self.accum_grad, len(micro_batches)))
         total = None
         self.reduce_log = []
+        if self.broadcast_buffers and self._collective():
+            self._broadcast_buffers()                                       # DDP broadcast_buffers=True: rank 0's running statistics
         for i, mb in enumerate(micro_batches):
             self._sync = i == self.accum_grad - 1                          # no_sync on all but the last micro-batch
             self._ready = [0] * len(self.buckets)
@@ -192,21 +295,24 @@ class DataParallelTrainer:
         while self._next < len(self.buckets):                               # parameters that took no part in this graph: still reduce
             self._launch(self._next)
             self._next += 1
-        for w in self._works:
+        for w, widen in self._works:
             w.wait()                                                        # the current stream waits for RCCL's
+            if widen is not None:
+                s, e, st = widen
+                self.flat_g[s:e].copy_(st)
         self._works = []
         self.finish()
         return total / self.accum_grad
 
     def finish(self):
         """clip by the global norm of the AVERAGED gradient (executor.py:150), Adam, zero the gradient buffer."""
-        inv_world = 1.0 / self.world
+        inv_world = 1.0 / self.world if self.grad_comm_dtype is None else 1.0    # 16-bit buckets arrive averaged
         scale = None
         if self.grad_clip is not None and self.grad_clip > 0:
             norm = self.kernels.sumsq(self.flat_g).sqrt() * inv_world       # 1-element device tensors: no sync
             scale = (self.grad_clip / (norm + 1e-6)).clamp(max=1.0) * inv_world
             self.last_grad_norm = norm
-        elif self.world > 1:
+        elif inv_world != 1.0:
             scale = torch.full((1,), inv_world, dtype=torch.float32, device=self.flat_g.device)
         self.step_count += 1
         self.kernels.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, warmup_lr(self.base_lr, self.warmup_steps, self.step_count),

