@@ -278,7 +278,7 @@ def live_traffic(args, steps=3, warmup=1, timeout=120):
             out = os.path.join(base, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", str(steps), "--warmup", str(warmup), "--batch", str(args.batch), "--frames", str(args.frames), "--precision", args.precision,
-                   "--graph", "0", "--train-steps", "0", "--no-cpu-baseline", "--no-parity", "--no-live-traffic"]
+                   "--graph", "0", "--train-steps", "0", "--no-cpu-baseline", "--no-parity", "--no-live-traffic", "--no-fp16"]
             r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
             files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
             if r.returncode != 0 or not files:
@@ -372,6 +372,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=6, help="optimizer steps of the short training measurement appended to the forward line (0: skip)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--ramp-ms", type=float, default=150.0, help="setup: replay the step for this long before the W warm-up steps (GPU clock ramp out of idle; 0: off)")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the fp16 measurement that accompanies a bf16 headline")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity figure (2 utterances against the CPU oracle)")
     args = ap.parse_args()
     world = check_world(args)                            # N > 1 outside a launcher: spawns the ranks and exits with their code
@@ -487,11 +488,13 @@ def main():
                 y_m, _ = enc(x, lens)
                 parity[mode] = float((y_m[:2].double().cpu() - y_ref.double()).abs().max() / y_ref.double().abs().max())
             enc.set_precision(None)
-    # ---- the same step in fp16 (meets the 1e-3 north-star tolerance at bf16 speed): eager step time beside the headline ----
-    alt = None
-    if rank == 0 and args.precision == "bf16":
+    # ---- the same step in fp16, as a FULL measurement: fp16 meets north_star's <= 1e-3 at bf16 speed, so the number that
+    # satisfies north_star in full must be quotable by itself -- same graph capture, ramp, W warm-up steps, K timed steps bracketed by barrier +
+    # sync, MAX over ranks (every rank takes part: timed_region's barriers are collectives); bf16 re-timed beside it, back to back ----
+    alt, fp16_line = None, None
+    if args.precision == "bf16" and not args.no_fp16:
         with torch.no_grad(), torch.cuda.stream(stream):
-            alt = {}
+            alt, el = {}, {}
             for mode in ("bf16", "fp16"):
                 enc.set_precision(mode)
                 for _ in range(3):
@@ -500,12 +503,21 @@ def main():
                 with torch.cuda.graph(g2, stream=stream):
                     enc(x, lens)
                 stream.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(50):
-                    g2.replay()
-                stream.synchronize()
-                alt[mode] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
+                t_ramp = time.perf_counter()
+                while time.perf_counter() - t_ramp < args.ramp_ms * 1e-3:
+                    for _ in range(10):
+                        g2.replay()
+                    stream.synchronize()
+                el[mode] = timed_region(g2.replay, args.steps, args.warmup, dist, lambda: torch.cuda.synchronize(device))
+                alt[mode] = round(el[mode] / args.steps * 1e3, 4)
             enc.set_precision(None)
+        fps16 = world * B * T * args.steps / el["fp16"]
+        fp16_line = {"metric": "encoder frames/sec (80-d fbank, T=%d), whole job" % T, "value": round(fps16, 1), "unit": "frames/s", "dtype": "fp16",
+                     "ms_per_step": alt["fp16"], "steps": args.steps, "warmup": args.warmup, "n_gpus": world, "launch": "hip graph replay",
+                     "max_rel_err_vs_oracle": None if parity is None else round(parity["fp16"], 7),
+                     "meets_north_star_1e-3": None if parity is None else bool(parity["fp16"] <= 1e-3),
+                     "bf16_ms_per_step_same_procedure": alt["bf16"],
+                     "note": "same kernels, fp16 MFMA operands / f32 accumulation / f32 residual stream; timed exactly like the headline"}
     # ---- BASELINE config 3 (training step), short: every rank takes part (the gradient all-reduce is a collective) ----
     train = None
     if args.train_steps > 0:
@@ -587,6 +599,7 @@ def main():
                        "max_rel_err_vs_oracle_by_mode": None if parity is None else {k: round(v, 7) for k, v in parity.items()},
                        "parity_note": "max|d|/max|ref| of utterances 0-1 of this batch against oracle/conformer_oracle.py (fp32 CPU), same weights, same run",
                        "ms_per_step_by_mode_graph_replay": alt},
+            "fp16": fp16_line,
             "train": train,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -34,6 +34,8 @@ __global__ void cfm_stream_prep_kernel(const int* __restrict__ offsets, int B, i
         const int f = slot_frame(off + T - 1, s, ring_T);
         const bool valid = f >= off - cached && f >= 0;
         if (threadIdx.x == 0) slot_mask[(int64_t)b * ring_T + s] = valid ? 1 : 0;
+        // f < max_len is the caller's job (encoder.StreamingBatch extends the table before a stream reaches its end); the clamp only keeps a
+        // misuse of the C entry point inside the allocation
         const int row = valid ? (f < max_len ? f : max_len - 1) : 0;
         for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4)
             *(f32x4*)(pos_rows + ((int64_t)b * ring_T + s) * D + c) = *(const f32x4*)(pe + (int64_t)row * D + c);

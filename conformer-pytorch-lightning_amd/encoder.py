@@ -155,8 +155,6 @@ class ConformerEncoder(nn.Module):
         return y.to(inputs.dtype), pad_mask
 
     def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None, abs_rows=None):
-        if self.training:
-            raise NotImplementedError("ConformerEncoder.forward_chunk: streaming is inference-only; call .eval()")
         """One streaming step.  Batch 1 as in the reference: attn_cache (L,H,Tc,2dk) or empty; returns (chunk output, new attn
         cache (L,H,Tc',2dk), cnn cache (L,0,0,0) -- the reference keeps no conv context).
         Batch B > 1 (beyond the reference, whose forward_chunk only works at batch 1: SURVEY 8 row S): B streams in lockstep at
@@ -164,6 +162,8 @@ class ConformerEncoder(nn.Module):
         batch-1 call on inputs[b:b+1] with attn_cache[:, b].
         pos_rows (cached + chunk, 1, D): the positional rows for this step in a caller-owned buffer instead of a slice taken at `offset`
         (StreamingSession replays one captured graph per step and refreshes that buffer between replays)."""
+        if self.training:
+            raise NotImplementedError("ConformerEncoder.forward_chunk: streaming is inference-only; call .eval()")
         inputs, cmvn = self._cmvn_args(inputs)
         cfm.require_hip(inputs)
         dev = inputs.device
@@ -346,6 +346,11 @@ class StreamingBatch:
         self.causal = bool(causal_conv)
         self.conv = torch.zeros((L, self.B, K - 1, D), dtype=torch.float32, device=dev) if self.causal else None
         self.pe = encoder.position_encoding.pe.reshape(-1, D).to(device=dev, dtype=torch.float32).contiguous()
+        # host mirror of an UPPER BOUND of `offsets` (every step advances every stream by `chunk`; reset() zeroes): lets step() see, without a
+        # device sync, that a stream is about to read past the sinusoid table -- the reference's pe[offset:offset+size] comes back short there
+        # and fails (attention.py:25-29; max_len = 5000 encoder frames = 200 s of audio); a long-lived stream here gets the table EXTENDED
+        # with the same formula instead of wrong rows (cfm_stream_prep used to clamp to the last row, silently)
+        self._host_off = [0] * self.B
         self.x = None
         self.use_graph, self.graph, self.y, self._sig = bool(graph), None, None, None
         self.steps = 0
@@ -354,16 +359,30 @@ class StreamingBatch:
         """start new utterances on the given streams (all by default): position 0, empty left context."""
         if streams is None:
             self.offsets.zero_()
+            self._host_off = [0] * self.B
             if self.conv is not None:
                 self.conv.zero_()
         else:
-            idx = torch.as_tensor(list(streams), dtype=torch.long, device=self.dev)
+            streams = list(streams)
+            idx = torch.as_tensor(streams, dtype=torch.long, device=self.dev)
+            for b in streams:
+                self._host_off[b] = 0
             self.offsets[idx] = 0
             if self.conv is not None:
                 self.conv[:, idx] = 0
 
     def _signature(self):
         return _weights_signature(self)
+
+    def _grow_table(self, rows_needed):
+        """Append sinusoid rows [len, new_len) -- the reference's formula (attention.py:12-16 / :109-115 incl. the absolute table's fp16
+        rounding), existing rows untouched -- and drop the captured graph (it holds the old table's address)."""
+        from attention import _sinusoid_table
+        have = self.pe.size(0)
+        new_len = max(2 * have, rows_needed)
+        full = _sinusoid_table(new_len, self.pe.size(1), type(self.enc.position_encoding)._table_dtype).reshape(new_len, -1)
+        self.pe = torch.cat([self.pe, full[have:].to(device=self.dev, dtype=torch.float32)]).contiguous()
+        self.graph = None
 
     def _step_impl(self):
         enc = self.enc
@@ -393,6 +412,9 @@ class StreamingBatch:
             self.x = torch.empty_like(frames, dtype=torch.float32).contiguous()
         self.x.copy_(frames)
         self.steps += 1
+        if max(self._host_off) + self.chunk > self.pe.size(0):
+            self._grow_table(max(self._host_off) + self.chunk)
+        self._host_off = [o + self.chunk for o in self._host_off]
         with torch.no_grad():
             if not self.use_graph:
                 return self._step_impl()

@@ -5,10 +5,12 @@ The mask half is on the hot path:
   subsequent_chunk_mask  utils.py:96-111  -> one launch of cfm_chunk_mask instead of a T'-iteration python loop of
                                              slice assignments (T' tiny kernels per forward in the reference)
   make_attn_mask         utils.py:115-160 -> same selector logic, host RNG draws kept (torch.randint(...).item())
-The reference's label helpers (pad_list, load_vocabs, add_blank, add_sos_eos, reverse_sequence: utils.py:31-81,171-190) are host-side
-label preparation, OUT OF SCOPE for this build and deliberately not provided: a deployment keeps the reference's own
-``utils.py`` for them and takes only the three mask builders from here.  ``load_cmvn`` stays: GlobalCMVN
-(cmvn.py) is on the path's "next" list and is folded into the first convolution.
+The reference's label helpers (pad_list, load_vocabs, add_blank, add_sos_eos, reverse_sequence, make_subsequent_mask: utils.py:31-81,
+163-190) are host-side label preparation, off the hot path -- but with this directory shadowing ``src/`` on sys.path (the
+file-swap route of INTEGRATION.md) the reference's own model.py / decoder.py (`from utils import *`) and executor.py
+(`from utils import load_vocabs`) import them from HERE, so they are provided, as plain torch host code with the reference's signatures and
+results (pinned by tests/golden/labels.npz, produced by the reference's functions).  ``load_cmvn`` feeds GlobalCMVN (cmvn.py), which is
+folded into the first convolution.
 """
 import json
 import math
@@ -67,3 +69,50 @@ def load_cmvn(json_cmvn_file):
         var = max(second / n - mu * mu, 1.0e-20)
         istd.append(1.0 / math.sqrt(var))
     return torch.tensor(mean), torch.tensor(istd)
+
+
+# ------------------------------------------------------------------- host-side label helpers (utils.py:31-81,163-190), off the hot path
+def pad_list(xs, pad_value):
+    """[(T_1, *), ..., (T_B, *)] -> (B, max T, *) filled with pad_value behind each sequence; dtype / device of the first entry."""
+    longest = max(int(x.size(0)) for x in xs)
+    out = xs[0].new_full((len(xs), longest) + tuple(xs[0].shape[1:]), pad_value)
+    for row, x in zip(out, xs):
+        row[:x.size(0)] = x
+    return out
+
+
+def load_vocabs(vocab_path):
+    """`word index` per line -> ({word: index}, size)."""
+    table = {}
+    with open(vocab_path) as f:
+        for line in f:
+            word, idx = line.strip().split(' ')
+            table[word] = int(idx)
+    return table, len(table)
+
+
+def add_blank(targets, blank, ignore_id):
+    """(B, U) -> (B, U+1): a blank in front of every row, padding (ignore_id) turned into blanks (the RNN-T predictor's input)."""
+    lead = targets.new_full((targets.size(0), 1), blank, dtype=torch.long)
+    out = torch.cat([lead, targets], dim=1)
+    return out.masked_fill(out == ignore_id, blank)
+
+
+def make_subsequent_mask(length, device):
+    """bool (length, length), lower triangle incl. the diagonal: position i sees positions <= i."""
+    idx = torch.arange(length, device=device)
+    return idx.unsqueeze(0) <= idx.unsqueeze(1)
+
+
+def add_sos_eos(targets, sos, eos, ignore_id):
+    """Padded labels -> (sos + labels padded with eos, labels + eos padded with ignore_id)."""
+    head = targets.new_tensor([sos], dtype=torch.long)
+    tail = targets.new_tensor([eos], dtype=torch.long)
+    rows = [row[row != ignore_id] for row in targets]
+    return pad_list([torch.cat([head, r]) for r in rows], eos), pad_list([torch.cat([r, tail]) for r in rows], ignore_id)
+
+
+def reverse_sequence(targets, target_lengths, ignore_id):
+    """Each row's first target_lengths[b] labels in reverse order (int32), padded with ignore_id to the longest."""
+    flipped = [row.int()[:int(n)].flip(0) for row, n in zip(targets, target_lengths)]
+    return nn.utils.rnn.pad_sequence(flipped, batch_first=True, padding_value=ignore_id)

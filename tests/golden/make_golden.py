@@ -504,11 +504,43 @@ def gen_train():
                                                     sub=(34, 44, 67), layer=(35, 45, 68), layer_norel=(37, 45, 69))))
 
 
+def gen_labels():
+    """The host-side label helpers of the reference's utils.py (pad_list, add_blank, add_sos_eos, reverse_sequence, make_subsequent_mask,
+    load_vocabs) on integer inputs drawn from numpy seeds: the drop-in utils.py must keep providing them (the file-swap route imports
+    `from utils import *` in model.py / decoder.py and `load_vocabs` in executor.py)."""
+    import tempfile
+    rs = np.random.RandomState(77)
+    lens = [7, 4, 1, 5]
+    targets = np.full((4, 7), -1, dtype=np.int64)
+    for b, n in enumerate(lens):
+        targets[b, :n] = rs.randint(2, 50, size=n)
+    tt = torch.from_numpy(targets)
+    arrays = {"targets": targets, "lens": np.array(lens, dtype=np.int64)}
+    arrays["add_blank"] = t2n(ref_utils.add_blank(tt, 0, -1))
+    a, b = ref_utils.add_sos_eos(tt, 51, 52, -1)
+    arrays["sos_in"], arrays["eos_out"] = t2n(a), t2n(b)
+    arrays["reverse"] = t2n(ref_utils.reverse_sequence(tt, torch.tensor(lens), -1))
+    arrays["subsequent_6"] = t2n(ref_utils.make_subsequent_mask(6, torch.device("cpu")))
+    seqs = [torch.from_numpy(rs.standard_normal(n).astype(np.float32)) for n in (5, 2, 3)]
+    arrays["pad_list"] = t2n(ref_utils.pad_list(seqs, -2.5))
+    words = ["<blank>", "<unk>", "a", "bc", "<sos/eos>"]
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for i, w in enumerate(words):
+            f.write("%s %d\n" % (w, i))
+    vocab, n = ref_utils.load_vocabs(f.name)
+    os.unlink(f.name)
+    save("labels", arrays, {"vocab": vocab, "vocab_size": n, "words": words, "pad_seed": 77})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "labels":       # new fixture only: the others keep the torch RNG stream they were committed with
+        gen_labels()
+        sys.exit(0)
     gen_masks()
     gen_modules()
     gen_encoders()
     gen_ctc()
     gen_joint()
     gen_train()
-    gen_greedy()          # last: the generators above keep the torch RNG stream they were committed with
+    gen_greedy()          # the generators above keep the torch RNG stream they were committed with
+    gen_labels()          # numpy seeds only

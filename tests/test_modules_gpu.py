@@ -736,6 +736,31 @@ def test_streaming_batch_per_stream_offsets(pkg, mode, graph):
     assert worst < TOL[mode] * 2.0, worst
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_streaming_batch_outlives_the_positional_table(pkg, graph):
+    """A stream that runs past max_len encoder frames (cfm_stream_prep clamped to the last table row, silently; the reference's
+    pe[offset:offset+size] fails there): the table is extended on demand with the same formula, so an encoder built with max_len = 24 streams
+    exactly like one built with max_len = 5000 -- bit for bit, before and after the growth, with staggered streams."""
+    _, meta = load_golden("enc_cfg1_stream")
+    pkg.cfm.set_precision("bf16")
+    small = build_encoder(pkg, dict(meta["cfg"], max_len=24), meta["wseed"])
+    big = build_encoder(pkg, meta["cfg"], meta["wseed"])
+    B, chunk, left, steps = 3, 4, 2, 16                                # 64 encoder frames per stream: the 24-row table grows twice
+    hop, window = 4 * chunk, (chunk - 1) * 4 + 7
+    feats = dev(synth.fbank(97, B, window + hop * steps))
+    sa, sb_ = pkg.encoder.StreamingBatch(small, B, chunk, left, graph=graph), pkg.encoder.StreamingBatch(big, B, chunk, left, graph=graph)
+    with torch.no_grad():
+        for s in range(steps):
+            if s == 9:
+                sa.reset([1]), sb_.reset([1])                          # stream 1 starts over: its rows come from the table's head again
+            w = feats[:, s * hop: s * hop + window].contiguous()
+            ya, yb = sa.step(w).clone(), sb_.step(w).clone()
+            assert torch.equal(ya, yb), "step %d differs after the table grew to %d rows" % (s, sa.pe.size(0))
+    assert sa.pe.size(0) >= 64 and sb_.pe.size(0) == 5000
+    assert torch.equal(sa.pe[:24], sb_.pe[:24]) and float((sa.pe[:64] - sb_.pe[:64]).abs().max()) <= 1e-6
+    assert sa.offsets.tolist() == [64, 28, 64]
+
+
 @pytest.mark.parametrize("mode,split", [("bf16", True), ("bf16", False), ("fp32", True)])
 def test_config5_64_streams_against_oracle(pkg, mode, split, monkeypatch):
     """BASELINE config 5 at its real size: 64 streams x chunk 16 (67-frame windows) x 4 cached chunks on the 12-layer d=256 model, one

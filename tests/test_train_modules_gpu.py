@@ -20,14 +20,22 @@ pytestmark = pytest.mark.gpu
 MODES = ["bf16", "fp16", "fp32"]
 DEV = "cuda"
 # module-level gates: (forward output, gradients)
-MOD_TOL = {"fp32": (5e-5, 1e-3), "fp16": (1e-3, 3e-3), "bf16": (8e-3, 2.5e-2)}
+# measured (round 3): fp32 7.1e-6 / 1.3e-5, fp16 5.2e-4 / 1.4e-3, bf16 3.5e-3 / 1.1e-2 -- gates at ~2x
+MOD_TOL = {"fp32": (2e-5, 5e-5), "fp16": (1e-3, 3e-3), "bf16": (7e-3, 2.2e-2)}
 # whole encoder + CTC: (loss relative, output, gradients)
-ENC_TOL = {"fp32": (1e-5, 5e-5, 1e-3), "fp16": (1e-4, 2e-3, 8e-3), "bf16": (1e-3, 1.5e-2, 4.5e-2)}
+# measured (round 3): fp32 2.0e-7 / 1.7e-5 / 6.6e-5, fp16 2.2e-5 / 1.2e-3 / 4.2e-3, bf16 7.4e-5 / 9.5e-3 / 3.0e-2
+ENC_TOL = {"fp32": (2e-6, 4e-5, 2e-4), "fp16": (5e-5, 2e-3, 8e-3), "bf16": (2e-4, 1.5e-2, 4.5e-2)}
 # The two front-end convolutions sit behind ReLUs on a few thousand positions.  A forward difference of one rounding error flips isolated
 # ReLU mask bits, and each flipped bit moves an entry of a convolution's weight gradient by one full term of a ~sqrt(positions)-sized sum:
 # the max-norm error of those tensors is a property of the fixture's size (T = 83..200 frames), not of the kernels (fp32 mode reproduces
 # them to 1e-5 when no bit flips).  They get their own max-norm gate.
-FRONT_TOL = {"fp32": 1.2e-2, "fp16": 9e-2, "bf16": 1.25e-1}
+# Measured on MI355X (round 3, every reference-pinned fixture): fp32 7.4e-6 .. 5.4e-5, fp16 2.8e-2 .. 6.0e-2, bf16 7.2e-2 .. 7.9e-2.
+FRONT_TOL = {"fp32": 2e-4, "fp16": 9e-2, "bf16": 1.25e-1}
+# The config-4-shape case (d = 512: conv2 sums 4608 products per output, against the ORACLE, not a reference fixture) is the one where an
+# fp32-mode rounding difference does flip a ReLU bit: measured 7.3e-3 max-norm at rel-L2 7.3e-4.  It keeps its own gate -- and the claim "it is
+# the flips, not the kernels" is TESTED by the same case with a margin around the ReLU thresholds (`margin=True`: no pre-activation within
+# 0.25 of zero), which must meet FRONT_TOL like every other case.
+FRONT_TOL_CFG4_FLIPS = {"fp32": 1.2e-2, "bf16": 8e-2}
 # Gradients that are ZERO in exact arithmetic: keys' bias and the batch path's positional parameters (constant along a softmax row), the
 # depthwise bias (removed by BatchNorm's batch mean).  The reference holds rounding noise there (1e-8 .. 1e-5 of the largest gradient), the
 # 16-bit modes somewhat more; they are checked against a 100x higher floor, i.e. as "stays negligible", not digit by digit.
@@ -211,10 +219,29 @@ def test_training_step_is_deterministic_and_accumulates(pkg):
         assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-3 * gmax), k
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_config4_shape_gradients_against_oracle(pkg, mode):
+def relu_margin_(enc, x, want=0.25):
+    """Rewrite the front-end's convolution parameters so that NO ReLU pre-activation of this input lies within `want` of zero: small taps, biases
+    alternating +-b per channel (half the channels always on, half always off -- the backward's ReLU gating is exercised, not bypassed).
+    Returns the measured margin (plain torch CPU convolutions)."""
+    import torch.nn.functional as F
+    with torch.no_grad():
+        c0, c2 = enc.embed.conv[0], enc.embed.conv[2]
+        sign = torch.tensor([1.0, -1.0]).repeat(c0.bias.numel() // 2)
+        c0.weight.mul_(0.25 / float(c0.weight.abs().sum((1, 2, 3)).max()) / max(1.0, float(np.abs(x).max())))   # |w * x| <= 0.25
+        c0.bias.copy_(1.0 * sign)
+        z1 = F.conv2d(torch.from_numpy(x).unsqueeze(1), c0.weight, c0.bias, stride=2)
+        a1 = torch.relu(z1)
+        c2.weight.mul_(0.5 / float(c2.weight.abs().sum((1, 2, 3)).max()) / max(1.0, float(a1.max())))           # |w * a1| <= 0.5
+        c2.bias.copy_(1.0 * sign)
+        z2 = F.conv2d(a1, c2.weight, c2.bias, stride=2)
+    return min(float(z1.abs().min()), float(z2.abs().min()))
+
+
+@pytest.mark.parametrize("mode,margin", [("fp32", False), ("bf16", False), ("fp32", True), ("bf16", True)])
+def test_config4_shape_gradients_against_oracle(pkg, mode, margin):
     """d = 512, h = 8, ff = 2048 (BASELINE config 4's encoder shape), 2 layers, ragged batch: gradients against the CPU oracle under
-    torch.autograd (the goldens stop at d = 256)."""
+    torch.autograd (the goldens stop at d = 256).  margin: the front-end's parameters leave >= 0.25 around every ReLU threshold, so no
+    rounding difference can flip a mask bit -- the front-end convolutions' gradients must then meet the ordinary gate."""
     from oracle import conformer_oracle as O
     from test_oracle_golden import encoder_shapes
     cfg = dict(input_dim=80, kernel_size=15, encoder_dim=512, dropout=0.0, attention_dropout=0.0, pos_enc_dropout=0.0, hidden_dim=2048, num_heads=8,
@@ -225,6 +252,9 @@ def test_config4_shape_gradients_against_oracle(pkg, mode):
     enc = synth.load_synth_(pkg.encoder.ConformerEncoder(cmvn=None, **cfg), 71)
     dec = synth.load_synth_(pkg.decoder.CTCDecoder(V, 512, 0.0), 72)
     x = synth.fbank(73, B, T)
+    if margin:
+        got = relu_margin_(enc, x)
+        assert got >= 0.25, got
     rs = np.random.RandomState(74)
     labels = rs.randint(1, V, size=(B, Umax))
     label_lens = np.array([6, 4, 3])
@@ -256,10 +286,10 @@ def test_config4_shape_gradients_against_oracle(pkg, mode):
             worst_front = max(worst_front, e)
         else:
             worst = max(worst, e)
-    print("  [%s] config-4 shape: loss %.5f vs %.5f, worst gradient %.3e (%s), front-end convs %.3e (%s), worst rel-L2 %.3e (%s)" % (
-        mode, float(loss), float(loss_o), worst[0], worst[1], worst_front[0], worst_front[1], worst_l2[0], worst_l2[1]))
+    print("  [%s] config-4 shape%s: loss %.5f vs %.5f, worst gradient %.3e (%s), front-end convs %.3e (%s), worst rel-L2 %.3e (%s)" % (
+        mode, " (ReLU margin)" if margin else "", float(loss), float(loss_o), worst[0], worst[1], worst_front[0], worst_front[1], worst_l2[0], worst_l2[1]))
     assert worst[0] < tg, worst
-    assert worst_front[0] < FRONT_TOL[mode], worst_front
+    assert worst_front[0] < (FRONT_TOL if margin else FRONT_TOL_CFG4_FLIPS)[mode], worst_front
     assert worst_l2[0] < tg, worst_l2                                   # isolated mask flips do not move the L2 error
 
 

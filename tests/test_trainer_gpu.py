@@ -98,7 +98,7 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
                     assert float((bufs[k] - bufs_r[k]).abs().max()) < 1e-6, k
         print("  trainer step vs plain autograd + clip_grad_norm_ + torch Adam: worst |difference| / |update| = %.3e (%s)" % worst)
         # torch keeps the Adam moments of ITS trajectory, the trainer of its own: identical by construction here (same gradients every step)
-        assert worst[0] < 2e-3, worst
+        assert worst[0] < 3e-4, worst                               # measured 1.5e-4 (round 2 and round 3 boxes)
     finally:
         if use_pg:
             dist.destroy_process_group()
