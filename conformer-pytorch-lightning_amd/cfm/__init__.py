@@ -45,7 +45,7 @@ class GemmTnDesc(ctypes.Structure):
                 ("a_dtype", c_i32), ("b_dtype", c_i32), ("mma_dtype", c_i32), ("split", c_i32), ("accumulate", c_i32), ("splits", c_i32),
                 ("alpha", ctypes.c_float),
                 ("conv_C", c_i32), ("conv_T1", c_i32), ("conv_F1", c_i32), ("conv_T2", c_i32), ("conv_F2", c_i32),
-                ("row_off", c_p), ("colsum_off", c_p), ("tile", c_i32)]
+                ("row_off", c_p), ("colsum_off", c_p), ("tile", c_i32), ("colsum_off2", c_p)]
 
 
 class AttnBwdDesc(ctypes.Structure):
@@ -226,6 +226,7 @@ def lib():
         L.cfm_joint_act.argtypes = [c_p, c_i64, c_p, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         c_f = ctypes.c_float
         L.cfm_gemm_tn.argtypes = [ctypes.POINTER(GemmTnDesc), c_p]
+        L.cfm_gemm_tn_group.argtypes = [ctypes.POINTER(GemmTnDesc), c_i32, c_p]
         L.cfm_attention_bwd.argtypes = [ctypes.POINTER(AttnBwdDesc), c_p]
         L.cfm_layernorm_bwd_ws.argtypes = [c_i64, c_i32]
         L.cfm_layernorm_bwd.argtypes = [c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i64, c_i32, c_p]
@@ -261,7 +262,7 @@ def lib():
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma", "cfm_conv12_relu", "cfm_conv12_supported",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
-                     "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_attention_bwd",
+                     "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_gemm_tn_group", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
                      "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_greedy_step", "cfm_ffn_split", "cfm_ffn_split_supported", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
                      "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):

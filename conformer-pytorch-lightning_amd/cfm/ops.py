@@ -8,7 +8,7 @@ import torch
 
 import cfm as _c
 
-__all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
+__all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "gemm_tn_group", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
            "ctc_nll_train", "ctc_grad", "ffn_split", "adam_step", "sumsq", "scratch_stats",
            "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "conv12_relu", "conv12_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
@@ -510,6 +510,28 @@ def gemm_tn(a, b, out=None, want_colsum=False, row_mask=None, alpha=1.0, conv=No
     d.split, d.accumulate, d.splits, d.alpha = 1 if split else 0, 1 if accumulate else 0, (1 if _deterministic[0] else splits), alpha
     _c.check(_c.lib().cfm_gemm_tn(ctypes.byref(d), _c.stream()), "cfm_gemm_tn")
     return out, colsum
+
+
+def gemm_tn_group(products, mma_code=_c.BF16, splits=0):
+    """Several weight-gradient products in ONE launch (include/cfm.h cfm_gemm_tn_group).  products: list of dicts with keys a [M,N], b [M,K],
+    out f32 [N,K] (zero-filled or holding a running sum: the products ACCUMULATE), optional colsum f32 [N], alpha, row_off / colsum_off /
+    colsum_off2 (int64 device tables; `out` / `colsum` are then the slab the offsets are relative to).  Returns nothing."""
+    n = len(products)
+    descs = (_c.GemmTnDesc * n)()
+    for d, pr in zip(descs, products):
+        a, b, out = _rows2d(pr["a"], "gemm_tn_group(a)"), _rows2d(pr["b"], "gemm_tn_group(b)"), pr["out"]
+        colsum = pr.get("colsum")
+        _c.require_hip(a, b, out, colsum)
+        if a.shape[0] != b.shape[0] or out.dtype != torch.float32 or (colsum is not None and colsum.dtype != torch.float32):
+            raise ValueError("cfm.gemm_tn_group: a %s, b %s, out %s" % (tuple(a.shape), tuple(b.shape), out.dtype))
+        d.A, d.B, d.C, d.colsum = a.data_ptr(), b.data_ptr(), out.data_ptr(), _c.ptr(colsum)
+        d.lda, d.ldb = a.stride(0), b.stride(0)
+        d.M, d.N, d.K = a.shape[0], a.shape[1], b.shape[1]
+        d.ldc = pr.get("ldc", d.K)
+        d.a_dtype, d.b_dtype, d.mma_dtype = _c.dt_code(a), _c.dt_code(b), mma_code
+        d.accumulate, d.splits, d.alpha = 1, (1 if _deterministic[0] else splits), float(pr.get("alpha", 1.0))
+        d.row_off, d.colsum_off, d.colsum_off2 = _c.ptr(pr.get("row_off")), _c.ptr(pr.get("colsum_off")), _c.ptr(pr.get("colsum_off2"))
+    _c.check(_c.lib().cfm_gemm_tn_group(descs, n, _c.stream()), "cfm_gemm_tn_group")
 
 
 def layernorm_bwd(x, dy, gamma, row_mask=None, dres=None, dx=None, eps=1e-5):

@@ -39,6 +39,7 @@ struct TnArgs {
     int chunks_per_split, atomic;   // atomic: 1 = f32 atomic adds, 0 = plain store, 2 = plain read-add-store (accumulate with ONE workgroup per tile)
     const int64_t* row_off;
     const int64_t* colsum_off;
+    const int64_t* colsum_off2;     // optional second destination of column sum n (< 0: none): pos_bias_u shares linear_q.bias' gradient
 };
 
 // LDS row stride in 16-bit elements: TILE + 16 -> 288 B = 72 words = 8 (mod 64) for TILE 128, 160 B = 40 words for TILE 64: the 4 rows of a
@@ -237,7 +238,10 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
 #pragma unroll
         for (int i = 0; i < FR; ++i) {
             const int n = n0 + wr * (TILE / 2) + i * 16 + l15;
-            if (n < g.N) unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n] : (int64_t)n), acs[i].x * g.alpha);
+            if (n < g.N) {
+                unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n] : (int64_t)n), acs[i].x * g.alpha);
+                if (g.colsum_off2 && g.colsum_off2[n] >= 0) unsafeAtomicAdd(g.colsum + g.colsum_off2[n], acs[i].x * g.alpha);
+            }
         }
     }
 }
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void cfm_gemm_tn_kernel(const TnArgs g) {
 __device__ __attribute__((aligned(16))) unsigned cfm_tn_zero16[4] = {0u, 0u, 0u, 0u};
 
 template <typename HT, bool CONV, int TILE, int NG>
-__global__ __launch_bounds__(256 * NG, 1) void cfm_gemm_tn_dma_kernel(const TnArgs g) {
+__device__ __forceinline__ void tn_dma_body(const TnArgs& g, const int block_x, const int block_y) {
     // Measured (scripts/bench_gemm_tn_splits.py, M = 2 380): ONE 64 x 64 workgroup walks its rows at ~0.6 us per 64-row chunk whatever is in
     // flight (8 buffers instead of 4: 27 us instead of 24 for 2 380 rows) -- with one wavefront per SIMD the chunk's own chain of address
     // arithmetic, barrier, 16 transposed reads and 8 dependent MFMAs is exposed; every split added costs ~1.5-5 us of atomics; the
@@ -281,9 +285,9 @@ __global__ __launch_bounds__(256 * NG, 1) void cfm_gemm_tn_dma_kernel(const TnAr
     const int g4 = lane >> 4, l15 = lane & 15;
     const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
     const int tiles_k = (g.K + TILE - 1) / TILE;
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
+    const int tile_n = block_x / tiles_k, tile_k = block_x % tiles_k;
     const int n0 = tile_n * TILE, k0 = tile_k * TILE;
-    const int chunk_begin = blockIdx.y * g.chunks_per_split;
+    const int chunk_begin = block_y * g.chunks_per_split;
     const int total_chunks = (g.M + MCH - 1) / MCH;
     int chunk_end = chunk_begin + g.chunks_per_split;
     chunk_end = chunk_end < total_chunks ? chunk_end : total_chunks;
@@ -442,9 +446,43 @@ __global__ __launch_bounds__(256 * NG, 1) void cfm_gemm_tn_dma_kernel(const TnAr
 #pragma unroll
         for (int i = 0; i < FR; ++i) {
             const int n = n0 + wr * (TILE / 2) + i * 16 + l15;
-            if (n < g.N) unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n] : (int64_t)n), acs[i].x * g.alpha);
+            if (n < g.N) {
+                unsafeAtomicAdd(g.colsum + (g.colsum_off ? g.colsum_off[n] : (int64_t)n), acs[i].x * g.alpha);
+                if (g.colsum_off2 && g.colsum_off2[n] >= 0) unsafeAtomicAdd(g.colsum + g.colsum_off2[n], acs[i].x * g.alpha);
+            }
         }
     }
+}
+
+template <typename HT, bool CONV, int TILE, int NG>
+__global__ __launch_bounds__(256 * NG, 1) void cfm_gemm_tn_dma_kernel(const TnArgs g) {
+    tn_dma_body<HT, CONV, TILE, NG>(g, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Several products in ONE launch (cfm_gemm_tn_group): the eight weight gradients of a conformer block -- 2 x (2048 x 256, 256 x 2048),
+// 768 x 256, 512 x 256, 2 x 256 x 256 -- are each too small to fill 256 CUs (16 .. 128 tiles of 64 x 64) and were 8 launches of 10-17 us per
+// block and micro-batch.  They do not feed the chain of input gradients, so the block's backward defers them to its end and issues them as
+// one grid: workgroup b belongs to the product p with first[p] <= b < first[p+1], tile (b - first[p]) % tiles[p], M-split (b - first[p]) /
+// tiles[p].  The products are ordered by rows per workgroup, longest first, so the tail of the grid is made of the short ones.
+constexpr int TN_GROUP_MAX = 12;
+struct TnGroupArgs {
+    TnArgs p[TN_GROUP_MAX];
+    int first[TN_GROUP_MAX + 1];
+    int tiles[TN_GROUP_MAX];
+    int n;
+};
+
+template <typename HT, int TILE, int NG>
+__global__ __launch_bounds__(256 * NG, 1) void cfm_gemm_tn_group_kernel(const TnGroupArgs G) {
+    const int b = (int)blockIdx.x;
+    int idx = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP_MAX; ++i)
+        if (i < G.n && b >= G.first[i]) idx = i;           // uniform: b is the workgroup id
+    const int rel = b - G.first[idx];
+    const int tiles = G.tiles[idx];
+    tn_dma_body<HT, false, TILE, NG>(G.p[idx], rel % tiles, rel / tiles);
 }
 
 template <typename HT>
@@ -477,9 +515,15 @@ int launch_tn(const TnArgs& a, bool conv, int tile, int splits, hipStream_t s, c
     return cfm_launch_status(name);
 }
 
-}  // namespace
+// Argument checks, tile / split choice and the kernel arguments of one product.  group_tiles > 0: the product is part of a grouped launch with
+// that many output tiles in total (the split rule then looks at the group, not at the product alone).
+struct TnPlan {
+    TnArgs a;
+    int tile, splits, tiles;
+    bool dma, conv, a32, b32;
+};
 
-extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
+int plan_tn(const cfm_gemm_tn_desc* d, TnPlan& pl, int group_tiles) {
     CFM_CHECK_ARG(d && d->A && d->B && d->C, "cfm_gemm_tn: null pointer");
     CFM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "cfm_gemm_tn: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
     CFM_CHECK_ARG(d->N % 8 == 0 && d->K % 8 == 0, "cfm_gemm_tn: N=%d and K=%d must be multiples of 8", d->N, d->K);
@@ -499,14 +543,13 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     } else {
         CFM_CHECK_ARG(d->ldb % (d->b_dtype == CFM_F32 ? 4 : 8) == 0 && d->ldb >= d->K, "cfm_gemm_tn: bad ldb=%lld", (long long)d->ldb);
     }
-    hipStream_t s = (hipStream_t)stream;
     const int mch128 = d->split ? 32 : 64;                  // chunk rows of the 128-wide tile; the 64-wide tile stages twice as many per barrier
     const int chunks128 = (d->M + mch128 - 1) / mch128;
     // 64 x 64 tiles while the output is small (fewer than 128 tiles of 128 x 128: every weight of the d = 256 / 512 blocks), 128 x 128 for
     // the big ones (the CTC head's 5008 x 256, the front-end convolutions): then about one workgroup per CU
     const int t128 = ((d->N + 127) / 128) * ((d->K + 127) / 128);
     CFM_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128, "cfm_gemm_tn: tile must be 0 (auto), 64 or 128");
-    const int tile = d->tile ? d->tile : ((t128 >= 128 || chunks128 >= 128) ? 128 : 64);     // M >= 8 k rows: enough splits of >= 4 chunks even with few big tiles
+    const int tile = group_tiles > 0 ? 64 : (d->tile ? d->tile : ((t128 >= 128 || chunks128 >= 128) ? 128 : 64));   // M >= 8 k rows: enough splits of >= 4 chunks even with few big tiles
     const bool a32 = d->a_dtype == CFM_F32, b32 = d->b_dtype == CFM_F32;
     // 16-bit operands without a row mask: the LDS-DMA kernel (64-row chunks, several in flight)
     const bool dma = !a32 && !b32 && !d->split && !d->row_mask;
@@ -515,7 +558,10 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     const int tiles = ((d->N + tile - 1) / tile) * ((d->K + tile - 1) / tile);
     int splits = d->splits;
     if (splits <= 0) {
-        if (dma) {
+        if (group_tiles > 0) {
+            // a grouped launch fills the chip with its tiles; M is split only while the whole group has fewer workgroups than ~2 per CU
+            splits = (512 + group_tiles / 2) / group_tiles;
+        } else if (dma) {
             // measured optimum at M = 2 380 / 1 300 rows (profiles/r02_gemm_tn_splits.txt): 4 splits for 16 tiles, 3 for 32, 2-3 for 48, 1-2 for 128;
             // a split's cost (atomics) is fixed and its gain shrinks with the rows it removes, so the optimum grows like sqrt(M)
             splits = (int)(16.0 / sqrt((double)tiles) * sqrt((double)d->M / 2400.0) + 0.5);
@@ -526,22 +572,40 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
         splits = splits > max_s ? max_s : splits;
     }
     splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
-    TnArgs a;
+    TnArgs& a = pl.a;
     a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum; a.mask = d->row_mask; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.M = d->M; a.N = d->N; a.K = d->K; a.alpha = d->alpha;
     a.convC = d->conv_C; a.T1 = d->conv_T1; a.F1 = d->conv_F1; a.T2 = d->conv_T2; a.F2 = d->conv_F2;
-    CFM_CHECK_ARG((!d->row_off && !d->colsum_off) || d->accumulate, "cfm_gemm_tn: row_off / colsum_off need accumulate = 1 (zero-filled by the caller)");
-    a.row_off = d->row_off; a.colsum_off = d->colsum_off;
+    CFM_CHECK_ARG((!d->row_off && !d->colsum_off && !d->colsum_off2) || d->accumulate, "cfm_gemm_tn: row_off / colsum_off need accumulate = 1 (zero-filled by the caller)");
+    CFM_CHECK_ARG(!d->colsum_off2 || d->colsum, "cfm_gemm_tn: colsum_off2 needs colsum");
+    a.row_off = d->row_off; a.colsum_off = d->colsum_off; a.colsum_off2 = d->colsum_off2;
     a.chunks_per_split = (chunks + splits - 1) / splits;
     splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;   // no empty split
     a.atomic = splits > 1 ? 1 : (d->accumulate ? 2 : 0);
-    if (!d->accumulate) {
-        if (a.atomic && hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->K * 4, (size_t)d->N, s) != hipSuccess)
-            return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of C failed");
-        if (d->colsum && hipMemsetAsync(d->colsum, 0, (size_t)d->N * 4, s) != hipSuccess)
-            return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of colsum failed");
-    }
-    if (dma) return d->mma_dtype == CFM_BF16 ? launch_tn_dma<BF16>(a, conv, tile, splits, s, "gemm_tn_dma_bf16") : launch_tn_dma<F16>(a, conv, tile, splits, s, "gemm_tn_dma_f16");
+    pl.tile = tile; pl.splits = splits; pl.tiles = tiles; pl.dma = dma; pl.conv = conv; pl.a32 = a32; pl.b32 = b32;
+    return CFM_OK;
+}
+
+int zero_fill_tn(const cfm_gemm_tn_desc* d, const TnPlan& pl, hipStream_t s) {
+    if (d->accumulate) return CFM_OK;
+    if (pl.a.atomic && hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->K * 4, (size_t)d->N, s) != hipSuccess)
+        return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of C failed");
+    if (d->colsum && hipMemsetAsync(d->colsum, 0, (size_t)d->N * 4, s) != hipSuccess)
+        return cfm_fail(CFM_ERR_LAUNCH, "cfm_gemm_tn: memset of colsum failed");
+    return CFM_OK;
+}
+
+}  // namespace
+
+extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
+    TnPlan pl;
+    if (int rc = plan_tn(d, pl, 0)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = zero_fill_tn(d, pl, s)) return rc;
+    const TnArgs& a = pl.a;
+    const bool conv = pl.conv, a32 = pl.a32, b32 = pl.b32;
+    const int tile = pl.tile, splits = pl.splits;
+    if (pl.dma) return d->mma_dtype == CFM_BF16 ? launch_tn_dma<BF16>(a, conv, tile, splits, s, "gemm_tn_dma_bf16") : launch_tn_dma<F16>(a, conv, tile, splits, s, "gemm_tn_dma_f16");
     if (d->split) return launch_tn<BF16, true, true, true>(a, conv, tile, splits, s, "gemm_tn_bf16x3");
 #define CFM_TN(HT, NAME)                                                                              \
     do {                                                                                              \
@@ -553,4 +617,56 @@ extern "C" int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream) {
     if (d->mma_dtype == CFM_BF16) CFM_TN(BF16, "gemm_tn_bf16");
     CFM_TN(F16, "gemm_tn_f16");
 #undef CFM_TN
+}
+
+// n products in one launch when every one of them can take the LDS-DMA 64 x 64 kernel (16-bit operands of one type, no row mask, no f32-accurate
+// split, no implicit convolution) and n <= TN_GROUP_MAX; otherwise one launch each, in order -- same results either way (the M splits may
+// differ: atomics then sum in another order).
+extern "C" int cfm_gemm_tn_group(const cfm_gemm_tn_desc* descs, int32_t n, cfm_stream_t stream) {
+    CFM_CHECK_ARG(descs && n > 0, "cfm_gemm_tn_group: no products");
+    hipStream_t s = (hipStream_t)stream;
+    bool groupable = n >= 2 && n <= TN_GROUP_MAX;
+    int group_tiles = 0;
+    for (int i = 0; i < n && groupable; ++i) {
+        const cfm_gemm_tn_desc& d = descs[i];
+        groupable = d.a_dtype != CFM_F32 && d.b_dtype != CFM_F32 && d.a_dtype == descs[0].a_dtype && d.b_dtype == d.a_dtype && d.mma_dtype == d.a_dtype &&
+                    !d.split && !d.row_mask && d.conv_C == 0 && (d.tile == 0 || d.tile == 64);
+        group_tiles += ((d.N + 63) / 64) * ((d.K + 63) / 64);
+    }
+    if (!groupable) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = cfm_gemm_tn(&descs[i], stream)) return rc;
+        return CFM_OK;
+    }
+    TnPlan pl[TN_GROUP_MAX];
+    int order[TN_GROUP_MAX];
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = plan_tn(&descs[i], pl[i], group_tiles)) return rc;
+        if (int rc = zero_fill_tn(&descs[i], pl[i], s)) return rc;
+        order[i] = i;
+        flops += 2.0 * descs[i].M * (double)descs[i].N * descs[i].K;
+        bytes += (double)descs[i].M * (descs[i].N + descs[i].K) * 2 + 4.0 * descs[i].N * descs[i].K;
+    }
+    for (int i = 1; i < n; ++i)                             // longest workgroups first (insertion sort, stable)
+        for (int j = i; j > 0 && pl[order[j]].a.chunks_per_split > pl[order[j - 1]].a.chunks_per_split; --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+    TnGroupArgs G;
+    G.n = n;
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+        const TnPlan& p = pl[order[i]];
+        G.p[i] = p.a;
+        G.first[i] = first;
+        G.tiles[i] = p.tiles;
+        first += p.tiles * p.splits;
+    }
+    for (int i = n; i < TN_GROUP_MAX; ++i) { G.p[i] = G.p[0]; G.first[i] = first; G.tiles[i] = 1; }
+    G.first[TN_GROUP_MAX] = first;
+    const bool bf = descs[0].mma_dtype == CFM_BF16;
+    CfmProfScope prof(bf ? "gemm_tn_group_bf16" : "gemm_tn_group_f16", s, flops, bytes);
+    if (bf) CFM_LAUNCH((cfm_gemm_tn_group_kernel<BF16, 64, 2>), dim3((unsigned)first), dim3(512), 0, s, G);
+    else CFM_LAUNCH((cfm_gemm_tn_group_kernel<F16, 64, 2>), dim3((unsigned)first), dim3(512), 0, s, G);
+    return cfm_launch_status("cfm_gemm_tn_group");
 }

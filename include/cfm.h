@@ -150,9 +150,17 @@ typedef struct {
     const int64_t* row_off;
     const int64_t* colsum_off;
     int32_t tile; /* 0 = chosen by the library; 64 or 128: output tile edge (experiments, scripts/bench_gemm_tn_splits.py) */
+    /* optional SECOND destination of column sum n: colsum[colsum_off2[n]] (entries < 0: none).  pos_bias_u's gradient is linear_q.bias'
+     * gradient (attention.py:81: (q + u) . k^T), so the fused q|k|v product writes both.  int64 [N], device; needs accumulate = 1. */
+    const int64_t* colsum_off2;
 } cfm_gemm_tn_desc;
 
 int cfm_gemm_tn(const cfm_gemm_tn_desc* d, cfm_stream_t stream);
+/* n products in ONE launch (the weight gradients of a conformer block: feedforward.py:17-20 x 2, attention.py:62-64,99, convolution.py:41,46
+ * under autograd): each is too small to fill the chip and none feeds the chain of input gradients, so a block's backward defers them to
+ * its end.  Grouped when all are 16-bit products of one type without row mask / f32 split / implicit convolution and n <= 12; otherwise
+ * one launch each, in order.  Same results as n calls of cfm_gemm_tn up to the order of the atomic sums. */
+int cfm_gemm_tn_group(const cfm_gemm_tn_desc* descs, int32_t n, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused feed-forward block (one launch; the [M,FF] hidden activation never reaches memory):

@@ -89,6 +89,69 @@ def test_gemm_tn_conv(cfm, B, T1, F1, C, split):
     assert relerr(out, ref) < (3e-5 if split else 1e-4)
 
 
+@pytest.mark.parametrize("wdt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [2380, 4130, 257])
+def test_gemm_tn_group_equals_single_products(cfm, M, wdt):
+    """cfm_gemm_tn_group: the eight weight gradients of a d = 256 / ff = 2048 block in ONE launch, every product against the f64 product of
+    the rounded operands and against cfm_gemm_tn on the same operands; the scatter tables (row_off / colsum_off / colsum_off2) as the fused
+    q|k|v product uses them; accumulation into a running sum; one split = bitwise reproducible."""
+    dt = W_DT[wdt]
+    D, FF = 256, 2048
+    shapes = [(D, FF), (FF, D), (D, D), (2 * D, D), (D, D), (3 * D, D), (D, FF), (FF, D)]      # (N, K) in a block's backward order
+    prods, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        a, b = rnd((M, N), 100 + i).to(dt), rnd((M, K), 200 + i).to(dt)
+        alpha = 0.5 if i in (0, 6) else 1.0
+        prods.append(dict(a=a, b=b, out=torch.zeros((N, K), device="cuda"), colsum=torch.zeros((N,), device="cuda"), alpha=alpha))
+        refs.append((alpha * a.double().t() @ b.double(), alpha * a.double().sum(0)))
+    cfm.gemm_tn_group(prods, mma_code=cfm.dt_code(dt))
+    for pr, (rw, rb) in zip(prods, refs):
+        assert relerr(pr["out"], rw) < 1e-4 and relerr(pr["colsum"], rb) < 1e-4
+        single, cs = cfm.gemm_tn(pr["a"], pr["b"], want_colsum=True, alpha=pr["alpha"], mma_code=cfm.dt_code(dt))
+        assert relerr(pr["out"], single) < 2e-6 and relerr(pr["colsum"], cs) < 2e-6
+    # a second call ACCUMULATES
+    cfm.gemm_tn_group(prods, mma_code=cfm.dt_code(dt))
+    for pr, (rw, rb) in zip(prods, refs):
+        assert relerr(pr["out"], 2 * rw) < 1e-4 and relerr(pr["colsum"], 2 * rb) < 1e-4
+    # splits = 1: no atomics on the products, two runs agree bit for bit
+    runs = []
+    for _ in range(2):
+        ps = [dict(pr, out=torch.zeros_like(pr["out"]), colsum=None) for pr in prods]
+        cfm.gemm_tn_group(ps, mma_code=cfm.dt_code(dt), splits=1)
+        runs.append(ps)
+    assert all(torch.equal(x["out"], y["out"]) for x, y in zip(*runs))
+    # scatter tables: rows of a fused 3D x D product land where three separate parameters live in a flat slab, the column sums too, and the
+    # first D column sums a second time (pos_bias_u = linear_q.bias' gradient)
+    a, b = prods[5]["a"], prods[5]["b"]
+    slab = torch.zeros((3 * D * D + 3 * D + D + 64,), device="cuda")
+    ar = torch.arange(D, device="cuda")
+    w_off, b_off, u_off = (2 * D * D + 16, 16, D * D + 16), (3 * D * D + 32 + D, 3 * D * D + 16, 3 * D * D + 48 + 2 * D), 3 * D * D + 48 + 3 * D
+    row_off = torch.cat([w_off[j] + ar * D for j in range(3)])
+    cs_off = torch.cat([b_off[j] + ar for j in range(3)])
+    cs_off2 = torch.cat([u_off + ar, torch.full((2 * D,), -1, device="cuda", dtype=torch.int64)])
+    extra = dict(a=prods[2]["a"], b=prods[2]["b"], out=torch.zeros((D, D), device="cuda"), colsum=torch.zeros((D,), device="cuda"))
+    cfm.gemm_tn_group([dict(a=a, b=b, out=slab, colsum=slab, row_off=row_off, colsum_off=cs_off, colsum_off2=cs_off2), extra], mma_code=cfm.dt_code(dt))
+    rw, rb = refs[5]
+    for j in range(3):
+        assert relerr(slab[w_off[j]:w_off[j] + D * D].view(D, D), rw[j * D:(j + 1) * D]) < 1e-4
+        assert relerr(slab[b_off[j]:b_off[j] + D], rb[j * D:(j + 1) * D]) < 1e-4
+    assert relerr(slab[u_off:u_off + D], rb[:D]) < 1e-4
+    assert relerr(extra["out"], refs[2][0]) < 1e-4
+
+
+def test_gemm_tn_group_falls_back_for_f32_operands(cfm):
+    """operands the grouped kernel does not take (f32 rows: the f32-accurate mode) run as single launches behind the same entry point."""
+    M = 700
+    prods, refs = [], []
+    for i, (N, K) in enumerate([(144, 576), (576, 144)]):
+        a, b = rnd((M, N), 300 + i), rnd((M, K), 310 + i)
+        prods.append(dict(a=a, b=b, out=torch.zeros((N, K), device="cuda"), colsum=torch.zeros((N,), device="cuda")))
+        refs.append(a.bfloat16().double().t() @ b.bfloat16().double())
+    cfm.gemm_tn_group(prods)
+    for pr, r in zip(prods, refs):
+        assert relerr(pr["out"], r) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------------------ GEMM training epilogues
 @pytest.mark.parametrize("M,N,K", [(500, 576, 144), (1992, 2048, 256)])
 @pytest.mark.parametrize("wdt", ["bf16", "fp16"])
