@@ -100,7 +100,13 @@ def build_train_job(device, rank, precision, n_micro=8):
         y, m = enc(x, lens)
         return dec(y, m.squeeze(1).sum(1), labels, label_lens)
 
-    tr = T.DataParallelTrainer([enc, dec], loss_fn, lr=1e-3, warmup_steps=25000, accum_grad=2, grad_clip=4.0, bucket_mb=25.0)
+    def window_loss_fn(window):
+        # the accumulation window in one pass: rows of both micro-batches through the block stack together (ConformerEncoder.forward_window)
+        outs = enc.forward_window([(mb[0], mb[1]) for mb in window])
+        return [dec(y, m.squeeze(1).sum(1), mb[2], mb[3]) for (y, m), mb in zip(outs, window)]
+
+    tr = T.DataParallelTrainer([enc, dec], loss_fn, lr=1e-3, warmup_steps=25000, accum_grad=2, grad_clip=4.0, bucket_mb=25.0,
+                               window_loss_fn=window_loss_fn if os.environ.get("CFM_TRAIN_WINDOW", "1") != "0" else None)
     return enc, dec, tr, mbs, frames
 
 

@@ -108,18 +108,26 @@ class LayerTrainWeights(ctypes.Structure):
     _fields_ = [(n, c_p) for n in _TRAIN_W_PTRS] + [("bn_momentum", ctypes.c_float), ("bn_eps", ctypes.c_float)]
 
 
+class TrainGroup(ctypes.Structure):
+    _fields_ = [("B", c_i32), ("T", c_i32), ("row0", c_i64), ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64)]
+
+
+LAYER_DONE_FN = ctypes.CFUNCTYPE(None, c_i32, c_p)
+
+
 class LayerTrainIO(ctypes.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("FF", c_i32), ("ktaps", c_i32), ("act_dtype", c_i32), ("w_dtype", c_i32),
                 ("attn_mask", c_p), ("am_sb", c_i64), ("am_sq", c_i64), ("pad_valid", c_p),
                 ("p_hidden_m", ctypes.c_float), ("p_hidden", ctypes.c_float), ("p_branch", ctypes.c_float), ("p_attn", ctypes.c_float),
-                ("p_attn_out", ctypes.c_float), ("seed", ctypes.c_uint32), ("deterministic", c_i32), ("grads_accumulate", c_i32), ("side_stream", c_p)]
+                ("p_attn_out", ctypes.c_float), ("seed", ctypes.c_uint32), ("deterministic", c_i32), ("grads_accumulate", c_i32), ("side_stream", c_p),
+                ("n_groups", c_i32), ("groups", ctypes.POINTER(TrainGroup)), ("defer_wgrad", c_i32)]
 
 
 _TRAIN_SAVED = ["xn1", "z1", "h1", "xn2", "qkv", "ctx", "xn3", "u", "glu", "s", "xn4", "z2", "h2", "x1", "x2", "x3", "x4", "c", "lse", "stats"]
 _TRAIN_SCRATCH = ["dxn", "dz", "dyb", "ds", "dglu", "du", "dctx", "dqkv", "delta", "ln_ws", "dwbn_ws", "dy_ws", "dz2", "dyb2", "dyb3", "dyb4"]
 _TRAIN_GRADS = ["slab", "ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "ln_conv_b", "ln_ff_g", "ln_ff_b", "ln_final_g", "ln_final_b",
                 "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "ff_w1", "ff_b1", "ff_w2", "ff_b2", "out_w", "out_b", "pw2_w", "pw2_b", "dw_w", "dw_b", "bn_g", "bn_b",
-                "pos_bias_u", "q_bias", "qkv_row_off", "qkv_bias_off", "pw1_row_off", "pw1_bias_off"]
+                "pos_bias_u", "q_bias", "qkv_row_off", "qkv_bias_off", "pw1_row_off", "pw1_bias_off", "qkv_bias_off2"]
 
 
 class LayerTrainSaved(ctypes.Structure):
@@ -247,6 +255,11 @@ def lib():
                                                       ctypes.POINTER(LayerTrainScratch), c_p, c_p, c_p]
         L.cfm_encoder_layer_train_backward.argtypes = [ctypes.POINTER(LayerTrainWeights), ctypes.POINTER(LayerTrainIO), ctypes.POINTER(LayerTrainSaved),
                                                        ctypes.POINTER(LayerTrainScratch), ctypes.POINTER(LayerTrainGrads), c_p, c_p, c_p, c_p]
+        L.cfm_encoder_train_forward.argtypes = [c_i32, ctypes.POINTER(LayerTrainWeights), ctypes.POINTER(LayerTrainIO), ctypes.POINTER(LayerTrainSaved),
+                                                ctypes.POINTER(LayerTrainScratch), ctypes.POINTER(c_p), c_p]
+        L.cfm_encoder_train_backward.argtypes = [c_i32, ctypes.POINTER(LayerTrainWeights), ctypes.POINTER(LayerTrainIO), ctypes.POINTER(LayerTrainSaved),
+                                                 ctypes.POINTER(LayerTrainScratch), c_i32, ctypes.POINTER(LayerTrainGrads), ctypes.POINTER(c_p), c_p, c_p, c_p,
+                                                 LAYER_DONE_FN, c_p, ctypes.POINTER(c_p), c_p]
         L.cfm_stream_prep.argtypes = [c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]
         L.cfm_kv_ring_write.argtypes = [c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_stream_advance.argtypes = [c_p, c_p, c_i32, c_i32, c_p]
@@ -265,7 +278,7 @@ def lib():
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_gemm_tn_group", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
                      "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_greedy_step", "cfm_ffn_split", "cfm_ffn_split_supported", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
-                     "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
+                     "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_encoder_train_forward", "cfm_encoder_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib

@@ -437,6 +437,7 @@ def _build_train_weights_struct(layer, pks):
 DIRECT_GRADS = os.environ.get("CFM_DIRECT_GRADS", "0") != "0"     # flat-leaf blocks add their gradients straight into the trainer's gradient buffer: measured
 # SLOWER at config 3 (17.8 vs 17.1 ms per step: the atomics / read-add-stores then hit a cold 139 MB buffer instead of a just-zeroed slab in cache) -- opt-in
 USE_PACK_KERNEL = os.environ.get("CFM_PACK_KERNEL", "1") != "0"   # one cfm_pack_matrices launch per block and step instead of ~25 torch ops
+WGRAD_BESIDE = os.environ.get("CFM_WGRAD_BESIDE", "0") != "0"     # stack path: each block's grouped weight-gradient launch on a side stream
 OVERLAP_WGRAD = os.environ.get("CFM_OVERLAP_WGRAD", "0") != "0"   # measured at config 3: 21.3 ms per step with, 19.7 ms without
 _SIDE = {}
 
@@ -614,6 +615,198 @@ class EncoderLayerFn(torch.autograd.Function):
         put("feed_forward_macaron.", g, "norm_ff_macaron", lng)
         names, tensors = _params(layer)
         return (d.view(B, T, D), None, None, None, None, None) + tuple(_ordered(names, grads, tensors))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the whole block STACK over an accumulation WINDOW (round 3): one host call each way (csrc/train_layer.cpp cfm_encoder_train_forward /
+# _backward), the micro-batches of the window concatenated along the row axis (cfm.h cfm_train_group), each block's weight gradients as ONE
+# grouped launch at the end of its backward, gradients written straight into the data-parallel trainer's flat buffer.
+# ----------------------------------------------------------------------------------------------------------------------
+_SAVED_ACT = ("xn1", "z1", "h1", "xn2", "qkv", "ctx", "xn3", "u", "glu", "s", "xn4", "z2", "h2")
+
+
+def stack_supported(layers, flat):
+    """The stack path needs every block on the composite train path with the same sizes and dropout rates (it shares one io struct)."""
+    l0 = layers[0]
+    bn0 = l0.conv_module.norm
+    key = lambda l: (l.encoder_dim, l.hidden_dim, l.num_heads, l.kernel_size, l.use_relative, l.dropout.p, l.self_attn.dropout.p,
+                     l.feed_forward_macaron.dropout.p, l.feed_forward.dropout.p)
+    return (USE_COMPOSITE and all(_composite_ok(l, None, flat) and key(l) == key(l0) and l.conv_module.norm.momentum is not None and
+                                  l.conv_module.norm.track_running_stats == bn0.track_running_stats for l in layers))
+
+
+def _stack_weights(owner, layers, prec):
+    """ctypes array of the blocks' weight structs (cached while the packs stay the same objects)."""
+    rel = layers[0].use_relative
+    pks = tuple(packing.pack_layer_train(l, prec, rel) for l in layers)
+    hit = owner.__dict__.get("_stack_w")
+    if hit is not None and len(hit[0]) == len(pks) and all(a is b for a, b in zip(hit[0], pks)):
+        return hit[1], pks
+    arr = (cfm.LayerTrainWeights * len(layers))()
+    for i, (l, pk) in enumerate(zip(layers, pks)):
+        arr[i] = _train_weights_struct(l, pk)
+    owner.__dict__["_stack_w"] = (pks, arr)
+    return arr, pks
+
+
+def _stack_grads(owner, layers, bases, lays, tag):
+    """ctypes array of the blocks' gradient destinations: block i's slab starts at address bases[i]; cached per destination."""
+    key = (tag, tuple(bases))
+    hit = owner.__dict__.get("_stack_g")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    arr = (cfm.LayerTrainGrads * len(layers))()
+    for g, base, lay in zip(arr, bases, lays):
+        g.slab = base
+        for name, field in _GRAD_FIELDS.items():
+            if name in lay["layout"]:
+                setattr(g, field, base + 4 * lay["layout"][name][0])
+        g.q_bias = base + 4 * lay["layout"]["self_attn.linear_q.bias"][0]
+        g.qkv_row_off, g.qkv_bias_off, g.pw1_row_off, g.pw1_bias_off = (lay[k].data_ptr() for k in ("qkv_row", "qkv_bias", "pw1_row", "pw1_bias"))
+        if "qkv_bias2" in lay:
+            g.qkv_bias_off2 = lay["qkv_bias2"].data_ptr()
+    owner.__dict__["_stack_g"] = (key, arr)
+    return arr
+
+
+class EncoderStackFn(torch.autograd.Function):
+    """All conformer blocks of the encoder in train mode over one accumulation window (encoder.py:72-73 under module.train())."""
+
+    @staticmethod
+    def forward(ctx, x, owner, layers, prec, groups, keep, flat, *params):
+        """x f32 [M,D]: the window's rows, micro-batch after micro-batch; groups: [(B, T, mask8 | None, (m_sb, m_sq))]; keep u8 [M] | None."""
+        dev, adt = x.device, prec.act_dtype
+        L, G = len(layers), len(groups)
+        l0 = layers[0]
+        D, FF, H = l0.encoder_dim, l0.hidden_dim, l0.num_heads
+        M = sum(B * T for B, T, _, _ in groups)
+        BHT = sum(B * H * T for B, T, _, _ in groups)
+        if tuple(x.shape) != (M, D) or x.dtype != torch.float32 or not x.is_contiguous():
+            raise RuntimeError("EncoderStackFn: rows must be contiguous float32 (%d,%d), got %s %s" % (M, D, tuple(x.shape), x.dtype))
+        if G > 8:
+            raise RuntimeError("EncoderStackFn: at most 8 micro-batches per window")
+        w_arr, pks = _stack_weights(owner, layers, prec)
+        esz = 4 if adt == torch.float32 else 2
+        widths = dict(xn1=D, z1=FF, h1=FF, xn2=D, qkv=3 * D, ctx=D, xn3=D, u=2 * D, glu=D, s=D, xn4=D, z2=FF, h2=FF)
+        per_act = M * sum(widths.values())
+        per_f32 = 5 * M * D + BHT + G * 4 * D
+        act = torch.empty((L * per_act,), dtype=adt, device=dev)
+        f32 = torch.empty((L * per_f32 + L * M * D,), dtype=torch.float32, device=dev)
+        sv = (cfm.LayerTrainSaved * L)()
+        xs = (ctypes.c_void_p * (L + 1))()
+        xs[0] = x.data_ptr()
+        pa, pf = act.data_ptr(), f32.data_ptr()
+        for l in range(L):
+            o = pa + l * per_act * esz
+            for name in _SAVED_ACT:
+                setattr(sv[l], name, o)
+                o += M * widths[name] * esz
+            o = pf + l * per_f32 * 4
+            for name, n in (("x1", M * D), ("x2", M * D), ("x3", M * D), ("x4", M * D), ("c", M * D), ("lse", BHT), ("stats", G * 4 * D)):
+                setattr(sv[l], name, o)
+                o += n * 4
+            xs[l + 1] = pf + (L * per_f32 + l * M * D) * 4
+        garr = (cfm.TrainGroup * G)()
+        row0 = 0
+        for g, (B, T, m8, m_str) in zip(garr, groups):
+            g.B, g.T, g.row0, g.attn_mask, g.am_sb, g.am_sq = B, T, row0, cfm.ptr(m8), m_str[0], m_str[1]
+            row0 += B * T
+        io = cfm.LayerTrainIO()
+        io.D, io.H, io.FF, io.ktaps, io.act_dtype, io.w_dtype = D, H, FF, l0.kernel_size, prec.act_code, prec.w_code
+        io.pad_valid = cfm.ptr(keep)
+        p_br, p_a = l0.dropout.p, l0.self_attn.dropout.p
+        io.p_hidden_m, io.p_hidden, io.p_branch, io.p_attn = l0.feed_forward_macaron.dropout.p, l0.feed_forward.dropout.p, p_br, p_a
+        io.p_attn_out = 0.0 if l0.use_relative else p_a
+        io.seed = draw_seed() if max(io.p_hidden_m, io.p_hidden, p_br, p_a) > 0 else 0
+        io.deterministic = 1 if cfm.ops._deterministic[0] else 0
+        io.n_groups, io.groups, io.defer_wgrad = G, garr, 1
+        ws = sum(cfm.lib().cfm_dwconv_bn_ws(B, T, D) for B, T, _, _ in groups)
+        sc = cfm.LayerTrainScratch()
+        sc.dwbn_ws = cfm.scratch("dwbn", ws, torch.float32, dev).data_ptr()
+        cfm.check(cfm.lib().cfm_encoder_train_forward(L, w_arr, ctypes.byref(io), sv, ctypes.byref(sc), xs, cfm.stream()), "cfm_encoder_train_forward")
+        if l0.conv_module.norm.track_running_stats:
+            torch._foreach_add_([l.conv_module.norm.num_batches_tracked for l in layers], G)
+        ctx.st = (owner, layers, prec, groups, keep, flat, w_arr, pks, io, garr, sv, xs, (act, f32, x), M, BHT, ws)
+        return f32[L * per_f32 + (L - 1) * M * D:].view(M, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        owner, layers, prec, groups, keep, flat, w_arr, pks, io, garr, sv, xs, held, M, BHT, ws = ctx.st
+        dev, adt = dy.device, prec.act_dtype
+        L = len(layers)
+        l0 = layers[0]
+        D, FF = l0.encoder_dim, l0.hidden_dim
+        det = cfm.ops._deterministic[0]
+        # where the gradients go: the trainer's flat gradient buffer itself (each block registered with a sink: trainer.py) -- nothing is
+        # returned to autograd for the leaves, the trainer's ready hook is called from the per-block callback -- or one zero-filled slab per
+        # block (plain autograd / deterministic sums), returned as the leaves' / parameters' gradients
+        sinks = [l.__dict__.get("_flat_grad_sink") for l in layers] if (flat and not det) else None
+        if sinks is not None and any(s is None or s[0].device != dev for s in sinks):
+            sinks = None
+        lays = [layer_grad_layout(l, l.__dict__.get("_flat_grad_offsets") if flat else None) for l in layers]
+        for lay, l in zip(lays, layers):
+            if "qkv_bias2" not in lay and "self_attn.pos_bias_u" in lay["layout"]:
+                u0 = lay["layout"]["self_attn.pos_bias_u"][0]
+                lay["qkv_bias2"] = torch.cat([u0 + torch.arange(D, dtype=torch.int64), torch.full((2 * D,), -1, dtype=torch.int64)]).to(dev)
+        if sinks is not None:
+            slabs = None
+            g_arr = _stack_grads(owner, layers, [s[0].data_ptr() for s in sinks], lays, "sink")
+            io.grads_accumulate = 1
+        else:
+            sizes = [(l.__dict__["_flat_leaf"].numel() if flat else lay["numel"]) for l, lay in zip(layers, lays)]
+            slab_all = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
+            slabs, o = [], 0
+            for n in sizes:
+                slabs.append(slab_all[o:o + n])
+                o += n
+            g_arr = _stack_grads(owner, layers, [s.data_ptr() for s in slabs], lays, "slab")
+            io.grads_accumulate = 0
+        # the grouped weight-gradient launch of each block on a side stream, beside the next block's chain (two scratch sets: its operands
+        # must outlive the block); measured at config 3 -- see WGRAD_BESIDE
+        beside = WGRAD_BESIDE and adt != torch.float32
+        io.side_stream = _side_stream(dev).cuda_stream if beside else None
+        n_sc = 2 if beside else 1
+        scs = (cfm.LayerTrainScratch * n_sc)()
+        for si, sc in enumerate(scs):
+            tag = "t%d_" % si
+            sc.dxn = cfm.scratch("t_dxn", M * D, torch.float32, dev).data_ptr()
+            for name, wd in (("dz", FF), ("dz2", FF), ("dyb", D), ("dyb2", D), ("dyb3", D), ("dyb4", D), ("du", 2 * D), ("dqkv", 3 * D)):
+                setattr(sc, name, cfm.scratch(tag + name, M * wd, adt, dev).data_ptr())         # operands of the deferred products: per set
+            for name, wd in (("ds", D), ("dglu", D), ("dctx", D)):
+                setattr(sc, name, cfm.scratch("t_" + name, M * wd, adt, dev).data_ptr())
+            sc.delta = cfm.scratch("attn_delta", BHT, torch.float32, dev).data_ptr()
+            sc.ln_ws = cfm.scratch("ln_bwd", cfm.lib().cfm_layernorm_bwd_ws(M, D), torch.float32, dev).data_ptr()
+            sc.dwbn_ws = cfm.scratch("dwbn", ws, torch.float32, dev).data_ptr()
+            sc.dy_ws = cfm.scratch("dwbn_dy", M * D, torch.float32, dev).data_ptr()
+        dyc = _f32c(dy.reshape(M, D))
+        bufs = torch.empty((2, M, D), dtype=torch.float32, device=dev)
+        failed = []
+
+        def done(layer, _user):
+            if sinks is not None:
+                try:
+                    sinks[layer][1]()                                   # the trainer's ready hook: this block's bucket may be all-reduced
+                except BaseException as e:                              # noqa: BLE001 -- ctypes would swallow it: re-raised below
+                    failed.append(e)
+
+        cb = cfm.LAYER_DONE_FN(done)
+        out = ctypes.c_void_p()
+        cfm.check(cfm.lib().cfm_encoder_train_backward(L, w_arr, ctypes.byref(io), sv, scs, n_sc, g_arr, xs, dyc.data_ptr(), bufs[0].data_ptr(),
+                                                       bufs[1].data_ptr(), cb, None, ctypes.byref(out), cfm.stream()), "cfm_encoder_train_backward")
+        if failed:
+            raise failed[0]
+        dx = bufs[0] if out.value == bufs[0].data_ptr() else bufs[1]
+        head = (dx, None, None, None, None, None, None)
+        if sinks is not None:
+            return head + (None,) * L
+        if flat:
+            return head + tuple(slabs)
+        grads = []
+        for l, slab, lay in zip(layers, slabs, lays):
+            for name, p in l.named_parameters():
+                off, n = lay["layout"][name]
+                grads.append(slab[off:off + n].view(p.shape) if p.requires_grad else None)
+        return head + tuple(grads)
 
 
 class CTCLossFn(torch.autograd.Function):

@@ -268,7 +268,7 @@ __device__ __forceinline__ u32x4 load_row8(const void* base, unsigned off) {
 }
 
 template <typename HT, int PMODE, bool MFULL, bool KVF32>
-__global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {   // 2 wavefronts per SIMD: two workgroups share a CU
+__device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block_x) {
     __shared__ u32x4 Kl[SK * 8];
     __shared__ u32x4 Pl[PMODE == 2 ? SK * 8 : 1];
     __shared__ __attribute__((aligned(16))) u16 Vl[SK * V2STR];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
     // ids 8 apart: they then share an L2 and K/V are fetched from memory once instead of once per q-tile (measured 41 MB of HBM
     // traffic per launch for 16 MB of compulsory bytes).  Groups of 8 pairs; padding blocks of the last group exit.
     const int nq = (a.Tq + QT - 1) / QT;
-    const int grp = blockIdx.x / (8 * nq), rem = blockIdx.x % (8 * nq);
+    const int grp = block_x / (8 * nq), rem = block_x % (8 * nq);
     const int pair = grp * 8 + rem % 8;
     if (pair >= a.B * a.H) return;                         // uniform, before any barrier
     const int b = pair / a.H, h = pair % a.H;
@@ -501,6 +501,31 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
     CFM_ASTAMP(7);
 }
 
+template <typename HT, int PMODE, bool MFULL, bool KVF32>
+__global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {   // 2 wavefronts per SIMD: two workgroups share a CU
+    attn2_body<HT, PMODE, MFULL, KVF32>(a, (int)blockIdx.x);
+}
+
+// Several attention problems in ONE launch (cfm_attention_group): the micro-batches of a training window have different lengths T_g, so each
+// is its own (B_g, H, T_g) problem with its own mask and strides -- but none of them fills the chip (8 x 4 x 4 tiles at a micro-batch of 8
+// utterances), and as separate launches they ran one after the other.  Workgroup b belongs to the problem with first[i] <= b < first[i+1].
+constexpr int ATTN_GROUP_MAX = 8;
+struct AttnGroupArgs {
+    AttnArgs a[ATTN_GROUP_MAX];
+    int first[ATTN_GROUP_MAX + 1];
+    int n;
+};
+
+template <typename HT, bool MFULL>
+__global__ __launch_bounds__(256, 2) void cfm_attn2_group_kernel(const AttnGroupArgs G) {
+    const int b = (int)blockIdx.x;
+    int idx = 0;
+#pragma unroll
+    for (int i = 1; i < ATTN_GROUP_MAX; ++i)
+        if (i < G.n && b >= G.first[i]) idx = i;            // uniform
+    attn2_body<HT, 0, MFULL, false>(G.a[idx], b - G.first[idx]);
+}
+
 template <typename HT>
 int launch_attn2(const AttnArgs& a, hipStream_t s, const char* name) {
     const int nq = (a.Tq + QT - 1) / QT, pairs = a.B * a.H;
@@ -564,7 +589,7 @@ int launch_attn(const AttnArgs& a, bool has_pos, hipStream_t s, const char* name
 
 }  // namespace
 
-extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
+static int attn_args(const cfm_attn_desc* d, AttnArgs& a, bool& fast) {
     CFM_CHECK_ARG(d && d->q && d->k && d->v && d->out, "cfm_attention: null pointer");
     CFM_CHECK_ARG(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "cfm_attention: empty problem");
     CFM_CHECK_ARG(d->dk > 0 && d->dk <= DKP && d->dk % 4 == 0, "cfm_attention: need dk %% 4 == 0 and dk <= 64 (dk=%d)", d->dk);
@@ -572,7 +597,6 @@ extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d->mma_dtype == CFM_BF16 || d->mma_dtype == CFM_F16, "cfm_attention: mma_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(!d->split || d->mma_dtype == CFM_BF16, "cfm_attention: split mode uses bf16 planes");
     CFM_CHECK_ARG(!d->p || (d->bias_u && d->bias_v), "cfm_attention: positional term needs bias_u and bias_v");
-    AttnArgs a;
     a.q = d->q; a.k = d->k; a.v = d->v; a.p = d->p; a.bias_u = d->p ? d->bias_u : nullptr; a.bias_v = d->p ? d->bias_v : nullptr;
     a.mask = d->mask; a.out = d->out;
     a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.k_sh = d->k_sh;
@@ -582,21 +606,71 @@ extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "cfm_attention: dropout probability must be in [0, 1)");
     CFM_CHECK_ARG(d->drop_p == 0.f || (int64_t)d->B * d->H * d->Tq * d->Tk < ((int64_t)1 << 32), "cfm_attention: dropout needs fewer than 2^32 score elements");
     a.drop = cfm_make_drop(d->drop_p, d->drop_seed);
-    hipStream_t s = (hipStream_t)stream;
     const bool pos = d->p != nullptr;
     // v2 fast path: d_k = 64, 16-bit q (and p) of the MFMA type, K/V either that type or f32 (streaming cache), 16-byte
     // aligned rows; everything else (f32-accurate split mode, d_k = 36 ...) runs the general v1 kernel.
     const bool al8 = (d->q_sb % 8 == 0) && (d->q_st % 8 == 0) && (d->k_sb % 4 == 0) && (d->k_st % 8 == 0) && (d->k_sh % 8 == 0) &&
                      (d->v_sb % 4 == 0) && (d->v_st % 8 == 0) && (d->v_sh % 8 == 0) && (!pos || ((d->p_sb % 8 == 0) && (d->p_st % 8 == 0)));
-    if (!d->split && d->dk == 64 && d->q_dtype == d->mma_dtype && (!pos || d->p_dtype == d->mma_dtype) &&
-        (d->kv_dtype == d->mma_dtype || d->kv_dtype == CFM_F32) && al8 && !getenv("CFM_ATTN_V1") &&
-        (int64_t)d->Tk * d->k_st < ((int64_t)1 << 31) && (int64_t)d->Tk * d->v_st < ((int64_t)1 << 31) && (int64_t)d->Tk * d->p_st < ((int64_t)1 << 31)) {
+    fast = !d->split && d->dk == 64 && d->q_dtype == d->mma_dtype && (!pos || d->p_dtype == d->mma_dtype) &&
+           (d->kv_dtype == d->mma_dtype || d->kv_dtype == CFM_F32) && al8 && !getenv("CFM_ATTN_V1") &&
+           (int64_t)d->Tk * d->k_st < ((int64_t)1 << 31) && (int64_t)d->Tk * d->v_st < ((int64_t)1 << 31) && (int64_t)d->Tk * d->p_st < ((int64_t)1 << 31);
+    return CFM_OK;
+}
+
+extern "C" int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream) {
+    AttnArgs a;
+    bool fast = false;
+    if (int rc = attn_args(d, a, fast)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool pos = d->p != nullptr;
+    if (fast) {
         if (d->mma_dtype == CFM_BF16) return launch_attn2<BF16>(a, s, pos ? "attn2_rel_bf16" : "attn2_bf16");
         return launch_attn2<F16>(a, s, pos ? "attn2_rel_f16" : "attn2_f16");
     }
     if (d->split) return launch_attn<BF16, true>(a, pos, s, pos ? "attn_rel_bf16x3" : "attn_bf16x3");
     if (d->mma_dtype == CFM_BF16) return launch_attn<BF16, false>(a, pos, s, pos ? "attn_rel_bf16" : "attn_bf16");
     return launch_attn<F16, false>(a, pos, s, pos ? "attn_rel_f16" : "attn_f16");
+}
+
+// n attention problems (the micro-batches of a training window: different B, T, mask) in one launch when every one takes the d_k = 64 fast
+// path without a positional term, with 16-bit K/V and the same kind of mask; otherwise one launch each, in order.  Same results either way.
+extern "C" int cfm_attention_group(const cfm_attn_desc* descs, int32_t n, cfm_stream_t stream) {
+    CFM_CHECK_ARG(descs && n > 0, "cfm_attention_group: no problems");
+    hipStream_t s = (hipStream_t)stream;
+    AttnGroupArgs G;
+    bool groupable = n >= 2 && n <= ATTN_GROUP_MAX;
+    bool mfull0 = false;
+    int first = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n && groupable; ++i) {
+        bool fast = false;
+        if (int rc = attn_args(&descs[i], G.a[i], fast)) return rc;
+        const AttnArgs& a = G.a[i];
+        const bool mfull = a.mask && a.m_sq != 0;
+        if (i == 0) mfull0 = mfull;
+        groupable = fast && !a.p && a.kv_dtype != CFM_F32 && mfull == mfull0 && descs[i].mma_dtype == descs[0].mma_dtype;
+        G.first[i] = first;
+        const int nq = (a.Tq + QT - 1) / QT, pairs = a.B * a.H;
+        first += ((pairs + 7) / 8) * 8 * nq;
+        flops += 4.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
+        bytes += 2.0 * a.B * a.H * ((double)a.Tq * 2 + (double)a.Tk * 2) * a.dk;
+    }
+    if (!groupable) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = cfm_attention(&descs[i], stream)) return rc;
+        return CFM_OK;
+    }
+    G.n = n;
+    for (int i = n; i <= ATTN_GROUP_MAX; ++i) G.first[i] = first;
+    for (int i = n; i < ATTN_GROUP_MAX; ++i) G.a[i] = G.a[0];
+    const bool bf = descs[0].mma_dtype == CFM_BF16;
+    CfmProfScope prof(bf ? "attn2_group_bf16" : "attn2_group_f16", s, flops, bytes);
+    const dim3 grid((unsigned)first), block(256);
+    if (bf && mfull0) CFM_LAUNCH((cfm_attn2_group_kernel<BF16, true>), grid, block, 0, s, G);
+    else if (bf) CFM_LAUNCH((cfm_attn2_group_kernel<BF16, false>), grid, block, 0, s, G);
+    else if (mfull0) CFM_LAUNCH((cfm_attn2_group_kernel<F16, true>), grid, block, 0, s, G);
+    else CFM_LAUNCH((cfm_attn2_group_kernel<F16, false>), grid, block, 0, s, G);
+    return cfm_launch_status("cfm_attention_group");
 }
 
 extern "C" int cfm_kv_cache_pack(const float* old_cache, int32_t Tc, const void* k, const void* v, int32_t kv_dtype,

@@ -340,14 +340,14 @@ __device__ __forceinline__ void tile_dot64(const u32x4* tile, const u32x4 (&fr)[
 }
 
 template <typename HT>
-__global__ __launch_bounds__(256) void cfm_attn_bwd_dq_fast_kernel(const AttnBwdArgs a) {
+__device__ __forceinline__ void attn_bwd_dq_fast_body(const AttnBwdArgs& a, const int block_x, const int block_y, const int block_z) {
     constexpr int TP = KT * 8;                           // u32x4 per tile
     __shared__ u32x4 Ks[2][TP], Vs[2][TP];
     __shared__ __attribute__((aligned(16))) uint8_t Ms[2][KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int qi = blockIdx.x * QT + wave * 16 + l15;
+    const int b = block_z, h = block_y;
+    const int qi = block_x * QT + wave * 16 + l15;
     const int qc = qi < a.Tq ? qi : a.Tq - 1;
     constexpr int dk = 64;
     const u16 *qp = (const u16*)a.q, *kp = (const u16*)a.k, *vp = (const u16*)a.v, *dop = (const u16*)a.dout;
@@ -419,15 +419,44 @@ __global__ __launch_bounds__(256) void cfm_attn_bwd_dq_fast_kernel(const AttnBwd
     }
 }
 
+// one conformer window's micro-batches in one launch (cfm_attention_bwd_group): see cfm_attn2_group_kernel in attention.hip
+constexpr int ATTN_GROUP_MAX = 8;
+struct AttnBwdGroupArgs {
+    AttnBwdArgs a[ATTN_GROUP_MAX];
+    int first[ATTN_GROUP_MAX + 1];     // first workgroup of each problem (grid of this launch)
+    int gx[ATTN_GROUP_MAX];            // its grid x extent (query or key tiles); y = H, z = B
+    int n;
+};
+
+__device__ __forceinline__ int attn_group_pick(const AttnBwdGroupArgs& G, int b) {
+    int idx = 0;
+#pragma unroll
+    for (int i = 1; i < ATTN_GROUP_MAX; ++i)
+        if (i < G.n && b >= G.first[i]) idx = i;          // uniform
+    return idx;
+}
+
 template <typename HT>
-__global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_fast_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dq_fast_kernel(const AttnBwdArgs a) {
+    attn_bwd_dq_fast_body<HT>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dq_group_kernel(const AttnBwdGroupArgs G) {
+    const int idx = attn_group_pick(G, (int)blockIdx.x);
+    const int rel = (int)blockIdx.x - G.first[idx], gx = G.gx[idx], H = G.a[idx].H;
+    attn_bwd_dq_fast_body<HT>(G.a[idx], rel % gx, (rel / gx) % H, rel / (gx * H));
+}
+
+template <typename HT>
+__device__ __forceinline__ void attn_bwd_dkv_fast_body(const AttnBwdArgs& a, const int block_x, const int block_y, const int block_z) {
     constexpr int TP = QT * 8;
     __shared__ u32x4 Qs[2][TP], Os[2][TP];
     __shared__ __attribute__((aligned(16))) float Ls[2][QT], Ds[2][QT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int kj = blockIdx.x * KT + wave * 16 + l15;
+    const int b = block_z, h = block_y;
+    const int kj = block_x * KT + wave * 16 + l15;
     const int kc = kj < a.Tk ? kj : a.Tk - 1;
     constexpr int dk = 64;
     const u16 *qp = (const u16*)a.q, *kp = (const u16*)a.k, *vp = (const u16*)a.v, *dop = (const u16*)a.dout;
@@ -514,12 +543,24 @@ __global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_fast_kernel(const AttnBw
     }
 }
 
+template <typename HT>
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_fast_kernel(const AttnBwdArgs a) {
+    attn_bwd_dkv_fast_body<HT>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_group_kernel(const AttnBwdGroupArgs G) {
+    const int idx = attn_group_pick(G, (int)blockIdx.x);
+    const int rel = (int)blockIdx.x - G.first[idx], gx = G.gx[idx], H = G.a[idx].H;
+    attn_bwd_dkv_fast_body<HT>(G.a[idx], rel % gx, (rel / gx) % H, rel / (gx * H));
+}
+
 // delta_i = dO_i . O_i for d_k = 64 16-bit rows: the row's sixteen 16-byte pieces requested together (the general kernel's loads sit behind
 // run-time dtype branches and go out one latency after the other)
 template <typename HT>
-__global__ void cfm_attn_delta_fast_kernel(const AttnBwdArgs a) {
+__device__ __forceinline__ void attn_delta_fast_body(const AttnBwdArgs& a, const int block_x) {
     const int64_t n = (int64_t)a.B * a.H * a.Tq;
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t id = (int64_t)block_x * blockDim.x + threadIdx.x;
     if (id >= n) return;
     const int i = (int)(id % a.Tq);
     const int h = (int)((id / a.Tq) % a.H);
@@ -544,19 +585,78 @@ __global__ void cfm_attn_delta_fast_kernel(const AttnBwdArgs a) {
     a.delta[id] = s;
 }
 
+template <typename HT>
+__global__ void cfm_attn_delta_fast_kernel(const AttnBwdArgs a) {
+    attn_delta_fast_body<HT>(a, (int)blockIdx.x);
+}
+
+template <typename HT>
+__global__ void cfm_attn_delta_group_kernel(const AttnBwdGroupArgs G) {
+    const int idx = attn_group_pick(G, (int)blockIdx.x);
+    attn_delta_fast_body<HT>(G.a[idx], (int)blockIdx.x - G.first[idx]);
+}
+
 static bool g_attn_bwd_general_only = false;      // tests: force the general kernels
+
+template <typename HT>
+bool bwd_fast_ok(const AttnBwdArgs& a) {
+    const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    return !g_attn_bwd_general_only && a.dk == 64 && a.io_dt == HT::kId && a.do_dt == HT::kId && (!a.mask || a.m_sq == 0) && a.q_st % 8 == 0 &&
+           a.k_st % 8 == 0 && a.v_st % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.dout) &&
+           al16(a.out);
+}
+
+// three launches for n problems: delta, dq, dkv -- each over all problems (callers have checked bwd_fast_ok for every one)
+template <typename HT>
+int launch_bwd_group(AttnBwdGroupArgs& G, hipStream_t s, const char* n_dq, const char* n_dkv) {
+    double fl = 0.0, by = 0.0, bd = 0.0;
+    int first = 0;
+    for (int i = 0; i < G.n; ++i) {
+        const AttnBwdArgs& a = G.a[i];
+        fl += 2.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
+        by += (double)a.B * a.H * (a.Tq + a.Tk) * a.dk * cfm_elt_size(a.io_dt) * 3;
+        bd += 2.0 * a.B * a.Tq * a.H * a.dk * cfm_elt_size(a.io_dt);
+        G.first[i] = first;
+        first += (int)(((int64_t)a.B * a.H * a.Tq + 255) / 256);
+    }
+    for (int i = G.n; i <= ATTN_GROUP_MAX; ++i) G.first[i] = first;
+    {
+        CfmProfScope prof("attn_bwd_delta_group", s, 0.0, bd);
+        CFM_LAUNCH((cfm_attn_delta_group_kernel<HT>), dim3((unsigned)first), dim3(256), 0, s, G);
+        if (int rc = cfm_launch_status("cfm_attention_bwd_group (delta)")) return rc;
+    }
+    first = 0;
+    for (int i = 0; i < G.n; ++i) {
+        const AttnBwdArgs& a = G.a[i];
+        G.first[i] = first;
+        G.gx[i] = (a.Tq + QT - 1) / QT;
+        first += G.gx[i] * a.H * a.B;
+    }
+    for (int i = G.n; i <= ATTN_GROUP_MAX; ++i) G.first[i] = first;
+    {
+        CfmProfScope prof(n_dq, s, 3.0 * fl, by);
+        CFM_LAUNCH((cfm_attn_bwd_dq_group_kernel<HT>), dim3((unsigned)first), dim3(256), 0, s, G);
+        if (int rc = cfm_launch_status("cfm_attention_bwd_group (dq)")) return rc;
+    }
+    first = 0;
+    for (int i = 0; i < G.n; ++i) {
+        const AttnBwdArgs& a = G.a[i];
+        G.first[i] = first;
+        G.gx[i] = (a.Tk + KT - 1) / KT;
+        first += G.gx[i] * a.H * a.B;
+    }
+    for (int i = G.n; i <= ATTN_GROUP_MAX; ++i) G.first[i] = first;
+    CfmProfScope prof(n_dkv, s, 4.0 * fl, by);
+    CFM_LAUNCH((cfm_attn_bwd_dkv_group_kernel<HT>), dim3((unsigned)first), dim3(256), 0, s, G);
+    return cfm_launch_status("cfm_attention_bwd_group (dkv)");
+}
 
 template <typename HT, bool SPLIT>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char* n_dkv) {
     const double fl = 2.0 * a.B * a.H * (double)a.Tq * a.Tk * a.dk;
     const double by = (double)a.B * a.H * (a.Tq + a.Tk) * a.dk * cfm_elt_size(a.io_dt) * 3;
     bool fast = false;
-    if constexpr (!SPLIT) {
-        const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-        fast = !g_attn_bwd_general_only && a.dk == 64 && a.io_dt == HT::kId && a.do_dt == HT::kId && (!a.mask || a.m_sq == 0) && a.q_st % 8 == 0 &&
-               a.k_st % 8 == 0 && a.v_st % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.dout) &&
-               al16(a.out);
-    }
+    if constexpr (!SPLIT) fast = bwd_fast_ok<HT>(a);
     {
         CfmProfScope prof("attn_bwd_delta", s, 0.0, 2.0 * a.B * a.Tq * a.H * a.dk * cfm_elt_size(a.io_dt));
         const int64_t n = (int64_t)a.B * a.H * a.Tq;
@@ -594,7 +694,7 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char
 
 extern "C" void cfm_attention_bwd_force_general(int32_t on) { g_attn_bwd_general_only = on != 0; }
 
-extern "C" int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream) {
+static int attn_bwd_args(const cfm_attn_bwd_desc* d, AttnBwdArgs& a) {
     CFM_CHECK_ARG(d && d->q && d->k && d->v && d->out && d->dout && d->lse && d->grad_q && d->grad_k && d->grad_v && d->delta, "cfm_attention_bwd: null pointer");
     CFM_CHECK_ARG(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "cfm_attention_bwd: empty problem");
     CFM_CHECK_ARG(d->dk > 0 && d->dk <= DKP && d->dk % 4 == 0, "cfm_attention_bwd: need dk %% 4 == 0 and dk <= 64 (dk=%d)", d->dk);
@@ -602,15 +702,43 @@ extern "C" int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream
     CFM_CHECK_ARG(d->mma_dtype == CFM_BF16 || d->mma_dtype == CFM_F16, "cfm_attention_bwd: mma_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(!d->split || d->mma_dtype == CFM_BF16, "cfm_attention_bwd: split mode uses bf16 planes");
     CFM_CHECK_ARG(d->io_dtype >= CFM_F32 && d->io_dtype <= CFM_F16 && d->dout_dtype >= CFM_F32 && d->dout_dtype <= CFM_F16, "cfm_attention_bwd: bad dtype");
-    AttnBwdArgs a;
     a.q = d->q; a.k = d->k; a.v = d->v; a.out = d->out; a.dout = d->dout; a.lse = d->lse; a.mask = d->mask;
     a.dq = d->grad_q; a.dkk = d->grad_k; a.dv = d->grad_v; a.delta = d->delta;
     a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st; a.m_sb = d->m_sb; a.m_sq = d->m_sq;
     a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk; a.dk = d->dk; a.io_dt = d->io_dtype; a.do_dt = d->dout_dtype; a.scale = d->scale;
     CFM_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "cfm_attention_bwd: dropout probability must be in [0, 1)");
     a.drop = cfm_make_drop(d->drop_p, d->drop_seed);
+    return CFM_OK;
+}
+
+extern "C" int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream) {
+    AttnBwdArgs a;
+    if (int rc = attn_bwd_args(d, a)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (d->split) return launch_bwd<BF16, true>(a, s, "attn_bwd_dq_bf16x3", "attn_bwd_dkv_bf16x3");
     if (d->mma_dtype == CFM_BF16) return launch_bwd<BF16, false>(a, s, "attn_bwd_dq_bf16", "attn_bwd_dkv_bf16");
     return launch_bwd<F16, false>(a, s, "attn_bwd_dq_f16", "attn_bwd_dkv_f16");
+}
+
+// n attention backward problems (the micro-batches of a training window) in three launches instead of 3 n when every one takes the d_k = 64 /
+// 16-bit fast kernels (no (B,Tq,Tk) mask); otherwise problem after problem.  Same results either way.
+extern "C" int cfm_attention_bwd_group(const cfm_attn_bwd_desc* descs, int32_t n, cfm_stream_t stream) {
+    CFM_CHECK_ARG(descs && n > 0, "cfm_attention_bwd_group: no problems");
+    hipStream_t s = (hipStream_t)stream;
+    AttnBwdGroupArgs G;
+    bool groupable = n >= 2 && n <= ATTN_GROUP_MAX;
+    for (int i = 0; i < n && groupable; ++i) {
+        if (int rc = attn_bwd_args(&descs[i], G.a[i])) return rc;
+        groupable = !descs[i].split && descs[i].mma_dtype == descs[0].mma_dtype &&
+                    (descs[i].mma_dtype == CFM_BF16 ? bwd_fast_ok<BF16>(G.a[i]) : bwd_fast_ok<F16>(G.a[i]));
+    }
+    if (!groupable) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = cfm_attention_bwd(&descs[i], stream)) return rc;
+        return CFM_OK;
+    }
+    G.n = n;
+    for (int i = n; i < ATTN_GROUP_MAX; ++i) { G.a[i] = G.a[0]; G.gx[i] = 1; }
+    if (descs[0].mma_dtype == CFM_BF16) return launch_bwd_group<BF16>(G, s, "attn_bwd_dq_group_bf16", "attn_bwd_dkv_group_bf16");
+    return launch_bwd_group<F16>(G, s, "attn_bwd_dq_group_f16", "attn_bwd_dkv_group_f16");
 }

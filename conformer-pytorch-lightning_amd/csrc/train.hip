@@ -266,12 +266,37 @@ constexpr int DWT = 16;
 constexpr int DWK = 15;                                     // taps (the only kernel size on the path, encoder.py:38 kernel_size=15)
 constexpr int DWW = DWT + DWK - 1;
 
+// The micro-batches of a training window (cfm_train_group): every kernel of the family takes the whole table, so a window is ONE launch per
+// stage whatever the number of micro-batches -- each has its own length T, its own BatchNorm statistics (stats + gi*4*D, coef + gi*2*D)
+// and its own range of partial-sum slots; a single (B, T) problem is a table of one.
+constexpr int DW_GROUPS_MAX = 8;
+struct DwGroup {
+    int B, T, nblk_t;          // utterances, frames, 16-frame time blocks per utterance
+    int blk0;                  // first (utterance, time block) slot of the group:  sum over earlier groups of B * nblk_t   (= its first workgroup)
+    int bnb0;                  // first BNB_ROWS-row block of the group (backward sums):  sum over earlier groups of ceil(B*T / BNB_ROWS)
+    int64_t row0;              // first row of the group in the window's [M, D] row matrices
+};
+struct DwGroups {
+    DwGroup g[DW_GROUPS_MAX];
+    int n;
+};
+
+__device__ __forceinline__ int dw_pick_blk(const DwGroups& G, int wg) {
+    int idx = 0;
+#pragma unroll
+    for (int i = 1; i < DW_GROUPS_MAX; ++i)
+        if (i < G.n && wg >= G.g[i].blk0) idx = i;          // uniform
+    return idx;
+}
+
 template <int GDT>
 __global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias,
-                                                               float* __restrict__ c_out, float* __restrict__ ws, int T, int D) {
-    const int b = blockIdx.y, t0 = blockIdx.x * DWT;
-    const int nblk_t = gridDim.x;
-    const int64_t ub = (int64_t)b * T * D;
+                                                               float* __restrict__ c_out, float* __restrict__ ws, const DwGroups G, int D) {
+    const int gi = dw_pick_blk(G, (int)blockIdx.x);
+    const DwGroup& gr = G.g[gi];
+    const int rel = (int)blockIdx.x - gr.blk0, T = gr.T;
+    const int b = rel / gr.nblk_t, t0 = (rel % gr.nblk_t) * DWT;
+    const int64_t ub = (gr.row0 + (int64_t)b * T) * D;
     for (int c = threadIdx.x; c < D; c += 256) {
         float win[DWW], wk[DWK];
 #pragma unroll
@@ -299,7 +324,7 @@ __global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __res
                 m2 += dlt * (a - mean);
             }
         }
-        const int64_t blk = (int64_t)b * nblk_t + blockIdx.x;
+        const int64_t blk = blockIdx.x;                     // = blk0 + b * nblk_t + time block
         ws[(blk * 2 + 0) * D + c] = mean;
         ws[(blk * 2 + 1) * D + c] = m2;
     }
@@ -307,7 +332,9 @@ __global__ __launch_bounds__(256) void cfm_dwconv_stats_kernel(const void* __res
 
 // stats[0..3][D] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running statistics updated (torch: unbiased variance)
 // one wavefront per channel: lane l combines partials l, l+64, ... (Chan's pairwise rule, fp64), then the 64 lane results are merged by a
-// butterfly -- the serial chain is (B * nblk_t)/64 + 6 combinations instead of B * nblk_t (36 us at config 3 as one thread per channel)
+// butterfly -- the serial chain is (B * nblk_t)/64 + 6 combinations instead of B * nblk_t (36 us at config 3 as one thread per channel).
+// Micro-batch after micro-batch INSIDE the wavefront: the running statistics take the momentum updates in the order of the forward passes
+// they stand for (the reference: one forward per micro-batch).
 __device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, double nb, double mb, double qb) {
     if (nb <= 0.0) return;
     const double d = mb - mean, nn = n + nb;
@@ -322,49 +349,65 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int o) {
     hi = __shfl_xor(hi, o, 64);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
 }
-__global__ __launch_bounds__(256) void cfm_bn_finalize_kernel(const float* __restrict__ ws, int nblk_t, int B, int T, int D, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void cfm_bn_finalize_kernel(const float* __restrict__ ws, const DwGroups G, int D, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
-                                                              float* __restrict__ stats) {
+                                                              float* __restrict__ stats_all) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= D) return;                                     // wave-uniform
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    const int total = B * nblk_t;
-    for (int blk = lane; blk < total; blk += 64) {
-        const int tb = blk % nblk_t;
-        chan_merge(n, mean, m2, (double)min(DWT, T - tb * DWT), ws[((int64_t)blk * 2 + 0) * D + c], ws[((int64_t)blk * 2 + 1) * D + c]);
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double on = shfl_xor_f64(n, o), om = shfl_xor_f64(mean, o), oq = shfl_xor_f64(m2, o);
-        // merge the partner's triple; both lanes of a pair compute the same symmetric result
-        const double nn = n + on;
-        if (nn > 0.0) {
-            const double d = om - mean;
-            m2 = m2 + oq + d * d * n * on / nn;
-            mean = (n * mean + on * om) / nn;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int gi = 0; gi < G.n; ++gi) {
+        const DwGroup& gr = G.g[gi];
+        const int nblk_t = gr.nblk_t, T = gr.T;
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        const int total = gr.B * nblk_t;
+        for (int blk = lane; blk < total; blk += 64) {
+            const int tb = blk % nblk_t;
+            const int64_t slot = gr.blk0 + blk;
+            chan_merge(n, mean, m2, (double)min(DWT, T - tb * DWT), ws[(slot * 2 + 0) * D + c], ws[(slot * 2 + 1) * D + c]);
         }
-        n = nn;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double on = shfl_xor_f64(n, o), om = shfl_xor_f64(mean, o), oq = shfl_xor_f64(m2, o);
+            // merge the partner's triple; both lanes of a pair compute the same symmetric result
+            const double nn = n + on;
+            if (nn > 0.0) {
+                const double d = om - mean;
+                m2 = m2 + oq + d * d * n * on / nn;
+                mean = (n * mean + on * om) / nn;
+            }
+            n = nn;
+        }
+        if (lane == 0) {
+            float* stats = stats_all + (int64_t)gi * 4 * D;
+            const double var = m2 / n;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * rstd;
+            stats[c] = (float)mean;
+            stats[D + c] = rstd;
+            stats[2 * D + c] = sc;
+            stats[3 * D + c] = beta[c] - (float)mean * sc;
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
+        }
     }
     if (lane != 0) return;
-    {
-    }
-    const double var = m2 / n;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * rstd;
-    stats[c] = (float)mean;
-    stats[D + c] = rstd;
-    stats[2 * D + c] = sc;
-    stats[3 * D + c] = beta[c] - (float)mean * sc;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
 }
 
-__global__ void cfm_bn_silu_apply_kernel(const float* __restrict__ c, const float* __restrict__ stats, void* __restrict__ out, int out_dt, int64_t M, int D) {
+__global__ void cfm_bn_silu_apply_kernel(const float* __restrict__ c, const float* __restrict__ stats_all, void* __restrict__ out, int out_dt, int64_t M, int D,
+                                         const DwGroups G) {
     const int qpr = D / 4;
     const int64_t n = M * qpr;
     for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)(id % qpr) * 4;
+        const int64_t row = id / qpr;
+        int gi = 0;
+#pragma unroll
+        for (int i = 1; i < DW_GROUPS_MAX; ++i)
+            if (i < G.n && row >= G.g[i].row0) gi = i;
+        const float* stats = stats_all + (int64_t)gi * 4 * D;
         const f32x4 v = *(const f32x4*)(c + id * 4), sc = *(const f32x4*)(stats + 2 * D + col), sh = *(const f32x4*)(stats + 3 * D + col);
         f32x4 o;
 #pragma unroll
@@ -373,18 +416,25 @@ __global__ void cfm_bn_silu_apply_kernel(const float* __restrict__ c, const floa
     }
 }
 
-// dy = ds * silu'(c*scale + shift) -> dy_out (f32); per-workgroup sums over 64 rows of dy and dy * chat -> ws[blk][2][D]
+// dy = ds * silu'(c*scale + shift) -> dy_out (f32); per-workgroup sums over 16 rows of dy and dy * chat -> ws[blk][2][D]
 constexpr int BNB_ROWS = 16;
 template <int SDT>
-__global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __restrict__ ds, const float* __restrict__ c, const float* __restrict__ stats,
-                                                              float* __restrict__ dy_out, float* __restrict__ ws, int64_t M, int D) {
-    const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
+__global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __restrict__ ds, const float* __restrict__ c, const float* __restrict__ stats_all,
+                                                              float* __restrict__ dy_out, float* __restrict__ ws, const DwGroups G, int D) {
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < DW_GROUPS_MAX; ++i)
+        if (i < G.n && (int)blockIdx.x >= G.g[i].bnb0) gi = i;
+    const DwGroup& gr = G.g[gi];
+    const float* stats = stats_all + (int64_t)gi * 4 * D;
+    const int64_t M = gr.row0 + (int64_t)gr.B * gr.T;         // one past the group's last row
+    const int64_t r0 = gr.row0 + (int64_t)((int)blockIdx.x - gr.bnb0) * BNB_ROWS;
     for (int ch = threadIdx.x; ch < D; ch += 256) {
         const float mean = stats[ch], rstd = stats[D + ch], sc = stats[2 * D + ch], sh = stats[3 * D + ch];
         float s1 = 0.f, s2 = 0.f;
         float cv[BNB_ROWS], dv[BNB_ROWS];
 #pragma unroll
-        for (int r = 0; r < BNB_ROWS; ++r) {                 // all loads first (rows past M: clamped address, zeroed value)
+        for (int r = 0; r < BNB_ROWS; ++r) {                 // all loads first (rows past the group: clamped address, zeroed value)
             const int64_t row = r0 + r < M ? r0 + r : M - 1;
             cv[r] = c[row * D + ch];
             dv[r] = ld_t<SDT>(ds, row * D + ch);
@@ -406,13 +456,18 @@ __global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __rest
 // dc = gamma*rstd * (dy - k1 - chat*k2), then the depthwise conv's backward: dg[t] = sum_k w[k] dc[t-k+7] and per-workgroup partials of
 // dw[k] = sum dc[t] g[t+k-7], db = sum dc  -> ws[blk][16][D]
 template <int GDT, int ODT>
-__global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ c, const float* __restrict__ stats,
-                                                             const float* __restrict__ coef, const void* __restrict__ g,
+__global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ c, const float* __restrict__ stats_all,
+                                                             const float* __restrict__ coef_all, const void* __restrict__ g,
                                                              const float* __restrict__ w, void* __restrict__ dg_out, float* __restrict__ ws,
-                                                             int T, int D) {
-    const int b = blockIdx.y, t0 = blockIdx.x * DWT;
-    const int64_t ub = (int64_t)b * T * D;
-    const int64_t blk = (int64_t)b * gridDim.x + blockIdx.x;
+                                                             const DwGroups G, int D) {
+    const int gi = dw_pick_blk(G, (int)blockIdx.x);
+    const DwGroup& gr = G.g[gi];
+    const float* stats = stats_all + (int64_t)gi * 4 * D;
+    const float* coef = coef_all + (int64_t)gi * 2 * D;
+    const int rel = (int)blockIdx.x - gr.blk0, T = gr.T;
+    const int b = rel / gr.nblk_t, t0 = (rel % gr.nblk_t) * DWT;
+    const int64_t ub = (gr.row0 + (int64_t)b * T) * D;
+    const int64_t blk = blockIdx.x;
     for (int ch = threadIdx.x; ch < D; ch += 256) {
         const float mean = stats[ch], rstd = stats[D + ch], sc = stats[2 * D + ch];       // sc = gamma * rstd
         const float k1 = coef[ch], k2 = coef[D + ch];
@@ -453,26 +508,37 @@ __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __rest
     }
 }
 
-// second stage of the BatchNorm backward sums: dbeta = S1, dgamma = S2, coef = (S1/N, S2/N)
-__global__ __launch_bounds__(256) void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, int nblk, int D, double inv_n, float* dgamma, float* dbeta, float* coef, int acc) {
+// second stage of the BatchNorm backward sums, micro-batch after micro-batch: coef_g = (S1_g/N_g, S2_g/N_g); dbeta = sum_g S1_g, dgamma = sum_g S2_g
+__global__ __launch_bounds__(256) void cfm_bn_bwd_finalize_kernel(const float* __restrict__ ws, const DwGroups G, int D, float* dgamma, float* dbeta, float* coef_all,
+                                                                  int acc) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wavefront per channel
     if (c >= D) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s1 += ws[((int64_t)b * 2 + 0) * D + c];
-        s2 += ws[((int64_t)b * 2 + 1) * D + c];
-    }
+    float tb = acc ? dbeta[c] : 0.f, tg = acc ? dgamma[c] : 0.f;        // acc: on top of what is there (one writer per element: reproducible)
+    for (int gi = 0; gi < G.n; ++gi) {
+        const DwGroup& gr = G.g[gi];
+        const int64_t Mg = (int64_t)gr.B * gr.T;
+        const int nblk = (int)((Mg + BNB_ROWS - 1) / BNB_ROWS);
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = lane; b < nblk; b += 64) {
+            s1 += ws[((int64_t)(gr.bnb0 + b) * 2 + 0) * D + c];
+            s2 += ws[((int64_t)(gr.bnb0 + b) * 2 + 1) * D + c];
+        }
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        s1 += shfl_xor_f64(s1, o);
-        s2 += shfl_xor_f64(s2, o);
+        for (int o = 1; o < 64; o <<= 1) {
+            s1 += shfl_xor_f64(s1, o);
+            s2 += shfl_xor_f64(s2, o);
+        }
+        if (lane == 0) {
+            tb += (float)s1;
+            tg += (float)s2;
+            coef_all[(int64_t)gi * 2 * D + c] = (float)(s1 / (double)Mg);
+            coef_all[(int64_t)gi * 2 * D + D + c] = (float)(s2 / (double)Mg);
+        }
     }
     if (lane != 0) return;
-    dbeta[c] = (acc ? dbeta[c] : 0.f) + (float)s1;          // acc: on top of what is there (one writer per element: reproducible)
-    dgamma[c] = (acc ? dgamma[c] : 0.f) + (float)s2;
-    coef[c] = (float)(s1 * inv_n);
-    coef[D + c] = (float)(s2 * inv_n);
+    dbeta[c] = tb;
+    dgamma[c] = tg;
 }
 
 // second stage of the depthwise gradients: dw_w[c][k] (the layout of depthwise_conv.weight (D,1,K)) and dw_b[c]
@@ -784,36 +850,70 @@ extern "C" int cfm_glu_bwd(const void* u, int32_t u_dtype, const void* dg, int32
 
 extern "C" int64_t cfm_dwconv_bn_ws(int32_t B, int32_t T, int32_t D) {     // floats: enough for the forward and for the backward
     const int64_t nblk_t = (T + DWT - 1) / DWT;
-    // backward: BatchNorm sums [nb][2][D] | coef [2][D] | depthwise partials [B*nblk_t][16][D]   (forward: [B*nblk_t][2][D])
+    // backward: BatchNorm sums [nb][2][D] | coef [2][D] | depthwise partials [B*nblk_t][16][D]   (forward: [B*nblk_t][2][D]).  A window of
+    // several micro-batches needs the SUM of its groups' sizes (the three regions of all groups laid out region by region).
     return (((int64_t)B * T + BNB_ROWS - 1) / BNB_ROWS) * 2 * D + 2 * (int64_t)D + (int64_t)B * nblk_t * 16 * D;
+}
+
+namespace {
+// the kernels' group table from the C one; totals: (utterance, time block) slots, BNB row blocks, rows
+int dw_groups(const cfm_train_group* groups, int n, int D, DwGroups& G, int& blks, int& bnbs, int64_t& rows, const char* who) {
+    CFM_CHECK_ARG(groups && n > 0 && n <= DW_GROUPS_MAX, "%s: %d row groups (1 .. %d)", who, n, DW_GROUPS_MAX);
+    CFM_CHECK_ARG(D > 0 && D % 4 == 0 && D <= 512, "%s: need D %% 4 == 0, D <= 512 (D=%d)", who, D);
+    blks = 0; bnbs = 0; rows = 0;
+    G.n = n;
+    for (int i = 0; i < n; ++i) {
+        const cfm_train_group& g = groups[i];
+        CFM_CHECK_ARG(g.B > 0 && g.T > 0 && g.B <= 65535 && g.row0 == rows, "%s: group %d (B=%d T=%d row0=%lld) must start at row %lld", who, i, g.B, g.T,
+                      (long long)g.row0, (long long)rows);
+        DwGroup& o = G.g[i];
+        o.B = g.B; o.T = g.T; o.nblk_t = (g.T + DWT - 1) / DWT; o.blk0 = blks; o.bnb0 = bnbs; o.row0 = g.row0;
+        blks += g.B * o.nblk_t;
+        bnbs += (int)(((int64_t)g.B * g.T + BNB_ROWS - 1) / BNB_ROWS);
+        rows += (int64_t)g.B * g.T;
+    }
+    for (int i = n; i < DW_GROUPS_MAX; ++i) G.g[i] = G.g[0];
+    return CFM_OK;
+}
+}  // namespace
+
+extern "C" int cfm_dwconv_bn_train_groups(const void* g, int32_t g_dtype, const float* w, const float* dw_bias, const float* gamma, const float* beta,
+                                          float* running_mean, float* running_var, float momentum, float eps, float* c_out, float* stats, void* s_out,
+                                          int32_t s_dtype, float* ws, const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps,
+                                          cfm_stream_t stream) {
+    CFM_CHECK_ARG(g && w && dw_bias && gamma && beta && c_out && stats && s_out && ws, "cfm_dwconv_bn_train: null pointer");
+    CFM_CHECK_ARG(ktaps == DWK, "cfm_dwconv_bn_train: %d taps (only %d is built: the conformer's kernel_size)", ktaps, DWK);
+    DwGroups G;
+    int blks, bnbs;
+    int64_t M;
+    if (int rc = dw_groups(groups, n_groups, D, G, blks, bnbs, M, "cfm_dwconv_bn_train")) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        CfmProfScope prof("dwconv_stats", s, 2.0 * M * D * DWK, (double)M * D * (cfm_elt_size(g_dtype) + 4.0));
+        const dim3 grid((unsigned)blks);
+        if (g_dtype == CFM_BF16) CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_BF16>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, G, D);
+        else if (g_dtype == CFM_F16) CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_F16>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, G, D);
+        else CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_F32>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, G, D);
+        if (int rc = cfm_launch_status("cfm_dwconv_bn_train (conv)")) return rc;
+    }
+    {
+        CfmProfScope prof("bn_finalize", s, 0.0, (double)blks * 2 * D * 4);
+        CFM_LAUNCH(cfm_bn_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, G, D, gamma, beta, running_mean, running_var, momentum,
+                   eps, stats);
+        if (int rc = cfm_launch_status("cfm_dwconv_bn_train (finalize)")) return rc;
+    }
+    CfmProfScope prof("bn_silu_apply", s, 0.0, (double)M * D * (4.0 + cfm_elt_size(s_dtype)));
+    CFM_LAUNCH(cfm_bn_silu_apply_kernel, dim3((unsigned)grid_for(M * (D / 4))), dim3(256), 0, s, (const float*)c_out, (const float*)stats, s_out, s_dtype, M, D, G);
+    return cfm_launch_status("cfm_dwconv_bn_train (apply)");
 }
 
 extern "C" int cfm_dwconv_bn_train(const void* g, int32_t g_dtype, const float* w, const float* dw_bias, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, float* c_out, float* stats, void* s_out,
                                    int32_t s_dtype, float* ws, int32_t B, int32_t T, int32_t D, int32_t ktaps, cfm_stream_t stream) {
-    CFM_CHECK_ARG(g && w && dw_bias && gamma && beta && c_out && stats && s_out && ws, "cfm_dwconv_bn_train: null pointer");
-    CFM_CHECK_ARG(ktaps == DWK, "cfm_dwconv_bn_train: %d taps (only %d is built: the conformer's kernel_size)", ktaps, DWK);
-    CFM_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 512 && B <= 65535, "cfm_dwconv_bn_train: need D %% 4 == 0, D <= 512 (B=%d T=%d D=%d)", B, T, D);
-    hipStream_t s = (hipStream_t)stream;
-    const int nblk_t = (T + DWT - 1) / DWT;
-    const int64_t M = (int64_t)B * T;
-    {
-        CfmProfScope prof("dwconv_stats", s, 2.0 * M * D * DWK, (double)M * D * (cfm_elt_size(g_dtype) + 4.0));
-        const dim3 grid((unsigned)nblk_t, (unsigned)B);
-        if (g_dtype == CFM_BF16) CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_BF16>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, T, D);
-        else if (g_dtype == CFM_F16) CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_F16>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, T, D);
-        else CFM_LAUNCH((cfm_dwconv_stats_kernel<CFM_F32>), grid, dim3(256), 0, s, g, w, dw_bias, c_out, ws, T, D);
-        if (int rc = cfm_launch_status("cfm_dwconv_bn_train (conv)")) return rc;
-    }
-    {
-        CfmProfScope prof("bn_finalize", s, 0.0, (double)B * nblk_t * 2 * D * 4);
-        CFM_LAUNCH(cfm_bn_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, nblk_t, B, T, D, gamma, beta, running_mean,
-                   running_var, momentum, eps, stats);
-        if (int rc = cfm_launch_status("cfm_dwconv_bn_train (finalize)")) return rc;
-    }
-    CfmProfScope prof("bn_silu_apply", s, 0.0, (double)M * D * (4.0 + cfm_elt_size(s_dtype)));
-    CFM_LAUNCH(cfm_bn_silu_apply_kernel, dim3((unsigned)grid_for(M * (D / 4))), dim3(256), 0, s, (const float*)c_out, (const float*)stats, s_out, s_dtype, M, D);
-    return cfm_launch_status("cfm_dwconv_bn_train (apply)");
+    cfm_train_group one = {};
+    one.B = B; one.T = T; one.row0 = 0;
+    return cfm_dwconv_bn_train_groups(g, g_dtype, w, dw_bias, gamma, beta, running_mean, running_var, momentum, eps, c_out, stats, s_out, s_dtype, ws, &one, 1, D,
+                                      ktaps, stream);
 }
 
 extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
@@ -822,34 +922,34 @@ extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const f
     return cfm_dwconv_bn_train_bwd_acc(ds, ds_dtype, c, stats, g, g_dtype, w, dg_out, dg_dtype, dw_w, dw_b, dgamma, dbeta, dy_ws, ws, B, T, D, ktaps, 0, stream);
 }
 
-extern "C" int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
-                                           void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
-                                           int32_t B, int32_t T, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream) {
+extern "C" int cfm_dwconv_bn_train_bwd_groups(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
+                                              void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
+                                              const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream) {
     CFM_CHECK_ARG(ds && c && stats && g && w && dg_out && dw_w && dw_b && dgamma && dbeta && dy_ws && ws, "cfm_dwconv_bn_train_bwd: null pointer");
     CFM_CHECK_ARG(ktaps == DWK, "cfm_dwconv_bn_train_bwd: %d taps (only %d is built)", ktaps, DWK);
-    CFM_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= 512 && B <= 65535, "cfm_dwconv_bn_train_bwd: need D %% 4 == 0, D <= 512 (B=%d T=%d D=%d)", B, T, D);
+    DwGroups G;
+    int blks, bnbs;
+    int64_t M;
+    if (int rc = dw_groups(groups, n_groups, D, G, blks, bnbs, M, "cfm_dwconv_bn_train_bwd")) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t M = (int64_t)B * T;
-    const int nb = (int)((M + BNB_ROWS - 1) / BNB_ROWS);
-    float* coef = ws + (int64_t)nb * 2 * D;                                 // [2][D] behind the BatchNorm partials
+    float* coef = ws + (int64_t)bnbs * 2 * D;                               // [n_groups][2][D] behind the BatchNorm partials
     {
         CfmProfScope prof("bn_silu_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(ds_dtype)));
-        if (ds_dtype == CFM_BF16) CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_BF16>), dim3((unsigned)nb), dim3(256), 0, s, ds, c, stats, dy_ws, ws, M, D);
-        else if (ds_dtype == CFM_F16) CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_F16>), dim3((unsigned)nb), dim3(256), 0, s, ds, c, stats, dy_ws, ws, M, D);
-        else CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_F32>), dim3((unsigned)nb), dim3(256), 0, s, ds, c, stats, dy_ws, ws, M, D);
+        if (ds_dtype == CFM_BF16) CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_BF16>), dim3((unsigned)bnbs), dim3(256), 0, s, ds, c, stats, dy_ws, ws, G, D);
+        else if (ds_dtype == CFM_F16) CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_F16>), dim3((unsigned)bnbs), dim3(256), 0, s, ds, c, stats, dy_ws, ws, G, D);
+        else CFM_LAUNCH((cfm_bn_silu_bwd_kernel<CFM_F32>), dim3((unsigned)bnbs), dim3(256), 0, s, ds, c, stats, dy_ws, ws, G, D);
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (silu/bn sums)")) return rc;
     }
     {
-        CfmProfScope prof("bn_bwd_finalize", s, 0.0, (double)nb * 2 * D * 4);
-        CFM_LAUNCH(cfm_bn_bwd_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, nb, D, 1.0 / (double)M, dgamma, dbeta, coef, accumulate);
+        CfmProfScope prof("bn_bwd_finalize", s, 0.0, (double)bnbs * 2 * D * 4);
+        CFM_LAUNCH(cfm_bn_bwd_finalize_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, s, (const float*)ws, G, D, dgamma, dbeta, coef, accumulate);
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (finalize)")) return rc;
     }
-    const int nblk_t = (T + DWT - 1) / DWT;
-    float* part = coef + 2 * (int64_t)D;                                    // depthwise partials [blk][16][D] behind coef
+    float* part = coef + 2 * (int64_t)D * n_groups;                         // depthwise partials [blk][16][D] behind coef
     {
         CfmProfScope prof("dwconv_bwd", s, 4.0 * M * D * DWK, (double)M * D * (8.0 + cfm_elt_size(g_dtype) + cfm_elt_size(dg_dtype)));
-        const dim3 grid((unsigned)nblk_t, (unsigned)B);
-#define CFM_DWB(GD, OD) CFM_LAUNCH((cfm_dwconv_bwd_kernel<GD, OD>), grid, dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, w, dg_out, part, T, D)
+        const dim3 grid((unsigned)blks);
+#define CFM_DWB(GD, OD) CFM_LAUNCH((cfm_dwconv_bwd_kernel<GD, OD>), grid, dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, w, dg_out, part, G, D)
         if (g_dtype == CFM_BF16 && dg_dtype == CFM_BF16) CFM_DWB(CFM_BF16, CFM_BF16);
         else if (g_dtype == CFM_F16 && dg_dtype == CFM_F16) CFM_DWB(CFM_F16, CFM_F16);
         else if (g_dtype == CFM_F32 && dg_dtype == CFM_F32) CFM_DWB(CFM_F32, CFM_F32);
@@ -861,9 +961,18 @@ extern "C" int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, con
 #undef CFM_DWB
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (conv)")) return rc;
     }
-    CfmProfScope prof("dwconv_bwd_finalize", s, 0.0, (double)B * nblk_t * 16 * D * 4);
-    CFM_LAUNCH(cfm_dwconv_bwd_finalize_kernel, dim3((unsigned)((16 * D + 63) / 64)), dim3(64 * RP_Q), 0, s, (const float*)part, B * nblk_t, D, dw_w, dw_b, accumulate);
+    CfmProfScope prof("dwconv_bwd_finalize", s, 0.0, (double)blks * 16 * D * 4);
+    CFM_LAUNCH(cfm_dwconv_bwd_finalize_kernel, dim3((unsigned)((16 * D + 63) / 64)), dim3(64 * RP_Q), 0, s, (const float*)part, blks, D, dw_w, dw_b, accumulate);
     return cfm_launch_status("cfm_dwconv_bn_train_bwd (reduce)");
+}
+
+extern "C" int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
+                                           void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
+                                           int32_t B, int32_t T, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream) {
+    cfm_train_group one = {};
+    one.B = B; one.T = T; one.row0 = 0;
+    return cfm_dwconv_bn_train_bwd_groups(ds, ds_dtype, c, stats, g, g_dtype, w, dg_out, dg_dtype, dw_w, dw_b, dgamma, dbeta, dy_ws, ws, &one, 1, D, ktaps, accumulate,
+                                          stream);
 }
 
 extern "C" int cfm_col2im_relu_bwd(const void* dcol, int32_t dcol_dtype, const void* h1, int32_t h1_dtype, void* dh1, int32_t dh1_dtype, int32_t B, int32_t T1,

@@ -8,11 +8,31 @@
 //
 // Parameter gradients are written (accumulated: the caller zero-fills) straight into a caller-provided flat buffer through per-parameter
 // pointers / row-offset maps -- in the data-parallel trainer that buffer IS the gradient bucket memory the RCCL all-reduce runs on.
+//
+// Round 3 -- what the training step's time was (13.4 ms, 1 460 launches of ~9 us, host and device both saturated) decided the shape of this file:
+//   * ROW GROUPS.  Everything in a block except attention, the depthwise convolution and the BatchNorm statistics is row-local, so the
+//     micro-batches of one accumulation window (train.sh:36 accum_grad 2; the weights do not change between them) are concatenated along
+//     the row axis: io->groups describes G micro-batches of B_g x T_g frames at row offset row0_g of ONE [M, D] row matrix.  The dense
+//     products, LayerNorms and their backward run ONCE over all M rows (half the launches, twice the rows per launch: these kernels are
+//     latency-bound at 2 400 rows), the weight gradient of the window is one product over all rows (what accumulating two micro-batch
+//     gradients computes), attention / depthwise / BatchNorm run per group -- BatchNorm statistics per micro-batch and the running
+//     statistics updated group after group, exactly the reference's sequence of two forward passes.
+//   * DEFERRED, GROUPED WEIGHT GRADIENTS.  The eight dW products of a block do not feed the chain of input gradients; with io->defer_wgrad
+//     their operands are kept (one buffer per sub-block) and the block's backward ends with ONE cfm_gemm_tn_group launch.
+//   * THE WHOLE STACK FROM ONE HOST CALL.  cfm_encoder_train_forward / _backward walk all blocks; the backward calls a host callback after
+//     each block's launches are enqueued (the data-parallel trainer launches that block's gradient bucket all-reduce from it).
 #include <math.h>
 
 #include "cfm_common.h"
 
 namespace {
+
+struct Grp {
+    int B, T;
+    int64_t row0, bht0;          // first row of the group; first element of its [B,H,T] arrays (lse, delta)
+    const uint8_t* mask;
+    int64_t sb, sq;
+};
 
 struct TCtx {
     const cfm_layer_train_weights* w;
@@ -21,7 +41,43 @@ struct TCtx {
     bool split;
     cfm_stream_t st;
     cfm_stream_t side;      // weight-gradient products go here when set (backward)
+    int ng;
+    Grp grp[CFM_TRAIN_MAX_GROUPS];
+    cfm_train_group cg[CFM_TRAIN_MAX_GROUPS];   // the same table in the C-ABI form (the depthwise / BatchNorm entry points take it)
+    bool defer;             // weight-gradient products are collected in `pend` and launched as one group at the end of the block's backward
+    cfm_stream_t wg_stream; // ... on this stream when set (the caller owns the hand-off back: cfm_encoder_train_backward)
+    cfm_gemm_tn_desc pend[12];
+    int npend;
 };
+
+// io -> the context's dimensions and row groups (n_groups == 0: the single micro-batch B x T of the round-2 interface)
+int init_ctx(TCtx& c, const cfm_layer_train_weights* w, const cfm_layer_train_io* io, cfm_stream_t stream) {
+    c.w = w; c.io = io; c.D = io->D; c.FF = io->FF; c.H = io->H; c.dk = io->D / io->H; c.adt = io->act_dtype; c.wdt = io->w_dtype;
+    c.split = io->act_dtype == CFM_F32; c.st = stream; c.side = nullptr; c.defer = false; c.npend = 0; c.wg_stream = nullptr;
+    if (io->n_groups > 0) {
+        CFM_CHECK_ARG(io->groups && io->n_groups <= CFM_TRAIN_MAX_GROUPS, "train layer: %d row groups (at most %d)", io->n_groups, CFM_TRAIN_MAX_GROUPS);
+        c.ng = io->n_groups;
+        int64_t rows = 0, bht = 0;
+        for (int i = 0; i < c.ng; ++i) {
+            const cfm_train_group& g = io->groups[i];
+            CFM_CHECK_ARG(g.B > 0 && g.T > 0 && g.row0 == rows, "train layer: group %d (B=%d T=%d row0=%lld) must start where group %d ends (%lld)", i, g.B, g.T,
+                          (long long)g.row0, i - 1, (long long)rows);
+            c.grp[i] = {g.B, g.T, g.row0, bht, g.attn_mask, g.am_sb, g.am_sq};
+            c.cg[i] = g;
+            rows += (int64_t)g.B * g.T;
+            bht += (int64_t)g.B * io->H * g.T;
+        }
+        CFM_CHECK_ARG(rows < (1ll << 31), "train layer: %lld rows", (long long)rows);
+        c.M = (int)rows;
+    } else {
+        c.ng = 1;
+        c.grp[0] = {io->B, io->T, 0, 0, io->attn_mask, io->am_sb, io->am_sq};
+        c.cg[0] = {};
+        c.cg[0].B = io->B; c.cg[0].T = io->T; c.cg[0].row0 = 0;
+        c.M = io->B * io->T;
+    }
+    return CFM_OK;
+}
 
 // A small pool of timing-free events for the main -> side stream hand-offs (created once per process; events are recorded and waited on
 // in stream order, so one event can be reused as soon as its wait has been enqueued).
@@ -77,8 +133,8 @@ int gemm(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* W, con
 
 // dW (+)= alpha * A^T . B, db (+)= alpha * colsum(A), accumulated into caller memory.  With a side stream: issued there, after everything the
 // main stream has enqueued so far (its operands); the operands must then stay untouched until the streams are joined (end of the backward)
-int wgrad(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* B, int b_dt, int64_t ldb, float* dW, float* db, int M, int N, int K, float alpha,
-          const uint8_t* row_mask, const int64_t* row_off, const int64_t* colsum_off) {
+int wgrad(TCtx& c, const void* A, int a_dt, int64_t lda, const void* B, int b_dt, int64_t ldb, float* dW, float* db, int M, int N, int K, float alpha,
+          const uint8_t* row_mask, const int64_t* row_off, const int64_t* colsum_off, const int64_t* colsum_off2 = nullptr) {
     cfm_stream_t st = c.st;
     if (c.side) {
         if (int rc = stream_after(c.st, c.side)) return rc;
@@ -87,8 +143,24 @@ int wgrad(const TCtx& c, const void* A, int a_dt, int64_t lda, const void* B, in
     cfm_gemm_tn_desc d = {};
     d.A = A; d.B = B; d.C = dW; d.colsum = db; d.row_mask = row_mask; d.lda = lda; d.ldb = ldb; d.ldc = K; d.M = M; d.N = N; d.K = K;
     d.a_dtype = a_dt; d.b_dtype = b_dt; d.mma_dtype = c.wdt; d.split = c.split ? 1 : 0; d.accumulate = 1; d.splits = c.io->deterministic ? 1 : 0;
-    d.alpha = alpha; d.row_off = row_off; d.colsum_off = colsum_off;
+    d.alpha = alpha; d.row_off = row_off; d.colsum_off = colsum_off; d.colsum_off2 = colsum_off2;
+    if (c.defer) {
+        if (c.npend >= 12) return cfm_fail(CFM_ERR_ARG, "train layer: too many deferred weight-gradient products");
+        c.pend[c.npend++] = d;
+        return CFM_OK;
+    }
     return cfm_gemm_tn(&d, st);
+}
+
+int flush_wgrads(TCtx& c) {
+    if (!c.npend) return CFM_OK;
+    const int n = c.npend;
+    c.npend = 0;
+    if (c.wg_stream) {                                   // after everything the block enqueued on the main stream (the operands), beside what follows
+        if (int rc = stream_after(c.st, c.wg_stream)) return rc;
+        return cfm_gemm_tn_group(c.pend, n, c.wg_stream);
+    }
+    return cfm_gemm_tn_group(c.pend, n, c.st);
 }
 
 int ln_fwd(const TCtx& c, const float* x, const float* g, const float* b, void* out, int out_dt, const uint8_t* mask) {
@@ -130,7 +202,7 @@ int ln_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const float* x, cons
 
 // d (f32 [M,D], the gradient of the sub-block's output) is updated in place to the gradient of its input.  dyb_buf != nullptr: the branch
 // gradient through the output dropout is already there (written by the previous LayerNorm backward, see Next)
-int ffn_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const void* dyb_buf, void* dz_buf, float* d, const float* x, const float* lg, const void* xn, const void* z,
+int ffn_bwd(TCtx& c, const cfm_layer_train_scratch* t, const void* dyb_buf, void* dz_buf, float* d, const float* x, const float* lg, const void* xn, const void* z,
             const void* h, const void* w1t, const void* w1tl, const void* w2t, const void* w2tl, float* gW1, float* gb1, float* gW2, float* gb2, float* glg,
             float* glb, float p_h, uint32_t s_h, const Next& nx) {
     const void* dyb = d;
@@ -144,16 +216,10 @@ int ffn_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const void* dyb_buf
     return ln_bwd(c, t, x, t->dxn, lg, nullptr, d, d, glg, glb, nx);
 }
 
-}  // namespace
-
-extern "C" int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
-                                               const cfm_layer_train_scratch* t, const float* x_in, float* y_out, cfm_stream_t stream) {
-    CFM_CHECK_ARG(w && io && sv && t && x_in && y_out, "cfm_encoder_layer_train_forward: null pointer");
-    CFM_CHECK_ARG(io->B > 0 && io->T > 0 && io->D > 0 && io->H > 0 && io->D % io->H == 0 && io->FF > 0 && io->D % 16 == 0,
-                  "cfm_encoder_layer_train_forward: bad dims B=%d T=%d D=%d H=%d FF=%d", io->B, io->T, io->D, io->H, io->FF);
-    TCtx c;
-    c.w = w; c.io = io; c.M = io->B * io->T; c.D = io->D; c.FF = io->FF; c.H = io->H; c.dk = io->D / io->H; c.adt = io->act_dtype; c.wdt = io->w_dtype;
-    c.split = io->act_dtype == CFM_F32; c.st = stream; c.side = nullptr;
+int layer_forward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_train_scratch* t, const float* x_in, float* y_out) {
+    const cfm_layer_train_weights* w = c.w;
+    const cfm_layer_train_io* io = c.io;
+    cfm_stream_t stream = c.st;
     const int M = c.M, D = c.D, adt = c.adt;
     const uint32_t sd = io->seed;
     // (1) macaron feed-forward
@@ -162,16 +228,22 @@ extern "C" int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w,
     // (2) self-attention: q + pos_bias_u rides in the projection's bias; the batch path's positional term is softmax-invariant
     CFM_TRY(ln_fwd(c, sv->x1, w->ln_mha_g, w->ln_mha_b, sv->xn2, adt, nullptr));
     CFM_TRY(gemm(c, sv->xn2, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, sv->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
-    {
-        cfm_attn_desc a = {};
-        const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
-        a.q = sv->qkv; a.k = eoff(sv->qkv, D, adt); a.v = eoff(sv->qkv, 2 * D, adt);
-        a.q_sb = a.k_sb = a.v_sb = sb; a.q_st = a.k_st = a.v_st = stt; a.k_sh = a.v_sh = c.dk;
-        a.q_dtype = a.kv_dtype = adt; a.out = sv->ctx; a.out_dtype = adt;
-        a.mask = io->attn_mask; a.m_sb = io->am_sb; a.m_sq = io->am_sq;
-        a.B = io->B; a.H = c.H; a.Tq = a.Tk = io->T; a.dk = c.dk; a.mma_dtype = c.wdt; a.split = c.split ? 1 : 0; a.scale = 1.0f / sqrtf((float)c.dk);
-        a.lse = sv->lse; a.drop_p = io->p_attn; a.drop_seed = site_seed(sd, 3);
-        CFM_TRY(cfm_attention(&a, stream));
+    {                                                        // attention mixes the frames of ONE utterance: a problem per micro-batch (its own T and mask), one launch
+        cfm_attn_desc ad[CFM_TRAIN_MAX_GROUPS];
+        for (int gi = 0; gi < c.ng; ++gi) {
+            const Grp& G = c.grp[gi];
+            cfm_attn_desc a = {};
+            const int64_t sb = (int64_t)G.T * 3 * D, stt = 3 * D;
+            const void* qkv = eoff(sv->qkv, G.row0 * 3 * D, adt);
+            a.q = qkv; a.k = eoff(qkv, D, adt); a.v = eoff(qkv, 2 * D, adt);
+            a.q_sb = a.k_sb = a.v_sb = sb; a.q_st = a.k_st = a.v_st = stt; a.k_sh = a.v_sh = c.dk;
+            a.q_dtype = a.kv_dtype = adt; a.out = eoffw(sv->ctx, G.row0 * D, adt); a.out_dtype = adt;
+            a.mask = G.mask; a.m_sb = G.sb; a.m_sq = G.sq;
+            a.B = G.B; a.H = c.H; a.Tq = a.Tk = G.T; a.dk = c.dk; a.mma_dtype = c.wdt; a.split = c.split ? 1 : 0; a.scale = 1.0f / sqrtf((float)c.dk);
+            a.lse = sv->lse + G.bht0; a.drop_p = io->p_attn; a.drop_seed = site_seed(sd, 3) + 0x7F4A7C15u * (uint32_t)gi;
+            ad[gi] = a;
+        }
+        CFM_TRY(c.ng == 1 ? cfm_attention(&ad[0], stream) : cfm_attention_group(ad, c.ng, stream));
     }
     {
         float p1 = io->p_branch, p2 = io->p_attn_out;
@@ -179,11 +251,11 @@ extern "C" int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w,
         if (p1 <= 0.f && p2 > 0.f) { p1 = p2; s1 = s2; p2 = 0.f; }
         CFM_TRY(gemm(c, sv->ctx, adt, D, w->out_w, w->out_w_lo, w->out_b, sv->x2, CFM_F32, D, M, D, D, CFM_ACT_NONE, sv->x1, 1.0f, nullptr, 0, nullptr, nullptr, p1, s1, p2, s2));
     }
-    // (3) convolution module, BatchNorm in training mode
+    // (3) convolution module, BatchNorm in training mode: statistics per micro-batch, running statistics updated group after group
     CFM_TRY(ln_fwd(c, sv->x2, w->ln_conv_g, w->ln_conv_b, sv->xn3, adt, io->pad_valid));
     CFM_TRY(gemm(c, sv->xn3, adt, D, w->pw1_w, w->pw1_w_lo, w->pw1_b, sv->glu, adt, D, M, 2 * D, D, CFM_ACT_GLU, nullptr, 0.f, nullptr, 0, sv->u, nullptr, 0.f, 0));
-    CFM_TRY(cfm_dwconv_bn_train(sv->glu, adt, w->dw_w, w->dw_b, w->bn_gamma, w->bn_beta, w->bn_running_mean, w->bn_running_var, w->bn_momentum, w->bn_eps, sv->c,
-                                sv->stats, sv->s, adt, t->dwbn_ws, io->B, io->T, D, io->ktaps, stream));
+    CFM_TRY(cfm_dwconv_bn_train_groups(sv->glu, adt, w->dw_w, w->dw_b, w->bn_gamma, w->bn_beta, w->bn_running_mean, w->bn_running_var, w->bn_momentum, w->bn_eps, sv->c,
+                                       sv->stats, sv->s, adt, t->dwbn_ws, c.cg, c.ng, D, io->ktaps, stream));
     CFM_TRY(gemm(c, sv->s, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, sv->x3, CFM_F32, D, M, D, D, CFM_ACT_NONE, sv->x2, 1.0f, io->pad_valid, 0, nullptr, nullptr,
                  io->p_branch, site_seed(sd, 6)));
     // (4) feed-forward, (5) norm_final
@@ -192,31 +264,35 @@ extern "C" int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w,
     return cfm_layernorm(sv->x4, w->ln_final_g, w->ln_final_b, y_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, 1e-5f, M, D, stream);
 }
 
-extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
-                                                const cfm_layer_train_scratch* t, const cfm_layer_train_grads* g, const float* x_in, const float* dy,
-                                                float* dx, cfm_stream_t stream) {
-    CFM_CHECK_ARG(w && io && sv && t && g && x_in && dy && dx && dx != dy, "cfm_encoder_layer_train_backward: null pointer (dx must not alias dy)");
-    TCtx c;
-    c.w = w; c.io = io; c.M = io->B * io->T; c.D = io->D; c.FF = io->FF; c.H = io->H; c.dk = io->D / io->H; c.adt = io->act_dtype; c.wdt = io->w_dtype;
-    c.split = io->act_dtype == CFM_F32; c.st = stream;
+int layer_backward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_train_scratch* t, const cfm_layer_train_grads* g, const float* x_in, const float* dy,
+                   float* dx) {
+    const cfm_layer_train_weights* w = c.w;
+    const cfm_layer_train_io* io = c.io;
+    cfm_stream_t stream = c.st;
     c.side = io->side_stream && io->side_stream != stream ? io->side_stream : nullptr;
-    CFM_CHECK_ARG(!c.side || (t->dz2 && t->dyb2 && t->dyb3 && t->dyb4), "cfm_encoder_layer_train_backward: a side stream needs the dz2 / dyb2..4 scratch buffers");
+    // deferral keeps every product's operands until the block's last launch: same buffers as the side-stream variant; the grouped kernel
+    // takes 16-bit operands (the f32-accurate mode keeps its immediate, single products).  Deferral AND a side stream: the one grouped
+    // launch goes to the side stream (c.wg_stream), everything else stays on the main one
+    c.defer = io->defer_wgrad && !c.split;
+    if (c.defer) { c.wg_stream = c.side; c.side = nullptr; }
+    const bool keep_ops = c.side || c.defer;
+    CFM_CHECK_ARG(!keep_ops || (t->dz2 && t->dyb2 && t->dyb3 && t->dyb4), "cfm_encoder_layer_train_backward: a side stream / deferred weight gradients need the dz2 / dyb2..4 scratch buffers");
     CFM_CHECK_ARG(!io->grads_accumulate || !io->deterministic, "cfm_encoder_layer_train_backward: grads_accumulate needs deterministic == 0");
     const int M = c.M, D = c.D, adt = c.adt;
     const uint32_t sd = io->seed;
     float* d = dx;                                        // the residual stream's gradient, updated in place from the block's output to its input
     // Each sub-block's branch gradient (dropout mask * alpha * d, act dtype) is written by the LayerNorm backward that produces d -- when it is
-    // needed at all: with dropout, or with a side stream (d is overwritten by the sub-block's own LayerNorm backward while a weight-gradient
-    // product on the side stream may still read its operand; one buffer per sub-block then)
-    const bool br = io->p_branch > 0.f || c.side;
+    // needed at all: with dropout, or when the operands must outlive the sub-block (d is overwritten by the sub-block's own LayerNorm backward
+    // while a weight-gradient product on the side stream / at the end of the block still reads its operand; one buffer per sub-block then)
+    const bool br = io->p_branch > 0.f || keep_ops;
     float pa1 = io->p_branch, pa2 = io->p_attn_out;
     uint32_t sa1 = site_seed(sd, 4), sa2 = site_seed(sd, 5);
     if (pa1 <= 0.f && pa2 > 0.f) { pa1 = pa2; sa1 = sa2; pa2 = 0.f; }
-    const bool bra = pa1 > 0.f || c.side;
+    const bool bra = pa1 > 0.f || keep_ops;
     const Next n_ff = {br ? t->dyb : nullptr, 0.5f, io->p_branch, site_seed(sd, 8), 0.f, 0, nullptr};
-    const Next n_conv = {br ? (c.side ? t->dyb2 : t->dyb) : nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0, io->pad_valid};
-    const Next n_att = {bra ? (c.side ? t->dyb3 : t->dyb) : nullptr, 1.0f, pa1, sa1, pa2, sa2, nullptr};
-    const Next n_ffm = {br ? (c.side ? t->dyb4 : t->dyb) : nullptr, 0.5f, io->p_branch, site_seed(sd, 2), 0.f, 0, nullptr};
+    const Next n_conv = {br ? (keep_ops ? t->dyb2 : t->dyb) : nullptr, 1.0f, io->p_branch, site_seed(sd, 6), 0.f, 0, io->pad_valid};
+    const Next n_att = {bra ? (keep_ops ? t->dyb3 : t->dyb) : nullptr, 1.0f, pa1, sa1, pa2, sa2, nullptr};
+    const Next n_ffm = {br ? (keep_ops ? t->dyb4 : t->dyb) : nullptr, 0.5f, io->p_branch, site_seed(sd, 2), 0.f, 0, nullptr};
     const Next n_none = {nullptr, 0.f, 0.f, 0, 0.f, 0, nullptr};
     // (5) norm_final
     CFM_TRY(ln_bwd(c, t, sv->x4, dy, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, n_ff));
@@ -231,8 +307,9 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
         if (n_conv.buf) { dyb = n_conv.buf; dyb_dt = adt; pm = nullptr; }   // the padded rows of the operand are already zero (Next.mask)
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, pm, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, pm, pm ? 1 : 0, nullptr, nullptr, 0.f, 0));
-        CFM_TRY(cfm_dwconv_bn_train_bwd_acc(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
-                                            io->B, io->T, D, io->ktaps, io->grads_accumulate, stream));
+        // per micro-batch its own BatchNorm statistics, one launch per stage for all of them; the parameter gradients are summed over the micro-batches
+        CFM_TRY(cfm_dwconv_bn_train_bwd_groups(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
+                                               c.cg, c.ng, D, io->ktaps, io->grads_accumulate ? 1 : 0, stream));
         CFM_TRY(cfm_glu_bwd(sv->u, adt, t->dglu, adt, t->du, adt, M, D, stream));
         CFM_TRY(wgrad(c, t->du, adt, 2 * D, sv->xn3, adt, D, g->slab, g->slab, M, 2 * D, D, 1.0f, nullptr, g->pw1_row_off, g->pw1_bias_off));
         CFM_TRY(gemm(c, t->du, adt, 2 * D, w->pw1_t, w->pw1_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 2 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
@@ -245,25 +322,137 @@ extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w
         if (n_att.buf) { dyb = n_att.buf; dyb_dt = adt; }
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->ctx, adt, D, g->out_w, g->out_b, M, D, D, 1.0f, nullptr, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->out_t, w->out_t_lo, nullptr, t->dctx, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
-        cfm_attn_bwd_desc b = {};
-        const int64_t sb = (int64_t)io->T * 3 * D, stt = 3 * D;
-        b.q = sv->qkv; b.k = eoff(sv->qkv, D, adt); b.v = eoff(sv->qkv, 2 * D, adt);
-        b.mask = io->attn_mask; b.out = sv->ctx; b.dout = t->dctx; b.lse = sv->lse;
-        b.grad_q = t->dqkv; b.grad_k = eoffw(t->dqkv, D, adt); b.grad_v = eoffw(t->dqkv, 2 * D, adt); b.delta = t->delta;
-        b.q_sb = b.k_sb = b.v_sb = sb; b.q_st = b.k_st = b.v_st = stt; b.m_sb = io->am_sb; b.m_sq = io->am_sq;
-        b.B = io->B; b.H = c.H; b.Tq = b.Tk = io->T; b.dk = c.dk; b.io_dtype = adt; b.dout_dtype = adt; b.mma_dtype = c.wdt; b.split = c.split ? 1 : 0;
-        b.scale = 1.0f / sqrtf((float)c.dk); b.drop_p = io->p_attn; b.drop_seed = site_seed(sd, 3);
-        CFM_TRY(cfm_attention_bwd(&b, stream));
-        CFM_TRY(wgrad(c, t->dqkv, adt, 3 * D, sv->xn2, adt, D, g->slab, g->slab, M, 3 * D, D, 1.0f, nullptr, g->qkv_row_off, g->qkv_bias_off));
-        if (g->pos_bias_u && g->q_bias &&              // d/du of (q + u) . k^T = d/d(linear_q.bias): the column sums of dq (same stream as that product)
-            hipMemcpyAsync(g->pos_bias_u, g->q_bias, (size_t)D * 4, hipMemcpyDeviceToDevice, (hipStream_t)(c.side ? c.side : stream)) != hipSuccess)
-            return cfm_fail(CFM_ERR_LAUNCH, "train layer: copy of the pos_bias_u gradient failed");
+        {
+            cfm_attn_bwd_desc bd[CFM_TRAIN_MAX_GROUPS];
+            for (int gi = 0; gi < c.ng; ++gi) {
+                const Grp& G = c.grp[gi];
+                cfm_attn_bwd_desc b = {};
+                const int64_t sb = (int64_t)G.T * 3 * D, stt = 3 * D;
+                const void* qkv = eoff(sv->qkv, G.row0 * 3 * D, adt);
+                void* dqkv = eoffw(t->dqkv, G.row0 * 3 * D, adt);
+                b.q = qkv; b.k = eoff(qkv, D, adt); b.v = eoff(qkv, 2 * D, adt);
+                b.mask = G.mask; b.out = eoff(sv->ctx, G.row0 * D, adt); b.dout = eoff(t->dctx, G.row0 * D, adt); b.lse = sv->lse + G.bht0;
+                b.grad_q = dqkv; b.grad_k = eoffw(dqkv, D, adt); b.grad_v = eoffw(dqkv, 2 * D, adt); b.delta = t->delta + G.bht0;
+                b.q_sb = b.k_sb = b.v_sb = sb; b.q_st = b.k_st = b.v_st = stt; b.m_sb = G.sb; b.m_sq = G.sq;
+                b.B = G.B; b.H = c.H; b.Tq = b.Tk = G.T; b.dk = c.dk; b.io_dtype = adt; b.dout_dtype = adt; b.mma_dtype = c.wdt; b.split = c.split ? 1 : 0;
+                b.scale = 1.0f / sqrtf((float)c.dk); b.drop_p = io->p_attn; b.drop_seed = site_seed(sd, 3) + 0x7F4A7C15u * (uint32_t)gi;
+                bd[gi] = b;
+            }
+            CFM_TRY(c.ng == 1 ? cfm_attention_bwd(&bd[0], stream) : cfm_attention_bwd_group(bd, c.ng, stream));
+        }
+        // d/du of (q + u) . k^T = d/d(linear_q.bias): the column sums of dq -- a second scatter table of the same product, or a copy after it
+        const bool u_table = g->pos_bias_u && g->qkv_bias_off2;
+        CFM_TRY(wgrad(c, t->dqkv, adt, 3 * D, sv->xn2, adt, D, g->slab, g->slab, M, 3 * D, D, 1.0f, nullptr, g->qkv_row_off, g->qkv_bias_off, u_table ? g->qkv_bias_off2 : nullptr));
+        if (g->pos_bias_u && g->q_bias && !u_table) {
+            CFM_CHECK_ARG(!c.defer, "cfm_encoder_layer_train_backward: deferred weight gradients need grads.qkv_bias_off2 for pos_bias_u");
+            if (hipMemcpyAsync(g->pos_bias_u, g->q_bias, (size_t)D * 4, hipMemcpyDeviceToDevice, (hipStream_t)(c.side ? c.side : stream)) != hipSuccess)
+                return cfm_fail(CFM_ERR_LAUNCH, "train layer: copy of the pos_bias_u gradient failed");
+        }
         CFM_TRY(gemm(c, t->dqkv, adt, 3 * D, w->qkv_t, w->qkv_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 3 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
         CFM_TRY(ln_bwd(c, t, sv->x1, t->dxn, w->ln_mha_g, nullptr, d, d, g->ln_mha_g, g->ln_mha_b, n_ffm));
     }
     // (1) macaron feed-forward
-    CFM_TRY(ffn_bwd(c, t, n_ffm.buf, c.side ? t->dz2 : t->dz, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t,
+    CFM_TRY(ffn_bwd(c, t, n_ffm.buf, keep_ops ? t->dz2 : t->dz, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t,
                     w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2, g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), n_none));
+    CFM_TRY(flush_wgrads(c));                            // deferred: the block's eight weight-gradient products, one launch
     if (c.side) return stream_after(c.side, c.st);       // join: the block's gradients are complete when the main stream gets past this point
+    return CFM_OK;                                       // (c.wg_stream: the caller joins -- cfm_encoder_layer_train_backward at once, the stack one block later)
+}
+
+int check_io(const cfm_layer_train_io* io, const char* who) {
+    CFM_CHECK_ARG(io->D > 0 && io->H > 0 && io->D % io->H == 0 && io->FF > 0 && io->D % 16 == 0 && (io->n_groups > 0 || (io->B > 0 && io->T > 0)),
+                  "%s: bad dims B=%d T=%d D=%d H=%d FF=%d", who, io->B, io->T, io->D, io->H, io->FF);
+    return CFM_OK;
+}
+
+// per-layer dropout seeds of a stack: layer l draws from seed + l * odd constant (0 stays 0: no dropout anywhere)
+inline uint32_t layer_seed(uint32_t seed, int l) { return seed ? seed + 0x632BE5ABu * (uint32_t)l : 0u; }
+
+}  // namespace
+
+extern "C" int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                               const cfm_layer_train_scratch* t, const float* x_in, float* y_out, cfm_stream_t stream) {
+    CFM_CHECK_ARG(w && io && sv && t && x_in && y_out, "cfm_encoder_layer_train_forward: null pointer");
+    CFM_TRY(check_io(io, "cfm_encoder_layer_train_forward"));
+    TCtx c;
+    CFM_TRY(init_ctx(c, w, io, stream));
+    return layer_forward(c, sv, t, x_in, y_out);
+}
+
+extern "C" int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                                const cfm_layer_train_scratch* t, const cfm_layer_train_grads* g, const float* x_in, const float* dy,
+                                                float* dx, cfm_stream_t stream) {
+    CFM_CHECK_ARG(w && io && sv && t && g && x_in && dy && dx && dx != dy, "cfm_encoder_layer_train_backward: null pointer (dx must not alias dy)");
+    CFM_TRY(check_io(io, "cfm_encoder_layer_train_backward"));
+    TCtx c;
+    CFM_TRY(init_ctx(c, w, io, stream));
+    CFM_TRY(layer_backward(c, sv, t, g, x_in, dy, dx));
+    if (c.wg_stream) return stream_after(c.wg_stream, c.st);
+    return CFM_OK;
+}
+
+// ---- the whole stack (encoder.py:72-73 `for block in self.encoders` under module.train()) from one host call each way ------------------------
+extern "C" int cfm_encoder_train_forward(int32_t n_layers, const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                         const cfm_layer_train_scratch* t, float* const* xs, cfm_stream_t stream) {
+    CFM_CHECK_ARG(n_layers > 0 && w && io && sv && t && xs, "cfm_encoder_train_forward: null pointer");
+    CFM_TRY(check_io(io, "cfm_encoder_train_forward"));
+    for (int l = 0; l < n_layers; ++l) {
+        CFM_CHECK_ARG(xs[l] && xs[l + 1], "cfm_encoder_train_forward: xs[%d] is null", l);
+        cfm_layer_train_io iol = *io;
+        iol.seed = layer_seed(io->seed, l);
+        TCtx c;
+        CFM_TRY(init_ctx(c, &w[l], &iol, stream));
+        CFM_TRY(layer_forward(c, &sv[l], t, xs[l], xs[l + 1]));
+    }
+    return CFM_OK;
+}
+
+extern "C" int cfm_encoder_train_backward(int32_t n_layers, const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                                          const cfm_layer_train_scratch* t, int32_t n_scratch, const cfm_layer_train_grads* g, float* const* xs, const float* dy,
+                                          float* dbuf0, float* dbuf1, cfm_layer_done_fn done, void* user, float** dx_out, cfm_stream_t stream) {
+    CFM_CHECK_ARG(n_layers > 0 && w && io && sv && t && g && xs && dy && dbuf0 && dbuf1 && dbuf0 != dbuf1 && dx_out && dy != dbuf0 && dy != dbuf1,
+                  "cfm_encoder_train_backward: null or aliased pointer");
+    CFM_CHECK_ARG(n_scratch == 1 || n_scratch == 2, "cfm_encoder_train_backward: n_scratch must be 1 or 2");
+    CFM_TRY(check_io(io, "cfm_encoder_train_backward"));
+    // Weight gradients beside the chain: with io->side_stream and io->defer_wgrad block l's grouped launch runs on the side stream while the main
+    // stream goes on with block l-1.  Its operands live in scratch set l & 1 (two sets: n_scratch == 2), which block l-2 reuses -- the main
+    // stream waits for block l's launch before block l-2 starts (two blocks later: never a stall in practice), and `done(l)` is reported one
+    // block late, after that wait, so that whoever reduces block l's gradients from the MAIN stream sees them complete.
+    const bool beside = io->side_stream && io->side_stream != stream && io->defer_wgrad && io->act_dtype != CFM_F32;
+    CFM_CHECK_ARG(!beside || n_scratch == 2, "cfm_encoder_train_backward: weight gradients on a side stream need two scratch sets");
+    static thread_local hipEvent_t wg_done[2] = {nullptr, nullptr};
+    if (beside)
+        for (int i = 0; i < 2; ++i)
+            if (!wg_done[i] && hipEventCreateWithFlags(&wg_done[i], hipEventDisableTiming) != hipSuccess)
+                return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: event creation failed");
+    const float* cur = dy;
+    float* bufs[2] = {dbuf0, dbuf1};
+    int k = 0;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        cfm_layer_train_io iol = *io;
+        iol.seed = layer_seed(io->seed, l);
+        TCtx c;
+        CFM_TRY(init_ctx(c, &w[l], &iol, stream));
+        const int set = n_scratch == 2 ? (l & 1) : 0;
+        if (beside && l + 2 < n_layers && hipStreamWaitEvent((hipStream_t)stream, wg_done[set], 0) != hipSuccess)       // block l+2's products have read this set
+            return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: stream wait failed");
+        CFM_TRY(layer_backward(c, &sv[l], &t[set], &g[l], xs[l], cur, bufs[k]));
+        cur = bufs[k];
+        k ^= 1;
+        if (beside) {
+            if (hipEventRecord(wg_done[set], (hipStream_t)io->side_stream) != hipSuccess) return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: event record failed");
+            if (l + 1 < n_layers) {
+                if (hipStreamWaitEvent((hipStream_t)stream, wg_done[set ^ 1], 0) != hipSuccess) return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: stream wait failed");
+                if (done) done(l + 1, user);
+            }
+        } else if (done) {
+            done(l, user);                                // every launch of block l's backward is enqueued: its gradients may be reduced
+        }
+    }
+    if (beside) {
+        if (int rc = stream_after(io->side_stream, stream)) return rc;     // join: block 0's (and, with it, every) weight gradient
+        if (done) done(0, user);
+    }
+    *dx_out = (float*)cur;
     return CFM_OK;
 }

@@ -127,21 +127,14 @@ class ConformerEncoder(nn.Module):
         return self
 
     def forward(self, inputs, input_lengths, decoding_chunk_size=0, num_decoding_chunk_size=-1):
+        if self.training:
+            # train mode (encoder.py:54-75 under module.train()): an accumulation window of one micro-batch
+            return self.forward_window([(inputs, input_lengths)], decoding_chunk_size, num_decoding_chunk_size)[0]
         inputs, cmvn = self._cmvn_args(inputs)
         cfm.require_hip(inputs, input_lengths)
         frames = inputs.size(1)
         x = self.embed.embed_frames(inputs, cmvn)
         x, pos_embed = self.position_encoding(x, 0)
-        if self.training:
-            # train mode (encoder.py:54-75 under module.train()): the same driver over the modules' autograd paths
-            from cfm import autograd as ag
-            pad_mask = cfm.valid_mask(input_lengths, x.size(1), first=6, stride=4).unsqueeze(1)
-            attn_mask = make_attn_mask(x, pad_mask, self.use_dynamic_chunk_size, self.use_dynamic_left_chunk,
-                                       decoding_chunk_size, self.static_chunk_size, num_decoding_chunk_size)
-            for block in self.encoders:
-                x, attn_mask, _, _ = block(x, attn_mask, pos_embed, pad_mask)
-            y = ag.LayerNormFn.apply(x, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
-            return y.to(inputs.dtype), pad_mask
         # (~make_pad_mask(len, T))[:, None, :][:, :, 2::2][:, :, 2::2]  ==  (6 + 4 j < len), built in one launch
         pad_mask = cfm.valid_mask(input_lengths, x.size(1), first=6, stride=4).unsqueeze(1)
         # (Tried: positional projection + mask on a side stream beside the front-end.  Under graph replay the fork/join costs more
@@ -153,6 +146,64 @@ class ConformerEncoder(nn.Module):
         # depends on which side of 1536 rows the batch falls (to rounding, 1e-3 of the output), and a batch shard no longer reproduces the batch bit for bit
         y, _ = self._run_blocks(x, attn_mask, pos_embed, pad_mask, None, 0, streaming=bool(getattr(self, "split_small_batches", False)))
         return y.to(inputs.dtype), pad_mask
+
+    def forward_window(self, batches, decoding_chunk_size=0, num_decoding_chunk_size=-1):
+        """Train mode: the micro-batches of ONE accumulation window (train.sh:36 accum_grad; the weights do not change between them) in a single
+        pass.  batches: [(inputs (B_g,T_g,F), lengths (B_g,)), ...]; returns [(outputs (B_g,T'_g,D), pad mask (B_g,1,T'_g)), ...], item g equal to
+        what `forward(*batches[g])` returns when the micro-batches are run one after the other as the reference does (encoder.py:54-75 called
+        accum_grad times; BatchNorm batch statistics per micro-batch, running statistics updated in micro-batch order; dropout masks
+        differ, as between any two calls).  The rows of all micro-batches go through the block stack TOGETHER (cfm/autograd.py EncoderStackFn:
+        the dense products, LayerNorms and the weight gradients see one [sum B_g*T'_g, D] row matrix; attention, depthwise convolution and
+        BatchNorm run per micro-batch), so a window costs about half the launches of two passes and its weight gradient is one product."""
+        if not self.training:
+            raise RuntimeError("ConformerEncoder.forward_window is the train-mode pass over an accumulation window; in eval mode call forward per batch")
+        from cfm import autograd as ag
+        from encoder_layer import _mask_args
+        layers = list(self.encoders)
+        flat = all(l.__dict__.get("_flat_leaf") is not None for l in layers)
+        if not ag.stack_supported(layers, flat):
+            # blocks the stack path does not take (other kernel sizes, parameter-free BatchNorm ...): micro-batch after micro-batch, block by block
+            outs = []
+            for inputs, lengths in batches:
+                inputs, cmvn = self._cmvn_args(inputs)
+                cfm.require_hip(inputs, lengths)
+                x, pos_embed = self.position_encoding(self.embed.embed_frames(inputs, cmvn), 0)
+                pad_mask = cfm.valid_mask(lengths, x.size(1), first=6, stride=4).unsqueeze(1)
+                attn_mask = make_attn_mask(x, pad_mask, self.use_dynamic_chunk_size, self.use_dynamic_left_chunk, decoding_chunk_size,
+                                           self.static_chunk_size, num_decoding_chunk_size)
+                for block in layers:
+                    x, attn_mask, _, _ = block(x, attn_mask, pos_embed, pad_mask)
+                y = ag.LayerNormFn.apply(x, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+                outs.append((y.to(inputs.dtype), pad_mask))
+            return outs
+        prec = cfm.resolve_precision(self)
+        rows, groups, keeps, shapes, pads = [], [], [], [], []
+        for gi, (inputs, lengths) in enumerate(batches):
+            inputs, cmvn = self._cmvn_args(inputs)
+            cfm.require_hip(inputs, lengths)
+            x, pos_embed = self.position_encoding(self.embed.embed_frames(inputs, cmvn), 0)
+            B, T, D = x.shape
+            pad_mask = cfm.valid_mask(lengths, T, first=6, stride=4).unsqueeze(1)
+            attn_mask = make_attn_mask(x, pad_mask, self.use_dynamic_chunk_size, self.use_dynamic_left_chunk, decoding_chunk_size,
+                                       self.static_chunk_size, num_decoding_chunk_size)
+            m8, m_str = _mask_args(attn_mask, B, T, T)
+            cfm.require_hip(m8)
+            rows.append(x.reshape(B * T, D))
+            groups.append((B, T, m8, m_str))
+            keeps.append(cfm.as_u8_mask(pad_mask).reshape(-1))
+            shapes.append((B, T, inputs.dtype))
+            pads.append(pad_mask)
+        x_rows = rows[0] if len(rows) == 1 else torch.cat(rows, 0)
+        x_rows = (x_rows if x_rows.dtype == torch.float32 else x_rows.float()).contiguous()
+        keep = keeps[0] if len(keeps) == 1 else torch.cat(keeps, 0)
+        params = tuple(l.__dict__["_flat_leaf"] for l in layers) if flat else tuple(p for l in layers for p in l.parameters())
+        y = ag.EncoderStackFn.apply(x_rows, self, layers, prec, groups, keep, flat, *params)
+        y = ag.LayerNormFn.apply(y, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+        outs, r0 = [], 0
+        for (B, T, dt), pad_mask in zip(shapes, pads):
+            outs.append((y[r0:r0 + B * T].view(B, T, -1).to(dt), pad_mask))
+            r0 += B * T
+        return outs
 
     def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None, abs_rows=None):
         """One streaming step.  Batch 1 as in the reference: attn_cache (L,H,Tc,2dk) or empty; returns (chunk output, new attn

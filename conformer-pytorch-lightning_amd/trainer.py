@@ -66,13 +66,18 @@ def warmup_lr(base_lr, warmup_steps, step_num):
 class DataParallelTrainer:
     def __init__(self, modules, loss_fn, lr=1e-3, warmup_steps=25000, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, accum_grad=2,
                  grad_clip=4.0, bucket_mb=25.0, process_group=None, kernels=None, always_reduce=False, broadcast_buffers=True,
-                 grad_comm_dtype=None):
+                 grad_comm_dtype=None, window_loss_fn=None):
         """modules: nn.Modules in FORWARD order (their parameters are flattened in reverse); loss_fn(batch) -> scalar loss tensor.
         always_reduce: issue the collectives even with one rank (lets a 1-GPU box rehearse the RCCL path).
         broadcast_buffers: rank 0's float buffers overwrite every rank's before each optimizer step's first forward (DDP's default).
-        grad_comm_dtype: None (f32 all-reduce) or torch.bfloat16 / torch.float16 (16-bit bucket payloads)."""
+        grad_comm_dtype: None (f32 all-reduce) or torch.bfloat16 / torch.float16 (16-bit bucket payloads).
+        window_loss_fn(micro_batches) -> [loss per micro-batch]: the whole accumulation window in ONE forward / backward (the weights do not
+        change between the micro-batches of a window, so their rows can share every row-local launch: ConformerEncoder.forward_window); the
+        gradients are the same sums the micro-batch loop accumulates, BatchNorm statistics stay per micro-batch.  Without it: loss_fn per
+        micro-batch, `no_sync` on all but the last, as the reference's Lightning loop does."""
         self.modules = list(modules)
         self.loss_fn = loss_fn
+        self.window_loss_fn = window_loss_fn
         self.base_lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
         self.accum_grad, self.grad_clip = int(accum_grad), grad_clip
         self.kernels = kernels if kernels is not None else HipStepKernels()
@@ -284,13 +289,26 @@ class DataParallelTrainer:
         self.reduce_log = []
         if self.broadcast_buffers and self._collective():
             self._broadcast_buffers()                                       # DDP broadcast_buffers=True: rank 0's running statistics
-        for i, mb in enumerate(micro_batches):
-            self._sync = i == self.accum_grad - 1                          # no_sync on all but the last micro-batch
+        if self.window_loss_fn is not None:
+            self._sync = True                                              # one backward for the window: every bucket is reduced as it completes
             self._ready = [0] * len(self.buckets)
             self._next = 0
-            loss = self.loss_fn(mb)
-            (loss / self.accum_grad).backward()
-            total = loss.detach() if total is None else total + loss.detach()
+            losses = self.window_loss_fn(micro_batches)
+            if len(losses) != self.accum_grad:
+                raise ValueError("window_loss_fn returned %d losses for %d micro-batches" % (len(losses), self.accum_grad))
+            total = losses[0]
+            for l in losses[1:]:
+                total = total + l
+            (total / self.accum_grad).backward()
+            total = total.detach()
+        else:
+            for i, mb in enumerate(micro_batches):
+                self._sync = i == self.accum_grad - 1                      # no_sync on all but the last micro-batch
+                self._ready = [0] * len(self.buckets)
+                self._next = 0
+                loss = self.loss_fn(mb)
+                (loss / self.accum_grad).backward()
+                total = loss.detach() if total is None else total + loss.detach()
         self._sync = False
         while self._next < len(self.buckets):                               # parameters that took no part in this graph: still reduce
             self._launch(self._next)

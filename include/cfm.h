@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFM_VERSION 203 /* 0.2.3: cfm_ffn_split, cfm_layer_scratch.psum (the feed-forward split over FF for few rows). 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
+#define CFM_VERSION 300 /* 0.3.0: row groups in the train entry points (cfm_train_group, cfm_layer_train_io.n_groups), cfm_gemm_tn_group + deferred weight gradients, cfm_encoder_train_forward / _backward (the whole stack from one host call). 0.2.3: cfm_ffn_split, cfm_layer_scratch.psum (the feed-forward split over FF for few rows). 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
 
 typedef void* cfm_stream_t;
 
@@ -312,6 +312,10 @@ typedef struct {
 } cfm_attn_desc;
 
 int cfm_attention(const cfm_attn_desc* d, cfm_stream_t stream);
+/* n attention problems in ONE launch: the micro-batches of a training window (cfm_train_group) differ in B, T and mask, and none fills the
+ * chip alone.  Grouped when every problem takes the d_k = 64 fast path without a positional term (16-bit K/V, same mask kind), n <= 8;
+ * otherwise one launch each, in order.  Results are those of n calls of cfm_attention. */
+int cfm_attention_group(const cfm_attn_desc* descs, int32_t n, cfm_stream_t stream);
 
 /* new_cache[b,h,t,0:dk] = K_t, [dk:2dk] = V_t with rows t < Tc copied from old_cache and rows t >= Tc
  * taken from (k,v) (same addressing as cfm_attn_desc).  f32 output [B,H,Tc+Tn,2dk].
@@ -547,6 +551,16 @@ int cfm_layernorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const fl
 int cfm_glu_bwd(const void* u, int32_t u_dtype, const void* dg, int32_t dg_dtype, void* du, int32_t du_dtype, int64_t M, int32_t D,
                 cfm_stream_t stream);
 
+/* One micro-batch of an accumulation window (train.sh:36 accum_grad; src/executor.py:151): B utterances of T frames whose rows start at row0
+ * of the window's row matrices.  Groups are contiguous: row0 of group i+1 = row0 of group i + B*T. */
+#define CFM_TRAIN_MAX_GROUPS 8
+typedef struct {
+    int32_t B, T;
+    int64_t row0;
+    const uint8_t* attn_mask; /* this micro-batch's attention mask, strides as cfm_layer_train_io.am_sb / am_sq */
+    int64_t am_sb, am_sq;
+} cfm_train_group;
+
 /* Depthwise conv (15 taps) -> BatchNorm1d in TRAINING mode -> SiLU  (convolution.py:43-45 under module.train()):
  *   c = dw(g) + bias            -> c_out f32 [B,T,D]  (kept for the backward)
  *   batch mean / biased variance over ALL B*T rows of each channel, padded frames included
@@ -570,6 +584,15 @@ int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, const float* c
 /* Front-end backward (convolution.py:60-63).  cfm_col2im_relu_bwd: dcol [B*T2*F2, 9*C] = dh2 . W2 (cfm_gemm on the transposed conv2 pack,
  * K order (kt,kf,c)) -> dh1 [B,T1,F1,C] = ReLU'(h1) * (transposed im2col of dcol).  cfm_conv1_wgrad: dh1 and the fbank input x [B,T,F]
  * (global CMVN folded as in cfm_conv1_relu) -> dw [9,C] tap-major, db [C]. */
+/* The same two entry points over the micro-batches of a training window (cfm_train_group; csrc/train_layer.cpp): g / c / s / ds / dg / dy_ws are the
+ * window's [M, D] row matrices, stats is [n_groups][4*D]; every stage is ONE launch for all micro-batches, each with its own batch statistics,
+ * the running statistics updated micro-batch after micro-batch.  ws: the sum of cfm_dwconv_bn_ws over the groups. */
+int cfm_dwconv_bn_train_groups(const void* g, int32_t g_dtype, const float* w, const float* dw_bias, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* c_out, float* stats, void* s_out,
+                               int32_t s_dtype, float* ws, const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, cfm_stream_t stream);
+int cfm_dwconv_bn_train_bwd_groups(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
+                                   void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
+                                   const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream);
 int cfm_col2im_relu_bwd(const void* dcol, int32_t dcol_dtype, const void* h1, int32_t h1_dtype, void* dh1, int32_t dh1_dtype, int32_t B, int32_t T1,
                         int32_t F1, int32_t C, cfm_stream_t stream);
 int64_t cfm_conv1_wgrad_ws(int32_t B, int32_t T, int32_t C);
@@ -600,6 +623,8 @@ typedef struct {
     uint32_t drop_seed;
 } cfm_attn_bwd_desc;
 int cfm_attention_bwd(const cfm_attn_bwd_desc* d, cfm_stream_t stream);
+/* n backward problems in three launches (delta, dq, dkv over all of them) when every one takes the d_k = 64 / 16-bit kernels; else one by one. */
+int cfm_attention_bwd_group(const cfm_attn_bwd_desc* descs, int32_t n, cfm_stream_t stream);
 /* d_k = 64 with 16-bit, 16-byte-aligned q / k / v / dO rows and no mask or a key-validity mask (m_sq == 0) takes fast kernels (tiles staged as
  * they lie in memory, transposed operands read with ds_read_b64_tr_b16, next tile prefetched) -- bit-identical to the general ones, which
  * this switch forces (tests). */
@@ -703,6 +728,7 @@ typedef struct {
     float bn_momentum, bn_eps;
 } cfm_layer_train_weights;
 
+
 typedef struct {
     int32_t B, T, D, H, FF, ktaps, act_dtype, w_dtype;
     const uint8_t* attn_mask;
@@ -719,6 +745,17 @@ typedef struct {
      * training batch sizes no single kernel fills the chip; the main stream waits for the side stream before the call's work is
      * complete from its point of view (an event wait, not a host synchronisation).  NULL: everything on `stream`. */
     cfm_stream_t side_stream;
+    /* ROW GROUPS (optional; n_groups = 0: one micro-batch B x T with attn_mask / am_sb / am_sq above).  The micro-batches of an accumulation
+     * window concatenated along the row axis: every row matrix has M = sum B_g*T_g rows, pad_valid has M entries, lse / delta are the groups'
+     * [B_g,H,T_g] arrays one after the other, stats is [n_groups][4*D].  Row-local work (dense products, LayerNorm, their backward, the
+     * weight gradients) runs once over all rows; attention, the depthwise convolution and BatchNorm run per group, BatchNorm's running
+     * statistics updated group after group -- the reference's sequence of forward passes over those micro-batches.  host array. */
+    int32_t n_groups;
+    const cfm_train_group* groups;
+    /* backward: keep the operands of the block's eight weight-gradient products until its last launch and issue them as ONE
+     * cfm_gemm_tn_group (needs the dz2 / dyb2..4 scratch buffers and, for pos_bias_u, grads.qkv_bias_off2; 16-bit modes -- ignored in the
+     * f32-accurate mode and with a side stream). */
+    int32_t defer_wgrad;
 } cfm_layer_train_io;
 
 typedef struct {
@@ -742,6 +779,7 @@ typedef struct {
     float* pos_bias_u;
     const float* q_bias;
     const int64_t *qkv_row_off, *qkv_bias_off, *pw1_row_off, *pw1_bias_off;
+    const int64_t* qkv_bias_off2; /* optional: int64 [3D], entry n < D = offset of pos_bias_u[n] relative to slab, others -1 (cfm_gemm_tn_desc.colsum_off2) */
 } cfm_layer_train_grads;
 
 int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
@@ -749,6 +787,22 @@ int cfm_encoder_layer_train_forward(const cfm_layer_train_weights* w, const cfm_
 int cfm_encoder_layer_train_backward(const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
                                      const cfm_layer_train_scratch* t, const cfm_layer_train_grads* g, const float* x_in, const float* dy, float* dx,
                                      cfm_stream_t stream);
+
+/* The whole block stack in train mode (src/encoder.py:72-73 `for block in self.encoders` under module.train()) from ONE host call each way.
+ *   w, sv, g  arrays of n_layers structs; io, t shared by all blocks (layer l's dropout seed is derived from io->seed and l)
+ *   xs        n_layers + 1 f32 [M,D] row matrices: xs[0] the stack's input, xs[l+1] block l's output (kept: block l+1's backward reads xs[l+1])
+ * backward: dy = gradient of xs[n_layers]; dbuf0 / dbuf1 two f32 [M,D] work buffers, *dx_out is set to the one holding the gradient of xs[0].
+ * `done(l, user)` (optional) is called on the host right after block l's backward launches have been enqueued, last block first -- the
+ * data-parallel trainer starts that block's gradient bucket all-reduce from it (DDP's reducer hook, executor.py:137-154).
+ * t is an array of n_scratch (1 or 2) scratch sets, block l uses set l & 1.  With io->defer_wgrad AND io->side_stream (two sets needed) each
+ * block's grouped weight-gradient launch runs on the side stream beside the next block's chain of input gradients; `done(l)` is then
+ * reported one block late, after the main stream has been made to wait for block l's launch, and the call ends with the streams joined. */
+typedef void (*cfm_layer_done_fn)(int32_t layer, void* user);
+int cfm_encoder_train_forward(int32_t n_layers, const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                              const cfm_layer_train_scratch* t, float* const* xs, cfm_stream_t stream);
+int cfm_encoder_train_backward(int32_t n_layers, const cfm_layer_train_weights* w, const cfm_layer_train_io* io, const cfm_layer_train_saved* sv,
+                               const cfm_layer_train_scratch* t, int32_t n_scratch, const cfm_layer_train_grads* g, float* const* xs, const float* dy,
+                               float* dbuf0, float* dbuf1, cfm_layer_done_fn done, void* user, float** dx_out, cfm_stream_t stream);
 
 /* Optimizer step over flat f32 buffers (module.py:140-143 Adam; executor.py:150 gradient_clip_val):  g' = g * (*grad_scale) + wd * p;
  * m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)   (torch.optim.Adam).

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(cfm):
     assert len(names) >= 20 and "cfm_gemm" in names and "cfm_ffn_fused" in names and "cfm_encoder_layer_forward" in names
     for n in names:
         assert hasattr(lib, n), "libconformer_gfx950.so does not export %s" % n
-    assert lib.cfm_version() == 203
+    assert lib.cfm_version() == 300
     assert isinstance(lib.cfm_last_error(), bytes)
 
 
@@ -46,7 +46,7 @@ def test_ctypes_structs_match_c_sizes(cfm, tmp_path):
                "cfm_gemm_tn_desc": cfm.GemmTnDesc, "cfm_attn_bwd_desc": cfm.AttnBwdDesc, "cfm_rowchain_desc": cfm.RowChainDesc,
                "cfm_layer_train_weights": cfm.LayerTrainWeights, "cfm_layer_train_io": cfm.LayerTrainIO, "cfm_layer_train_saved": cfm.LayerTrainSaved,
                "cfm_layer_train_scratch": cfm.LayerTrainScratch, "cfm_layer_train_grads": cfm.LayerTrainGrads,
-               "cfm_ln_bwd_desc": cfm.LnBwdDesc, "cfm_greedy_desc": cfm.GreedyDesc, "cfm_ffn_split_desc": cfm.FfnSplitDesc}
+               "cfm_ln_bwd_desc": cfm.LnBwdDesc, "cfm_train_group": cfm.TrainGroup, "cfm_greedy_desc": cfm.GreedyDesc, "cfm_ffn_split_desc": cfm.FfnSplitDesc}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "cfm.h"\nint main(){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in structs) + "return 0;}\n")
@@ -59,7 +59,7 @@ def test_ctypes_structs_match_c_sizes(cfm, tmp_path):
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "c.c"
-    src.write_text('#include "cfm.h"\nint main(void){return CFM_VERSION == 203 ? 0 : 1;}\n')
+    src.write_text('#include "cfm.h"\nint main(void){return CFM_VERSION == 300 ? 0 : 1;}\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "c")], check=True)
 
 

@@ -15,6 +15,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+STRUCT_ZERO = ("linear_k.bias", "pos_bias_v", "linear_pos.weight", "depthwise_conv.bias")      # tests/test_train_modules_gpu.py
+
+
 def build(meta, seed_shift=0):
     import decoder
     import encoder
@@ -31,6 +34,13 @@ def make_loss(enc, dec):
     return loss_fn
 
 
+def make_window_loss(enc, dec):
+    def window_loss_fn(window):
+        outs = enc.forward_window([(mb[0], mb[1]) for mb in window])
+        return [dec(y, m.squeeze(1).sum(1), mb[2], mb[3]) for (y, m), mb in zip(outs, window)]
+    return window_loss_fn
+
+
 def micro_batches(n, seed):
     import trainer as T
     rs = np.random.RandomState(seed)
@@ -41,8 +51,8 @@ def micro_batches(n, seed):
     return out
 
 
-@pytest.mark.parametrize("use_pg", [False, True])
-def test_trainer_step_equals_plain_autograd_step(use_pg):
+@pytest.mark.parametrize("use_pg,window", [(False, False), (True, False), (False, True), (True, True)])
+def test_trainer_step_equals_plain_autograd_step(use_pg, window):
     import cfm
     import trainer as T
     import torch.distributed as dist
@@ -58,7 +68,7 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
         steps, accum, clip, lr, warmup = 3, 2, 4.0, 1e-3, 2
         data = [micro_batches(accum, 500 + s) for s in range(steps)]
         tr = T.DataParallelTrainer([enc, dec], make_loss(enc, dec), lr=lr, warmup_steps=warmup, accum_grad=accum, grad_clip=clip, bucket_mb=1.0,
-                                   always_reduce=use_pg)
+                                   always_reduce=use_pg, window_loss_fn=make_window_loss(enc, dec) if window else None)
         assert len(tr.buckets) >= 4 and tr.params[0] is dec.ctc_lo.bias
         params_r = list(enc_r.parameters()) + list(dec_r.parameters())
         opt = torch.optim.Adam(params_r, lr=lr)
@@ -91,6 +101,10 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
             assert abs(float(loss) - tot / accum) < 1e-5 * abs(tot / accum)
             assert abs(float(tr.last_grad_norm) - float(norm)) < 1e-4 * float(norm)
             for ((k, a), b), a0 in zip(zip(named, params_r), before):
+                if window and k.endswith(STRUCT_ZERO):
+                    # gradients that are zero in exact arithmetic hold rounding noise, and Adam turns the noise's SIGN into a full +-lr step.  The
+                    # window sums its rows in another order than two passes do, so the noise differs -- in any implementation
+                    continue
                 upd = float((b - a0).abs().max())                       # how far torch's step moved this parameter
                 worst = max(worst, (float((a - b).abs().max()) / max(upd, 1e-12), k))
             for k in bufs:
@@ -98,7 +112,10 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
                     assert float((bufs[k] - bufs_r[k]).abs().max()) < 1e-6, k
         print("  trainer step vs plain autograd + clip_grad_norm_ + torch Adam: worst |difference| / |update| = %.3e (%s)" % worst)
         # torch keeps the Adam moments of ITS trajectory, the trainer of its own: identical by construction here (same gradients every step)
-        assert worst[0] < 3e-4, worst                               # measured 1.5e-4 (round 2 and round 3 boxes)
+        # micro-batch loop: measured 1.5e-4 (round 2 and round 3 boxes).  Window: its gradients equal the loop's to 6e-7 of the largest entry
+        # (tests/test_train_modules_gpu.py::test_accumulation_window_equals_sequential_micro_batches) -- the order of f32 sums -- and Adam's
+        # first steps move an element by lr * g / (|g| + eps): entries with |g| ~ 1e-6 max|g| turn that noise into a per-cent of lr (measured 6.7e-3)
+        assert worst[0] < (2e-2 if window else 3e-4), worst
     finally:
         if use_pg:
             dist.destroy_process_group()
@@ -106,8 +123,9 @@ def test_trainer_step_equals_plain_autograd_step(use_pg):
         cfm.set_deterministic(False)
 
 
+@pytest.mark.parametrize("window", [False, True])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_trainer_bf16_loss_goes_down(p_drop):
+def test_trainer_bf16_loss_goes_down(p_drop, window):
     """20 optimizer steps on a fixed pair of micro-batches in the headline dtype, without and WITH the reference's dropout 0.1 (train.sh):
     the loss must fall (the step is wired end to end)."""
     import cfm
@@ -117,10 +135,11 @@ def test_trainer_bf16_loss_goes_down(p_drop):
     meta = dict(meta, cfg=dict(meta["cfg"], dropout=p_drop, attention_dropout=p_drop, pos_enc_dropout=p_drop))
     torch.manual_seed(7)
     enc, dec = build(meta)
-    tr = T.DataParallelTrainer([enc, dec], make_loss(enc, dec), lr=2e-3, warmup_steps=5, accum_grad=2, grad_clip=4.0)
+    tr = T.DataParallelTrainer([enc, dec], make_loss(enc, dec), lr=2e-3, warmup_steps=5, accum_grad=2, grad_clip=4.0,
+                               window_loss_fn=make_window_loss(enc, dec) if window else None)
     data = micro_batches(2, 777)
     losses = [float(tr.step(data)) for _ in range(20)]
-    print("  bf16 training loss (dropout %.1f): %.3f -> %.3f" % (p_drop, losses[0], losses[-1]))
+    print("  bf16 training loss (dropout %.1f, %s): %.3f -> %.3f" % (p_drop, "one pass per accumulation window" if window else "micro-batch loop", losses[0], losses[-1]))
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0]
 
 
