@@ -635,10 +635,10 @@ def stack_supported(layers, flat):
                                   l.conv_module.norm.track_running_stats == bn0.track_running_stats for l in layers))
 
 
-def _stack_weights(owner, layers, prec):
+def _stack_weights(owner, layers, prec, flat):
     """ctypes array of the blocks' weight structs (cached while the packs stay the same objects)."""
     rel = layers[0].use_relative
-    pks = tuple(packing.pack_layer_train(l, prec, rel) for l in layers)
+    pks = packing.pack_stack_train(owner, layers, prec, rel, flat) if USE_PACK_KERNEL else tuple(packing.pack_layer_train(l, prec, rel) for l in layers)
     hit = owner.__dict__.get("_stack_w")
     if hit is not None and len(hit[0]) == len(pks) and all(a is b for a, b in zip(hit[0], pks)):
         return hit[1], pks
@@ -685,7 +685,7 @@ class EncoderStackFn(torch.autograd.Function):
             raise RuntimeError("EncoderStackFn: rows must be contiguous float32 (%d,%d), got %s %s" % (M, D, tuple(x.shape), x.dtype))
         if G > 8:
             raise RuntimeError("EncoderStackFn: at most 8 micro-batches per window")
-        w_arr, pks = _stack_weights(owner, layers, prec)
+        w_arr, pks = _stack_weights(owner, layers, prec, flat)
         esz = 4 if adt == torch.float32 else 2
         widths = dict(xn1=D, z1=FF, h1=FF, xn2=D, qkv=3 * D, ctx=D, xn3=D, u=2 * D, glu=D, s=D, xn4=D, z2=FF, h2=FF)
         per_act = M * sum(widths.values())

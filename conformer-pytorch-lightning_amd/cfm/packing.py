@@ -342,27 +342,35 @@ class _LayerPackPlan:
     def valid_for(self, prec):
         return prec.name == self.prec.name and tuple(t.data_ptr() for t in self.srcs) == self.ptrs
 
-    def run(self, layer):
+    def run(self, layer, launch=True, vectors=None):
+        """launch=False: the matrices were packed by a launch covering several blocks (_StackPackPlan); vectors = (qkv_b, pw1_b) likewise."""
         prec = self.prec
-        _c.check(_c.lib().cfm_pack_matrices(self.jobs.data_ptr(), self.jobs.shape[0], self.tiles, _c.BF16 if prec.split else prec.w_code, 1 if prec.split else 0,
-                                            _c.stream()), "cfm_pack_matrices")
+        if launch:
+            _c.check(_c.lib().cfm_pack_matrices(self.jobs.data_ptr(), self.jobs.shape[0], self.tiles, _c.BF16 if prec.split else prec.w_code, 1 if prec.split else 0,
+                                                _c.stream()), "cfm_pack_matrices")
         ffm, att, cv, ff = layer.feed_forward_macaron, layer.self_attn, layer.conv_module, layer.feed_forward
         o = self.out
 
         def ffn(mod, pre):
             (w1, w1l, w1t, w1tl), (w2, w2l, w2t, w2tl) = o[pre + "_w1"], o[pre + "_w2"]
             return Packed(w1=w1, w1_lo=w1l, b1=f32(mod.w_1.bias), w2=w2, w2_lo=w2l, b2=f32(mod.w_2.bias), w1t=w1t, w1t_lo=w1tl, w2t=w2t, w2t_lo=w2tl)
-        bq = att.linear_q.bias.detach().float()
-        if self.relative:
-            bq = bq + att.pos_bias_u.detach().float().reshape(-1)
-        qkv_b = torch.cat([bq, att.linear_k.bias.detach().float(), att.linear_v.bias.detach().float()], 0).contiguous()
+        if vectors is not None:
+            qkv_b = vectors[0]
+        else:
+            bq = att.linear_q.bias.detach().float()
+            if self.relative:
+                bq = bq + att.pos_bias_u.detach().float().reshape(-1)
+            qkv_b = torch.cat([bq, att.linear_k.bias.detach().float(), att.linear_v.bias.detach().float()], 0).contiguous()
         (qkv, qkvl, qkvt, qkvtl), (out, outl, outt, outtl) = o["qkv"], o["out"]
         pa = Packed(qkv_w=qkv, qkv_w_lo=qkvl, qkv_t=qkvt, qkv_t_lo=qkvtl, qkv_b=qkv_b, out_w=out, out_w_lo=outl, out_t=outt, out_t_lo=outtl,
                     out_b=f32(att.linear_out.bias))
         D = cv.pointwise_conv2.weight.shape[0]
         dev = qkv.device
         bn = cv.norm
-        b1 = (cv.pointwise_conv1.bias.detach() if cv.pointwise_conv1.bias is not None else torch.zeros(2 * D, device=dev))[self.idx]
+        if vectors is not None:
+            b1 = vectors[1]
+        else:
+            b1 = (cv.pointwise_conv1.bias.detach() if cv.pointwise_conv1.bias is not None else torch.zeros(2 * D, device=dev))[self.idx]
         dwb = cv.depthwise_conv.bias.detach() if cv.depthwise_conv.bias is not None else torch.zeros(D, device=dev)
         gamma = bn.weight.detach() if bn.weight is not None else torch.ones(D, device=dev)
         beta = bn.bias.detach() if bn.bias is not None else torch.zeros(D, device=dev)
@@ -388,6 +396,75 @@ def pack_layer_train(layer, prec, relative):
         plan = st[1] if st is not None and st[1].valid_for(prec) else _LayerPackPlan(layer, prec, relative)
         val = plan.run(layer)
     layer.__dict__["_pack_layer_train"] = (key, plan, val)
+    return val
+
+
+class _StackPackPlan:
+    """The training packs of ALL blocks of an encoder in two launches per optimizer step -- the blocks' matrix jobs in one table
+    (cfm_pack_matrices), their two small gathered vectors (fused q|k|v bias + pos_bias_u, interleaved pointwise-conv-1 bias) through
+    element-pointer tables (cfm_pack_vectors) -- instead of one matrix launch and ~4 torch operations per block (12 blocks: 60 launches)."""
+
+    def __init__(self, layers, prec, relative):
+        self.plans = [_LayerPackPlan(l, prec, relative) for l in layers]
+        dev = self.plans[0].jobs.device
+        tables, off = [], 0
+        for pl in self.plans:
+            j = pl.jobs.clone()
+            j[:, 7] += off
+            off += pl.tiles
+            tables.append(j)
+        self.jobs, self.tiles = torch.cat(tables, 0).contiguous(), off
+        pa, pb, self.vec_slices, n = [], [], [], 0
+        el = lambda t: t.data_ptr() + 4 * torch.arange(t.numel(), device=dev, dtype=torch.int64)
+        for l, pl in zip(layers, self.plans):
+            att, cv = l.self_attn, l.conv_module
+            D = cv.pointwise_conv2.weight.shape[0]
+            for t in (att.linear_q.bias, att.linear_k.bias, att.linear_v.bias, cv.pointwise_conv1.bias) + ((att.pos_bias_u,) if relative else ()):
+                if t is None or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise TypeError("the stack pack needs contiguous float32 bias parameters")
+            zeros = torch.zeros(D, device=dev, dtype=torch.int64)
+            pa += [el(att.linear_q.bias), el(att.linear_k.bias), el(att.linear_v.bias), el(cv.pointwise_conv1.bias)[pl.idx]]
+            pb += [el(att.pos_bias_u) if relative else zeros, zeros, zeros, zeros, zeros]
+            self.vec_slices.append((n, n + 3 * D, n + 5 * D))
+            n += 5 * D
+        self.pa, self.pb = torch.cat(pa).contiguous(), torch.cat(pb).contiguous()
+        self.vec = torch.empty(n, dtype=torch.float32, device=dev)
+        self.prec, self.layers, self.val = prec, list(layers), None
+        self.srcs = [t for pl in self.plans for t in pl.srcs]
+        self.ptrs = tuple(t.data_ptr() for l in layers for t in l.parameters())
+
+    def valid_for(self, layers, prec):
+        return (prec.name == self.prec.name and len(layers) == len(self.layers) and all(a is b for a, b in zip(layers, self.layers)) and
+                tuple(t.data_ptr() for l in layers for t in l.parameters()) == self.ptrs)
+
+    def run(self):
+        prec = self.prec
+        _c.check(_c.lib().cfm_pack_matrices(self.jobs.data_ptr(), self.jobs.shape[0], self.tiles, _c.BF16 if prec.split else prec.w_code, 1 if prec.split else 0,
+                                            _c.stream()), "cfm_pack_matrices")
+        _c.check(_c.lib().cfm_pack_vectors(self.pa.data_ptr(), self.pb.data_ptr(), self.vec.data_ptr(), self.vec.numel(), _c.stream()), "cfm_pack_vectors")
+        if self.val is None:        # the destinations never move (valid_for checks the sources' addresses): the same Packed objects every step, so
+            # whoever caches on their identity (the stack's ctypes weight structs, cfm/autograd.py) keeps its cache across optimizer steps
+            self.val = tuple(pl.run(l, launch=False, vectors=(self.vec[a:b], self.vec[b:c])) for l, pl, (a, b, c) in zip(self.layers, self.plans, self.vec_slices))
+        return self.val
+
+
+def pack_stack_train(owner, layers, prec, relative, flat=False):
+    """((macaron FFN, attention, conv module, FFN) training packs) per block for the whole stack, two launches when anything changed.
+    flat: every parameter lives in the data-parallel trainer's flat buffer and changes only through its step (which bumps the pack epoch) --
+    the per-tensor version walk (~300 tensors) is skipped."""
+    st = owner.__dict__.get("_pack_stack_train")
+    if flat and st is not None and st[0][:3] == ("flat", prec.name, _EPOCH[0]) and st[1].valid_for(layers, prec):
+        return st[2]
+    if flat:
+        key = ("flat", prec.name, _EPOCH[0])
+    else:
+        key = ("walk",) + _key([p for l in layers for n, p in l.named_parameters() if not n.startswith("norm_")], prec)
+        if st is not None and st[0] == key:
+            return st[2]
+    with torch.no_grad():
+        plan = st[1] if st is not None and st[1].valid_for(layers, prec) else _StackPackPlan(layers, prec, relative)
+        val = plan.run()
+    owner.__dict__["_pack_stack_train"] = (key, plan, val)
     return val
 
 

@@ -737,8 +737,11 @@ __global__ void cfm_dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, Cf
 // 16-byte pieces along their own fast axis.  Job = 8 x int64: rows, N, K, dst, dst_lo, dst_t, dst_t_lo, first tile.
 __global__ __launch_bounds__(256) void cfm_pack_kernel(const int64_t* __restrict__ jobs, int n_jobs, int dt, int split) {
     __shared__ float tile[64][65];
-    int j = 0;
-    while (j + 1 < n_jobs && jobs[(j + 1) * 8 + 7] <= (int64_t)blockIdx.x) ++j;     // uniform
+    int j = 0, hi = n_jobs;                                                           // last job whose first tile is <= blockIdx.x (uniform)
+    while (hi - j > 1) {
+        const int mid = (j + hi) >> 1;
+        if (jobs[mid * 8 + 7] <= (int64_t)blockIdx.x) j = mid; else hi = mid;
+    }
     const int64_t* job = jobs + j * 8;
     const float* const* rows = (const float* const*)job[0];
     const int N = (int)job[1], K = (int)job[2];
@@ -781,6 +784,16 @@ __global__ __launch_bounds__(256) void cfm_pack_kernel(const int64_t* __restrict
             emit(dst_t + o, dst_t_lo + o, a, b);
         }
     }
+}
+
+// Small f32 vectors of the training packs in one launch for a whole stack: out[i] = *a[i] + (b[i] ? *b[i] : 0) through two tables of element
+// pointers -- the fused q|k|v bias (linear_q.bias + pos_bias_u | linear_k.bias | linear_v.bias, attention.py:62-64,81) and the GLU-interleaved
+// pointwise-conv-1 bias are gathers of parameter elements whose addresses never move (the optimizer writes in place).
+__global__ void cfm_pack_vectors_kernel(const float* const* __restrict__ a, const float* const* __restrict__ b, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* pb = b[i];
+    out[i] = *a[i] + (pb ? *pb : 0.f);
 }
 
 inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
@@ -1023,12 +1036,20 @@ extern "C" int cfm_dropout_rows(const void* x, int32_t x_dtype, void* y, int32_t
 }
 
 extern "C" int cfm_pack_matrices(const int64_t* jobs_dev, int32_t n_jobs, int64_t total_tiles, int32_t w_dtype, int32_t split, cfm_stream_t stream) {
-    CFM_CHECK_ARG(jobs_dev && n_jobs > 0 && n_jobs <= 64 && total_tiles > 0 && total_tiles < ((int64_t)1 << 31), "cfm_pack_matrices: bad arguments (at most 64 jobs)");
+    CFM_CHECK_ARG(jobs_dev && n_jobs > 0 && n_jobs <= 512 && total_tiles > 0 && total_tiles < ((int64_t)1 << 31), "cfm_pack_matrices: bad arguments (at most 512 jobs)");
     CFM_CHECK_ARG(split ? w_dtype == CFM_BF16 : cfm_is16(w_dtype), "cfm_pack_matrices: 16-bit destination type (split: bf16 hi/lo planes)");
     hipStream_t s = (hipStream_t)stream;
     CfmProfScope prof("pack_matrices", s, 0.0, (double)total_tiles * 64 * 64 * 8);
     CFM_LAUNCH(cfm_pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, jobs_dev, n_jobs, w_dtype, split);
     return cfm_launch_status("cfm_pack_matrices");
+}
+
+extern "C" int cfm_pack_vectors(const float* const* a, const float* const* b, float* out, int64_t n, cfm_stream_t stream) {
+    CFM_CHECK_ARG(a && b && out && n > 0 && n < ((int64_t)1 << 31), "cfm_pack_vectors: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    CfmProfScope prof("pack_vectors", s, 0.0, (double)n * 28);
+    CFM_LAUNCH(cfm_pack_vectors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
+    return cfm_launch_status("cfm_pack_vectors");
 }
 
 extern "C" int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream_t stream) {

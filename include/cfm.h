@@ -699,6 +699,10 @@ int cfm_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, cfm_stream
  * Replaces the per-step torch casts / transposes of cfm/packing.py (what the reference's optimizer step makes necessary: the kernels
  * read 16-bit copies of the f32 master weights). */
 int cfm_pack_matrices(const int64_t* jobs_dev, int32_t n_jobs, int64_t total_tiles, int32_t w_dtype, int32_t split, cfm_stream_t stream);
+/* out[i] = *a[i] + (b[i] ? *b[i] : 0), i < n: the small f32 vectors of the training packs of a whole block stack in one launch (the fused
+ * q|k|v bias with pos_bias_u added to its first third, attention.py:62-64,81; the GLU-interleaved pointwise-conv-1 bias, convolution.py:41-42)
+ * as gathers through two device tables of element pointers. */
+int cfm_pack_vectors(const float* const* a, const float* const* b, float* out, int64_t n, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * One conformer block in TRAIN mode as two host calls (csrc/train_layer.cpp): encoder_layer.py:49-71 under module.train() and its
