@@ -9,7 +9,7 @@ import torch
 import cfm as _c
 
 __all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "gemm_tn_group", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
-           "ctc_nll_train", "ctc_grad", "ffn_split", "adam_step", "sumsq", "scratch_stats",
+           "ctc_nll_train", "ctc_grad", "ffn_split", "adam_step", "adam_clip_step", "sumsq", "scratch_stats",
            "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "conv12_relu", "conv12_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
@@ -710,6 +710,20 @@ def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=None):
             raise ValueError("cfm.adam_step: p, g, m, v must be contiguous float32 buffers of one size")
     _c.check(_c.lib().cfm_adam_step(_c.ptr(p), _c.ptr(g), _c.ptr(m), _c.ptr(v), n, lr, betas[0], betas[1], eps, weight_decay, step, _c.ptr(grad_scale),
                                     _c.stream()), "cfm_adam_step")
+
+
+def adam_clip_step(p, g, m, v, lr, betas, eps, weight_decay, step, sumsq_t, clip, inv_world, zero_grad=True):
+    """adam_step with the clip coefficient computed on the device from `sumsq_t` (cfm.sumsq of g), the 1/world averaging and the zeroing of g in
+    the same launch (include/cfm.h cfm_adam_clip_step).  Returns the averaged gradient's norm as a 1-element device tensor."""
+    _c.require_hip(p, g, m, v, sumsq_t)
+    n = p.numel()
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+            raise ValueError("cfm.adam_clip_step: p, g, m, v must be contiguous float32 buffers of one size")
+    norm = torch.empty((1,), dtype=torch.float32, device=p.device)
+    _c.check(_c.lib().cfm_adam_clip_step(_c.ptr(p), _c.ptr(g), _c.ptr(m), _c.ptr(v), n, lr, betas[0], betas[1], eps, weight_decay, step, _c.ptr(sumsq_t),
+                                         float(clip or 0.0), float(inv_world), 1 if zero_grad else 0, _c.ptr(norm), _c.stream()), "cfm_adam_clip_step")
+    return norm
 
 
 def sumsq(x):

@@ -655,6 +655,10 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
             // choice a batch of 2 would no longer reproduce the first two utterances of a batch of 16 bit for bit (the tile follows M)
             if constexpr (!A_F32 && !CONV) {
                 if (kgroups_ok && (tile == 5 || tile == 3) && a.K >= 1024 && t64 <= 512) tile = 11;
+                // an accumulation WINDOW of micro-batches (round 3: M ~ 2 800 .. 4 800 rows per launch): wide outputs over a short K have enough
+                // 64 x 64 tiles for several per CU and half the L2 bytes per FLOP of 32 x 64 -- measured (scripts/bench_gemm_tiles.py) at
+                // M = 3 400 / 4 400: N = 2 048: 13.9 / 17.8 us against 15.9 / 18.8; N = 768: 7.7 / 8.7 against 8.6 / 9.8; narrower outputs keep 32 x 64
+                if (kgroups_ok && tile == 5 && a.K <= 256 && ((a.N >= 1024 && t64 >= 1400) || (a.N >= 768 && t64 >= 600))) tile = 3;
             }
         }
     }

@@ -51,6 +51,11 @@ class HipStepKernels:
         import cfm
         cfm.adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=grad_scale)
 
+    def adam_clip_step(self, p, g, m, v, lr, betas, eps, weight_decay, step, clip, inv_world):
+        """sum of squares, then ONE launch: clip coefficient from it, 1/world averaging, Adam, gradient buffer zeroed.  Returns the norm."""
+        import cfm
+        return cfm.adam_clip_step(p, g, m, v, lr, betas, eps, weight_decay, step, cfm.sumsq(g) if clip else None, clip, inv_world, zero_grad=True)
+
     def weights_changed(self):
         from cfm import packing
         packing.bump_epoch()               # the flat update bypasses torch's version counters: invalidate the packed weights
@@ -325,6 +330,15 @@ class DataParallelTrainer:
     def finish(self):
         """clip by the global norm of the AVERAGED gradient (executor.py:150), Adam, zero the gradient buffer."""
         inv_world = 1.0 / self.world if self.grad_comm_dtype is None else 1.0    # 16-bit buckets arrive averaged
+        if hasattr(self.kernels, "adam_clip_step"):                        # the HIP kernels: scalar glue and the zero-fill inside the Adam launch
+            self.step_count += 1
+            clip = self.grad_clip if (self.grad_clip is not None and self.grad_clip > 0) else 0.0
+            norm = self.kernels.adam_clip_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, warmup_lr(self.base_lr, self.warmup_steps, self.step_count),
+                                               self.betas, self.eps, self.weight_decay, self.step_count, clip, inv_world)
+            if clip:
+                self.last_grad_norm = norm
+            self.kernels.weights_changed()
+            return
         scale = None
         if self.grad_clip is not None and self.grad_clip > 0:
             norm = self.kernels.sumsq(self.flat_g).sqrt() * inv_world       # 1-element device tensors: no sync

@@ -815,6 +815,11 @@ int cfm_encoder_train_backward(int32_t n_layers, const cfm_layer_train_weights* 
 int cfm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int64_t step, const float* grad_scale, cfm_stream_t stream);
 int cfm_sumsq(const float* x, int64_t n, float* partials, int32_t n_partials, float* out, cfm_stream_t stream);
+/* cfm_adam_step with the step's scalar glue inside (executor.py:150 gradient_clip_val + Lightning DDP's gradient averaging): the gradient
+ * scale is min(1, clip / (sqrt(*sumsq) * inv_world + 1e-6)) * inv_world (clip <= 0: inv_world), computed on the device from cfm_sumsq's result;
+ * *norm_out (optional) receives the averaged gradient's norm; zero_grad != 0 zeroes g as it is read (the next step's accumulation buffer). */
+int cfm_adam_clip_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t step, const float* sumsq, float clip, float inv_world, int32_t zero_grad, float* norm_out, cfm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling table (aux subsystem: tracing).  When enabled, every kernel launch made through this

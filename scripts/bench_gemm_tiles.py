@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "conformer-pytorch-lightning_amd"))
 import cfm  # noqa: E402
 
-TILES = {0: "auto", 1: "128x128", 2: "64x128", 3: "64x64", 4: "128x64", 5: "32x64", 6: "32x128", 9: "32x64k2", 10: "64x64k4", 11: "64x64k2"}
+TILES = {-1: "auto-train", 0: "auto", 1: "128x128", 2: "64x128", 3: "64x64", 4: "128x64", 5: "32x64", 6: "32x128", 9: "32x64k2", 10: "64x64k4", 11: "64x64k2"}
 
 
 def main():
@@ -27,7 +27,7 @@ def main():
         c = torch.empty((M, N), dtype=bf, device=dev)
         bias = torch.zeros((N,), device=dev)
         row = []
-        for tile in (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 0):
+        for tile in (-1, 1, 2, 3, 4, 5, 6, 9, 10, 11):
             d = cfm.GemmDesc()
             d.A, d.W, d.C, d.bias = a.data_ptr(), w.data_ptr(), c.data_ptr(), bias.data_ptr()
             d.lda, d.ldc, d.M, d.N, d.K = K, N, M, N, K
