@@ -18,6 +18,7 @@
 //   conv   B rows may be the implicit im2col rows of a channels-last image (3x3 stride 2): the front-end's conv2 weight gradient
 //   SPLIT  f32 operands split into bf16 hi/lo planes while staging, 3 MFMAs per fragment pair (the f32-accurate mode)
 #include <math.h>
+#include <stdlib.h>
 #include <string>
 
 #include "cfm_common.h"
@@ -561,6 +562,8 @@ int plan_tn(const cfm_gemm_tn_desc* d, TnPlan& pl, int group_tiles) {
         if (group_tiles > 0) {
             // a grouped launch fills the chip with its tiles; M is split only while the whole group has fewer workgroups than ~2 per CU
             splits = (512 + group_tiles / 2) / group_tiles;
+            // (measured and dropped: splitting the SMALL products of a block's group in two so that they fill the last, partly filled round of the
+            // grid with half passes -- 59 us by the round count against 70 -- costs more in atomics than it saves: 8.49 against 8.37 ms per step)
         } else if (dma) {
             // measured optimum at M = 2 380 / 1 300 rows (profiles/r02_gemm_tn_splits.txt): 4 splits for 16 tiles, 3 for 32, 2-3 for 48, 1-2 for 128;
             // a split's cost (atomics) is fixed and its gain shrinks with the rows it removes, so the optimum grows like sqrt(M)
