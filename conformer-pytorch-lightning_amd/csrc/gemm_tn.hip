@@ -562,7 +562,9 @@ int plan_tn(const cfm_gemm_tn_desc* d, TnPlan& pl, int group_tiles) {
         if (group_tiles > 0) {
             // a grouped launch fills the chip with its tiles; M is split only while the whole group has fewer workgroups than ~2 per CU
             splits = (512 + group_tiles / 2) / group_tiles;
-            // (measured and dropped: splitting the SMALL products of a block's group in two so that they fill the last, partly filled round of the
+            // (measured and dropped, config-3 window, ms per optimizer step: 128 x 128 tiles with four wavefronts for the whole group -- 156 workgroups in
+            // one round -- 8.44 against 8.33; the same with every product split in two: 9.64, the atomics of a split cost far more than the idle CUs;
+            // splitting the SMALL products of a block's group in two so that they fill the last, partly filled round of the
             // grid with half passes -- 59 us by the round count against 70 -- costs more in atomics than it saves: 8.49 against 8.37 ms per step)
         } else if (dma) {
             // measured optimum at M = 2 380 / 1 300 rows (profiles/r02_gemm_tn_splits.txt): 4 splits for 16 tiles, 3 for 32, 2-3 for 48, 1-2 for 128;
