@@ -4,6 +4,10 @@
     python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: this file starts the N ranks itself, before any HIP call, and relays rank 0's line)
+
+--gpus is what is measured: WORLD_SIZE from a launcher must equal it (non-zero exit otherwise), N > 1 without a launcher spawns the ranks, fewer
+visible devices than N or two ranks on one physical GPU abort; the line states rccl_ranks and the device of every rank.
 
 A "step" is ONE ConformerEncoder.forward (front-end + 12 blocks + after_norm) over one batch of 32 x (80 x 1000)
 synthetic fbank already resident in HBM.  Utterances are independent, so N GPUs run N batch-sharded replicas with NO
@@ -22,6 +26,9 @@ Besides the headline value the line carries
                 launch from the PMC counters, MEASURED IN THIS RUN at N=1 (two child passes of this file under rocprofv3 --pmc, FETCH_SIZE and
                 WRITE_SIZE separately, gfx950 correction; roofline.traffic_source says how) -- a committed profile is quoted only as a
                 fallback and only when its source digest matches the library's sources, else null;
+  fp16          the same measurement in fp16 (graph, ramp, W + K steps, barriers, MAX over ranks): the precision that meets north_star's <= 1e-3
+                at bf16 speed, quotable by itself (value, ms_per_step, max_rel_err_vs_oracle, meets_north_star_1e-3);
+  train         BASELINE config 3 (optimizer steps over an accumulation window, every rank taking part) -- `--mode train` makes it the headline;
   cpu_baseline  the CPU oracle (a port of the reference's PyTorch CPU path, oracle/conformer_oracle.py) timed on the host
                 cores of the same box on a bounded sample of the same workload (rank 0, N=1 only).
 """
