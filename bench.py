@@ -109,8 +109,10 @@ def build_train_job(device, rank, precision, n_micro=8):
 
     def window_loss_fn(window):
         # the accumulation window in one pass: rows of both micro-batches through the block stack together (ConformerEncoder.forward_window)
-        outs = enc.forward_window([(mb[0], mb[1]) for mb in window])
-        return [dec(y, m.squeeze(1).sum(1), mb[2], mb[3]) for (y, m), mb in zip(outs, window)]
+        # ... and the CTC heads of the window in one vocabulary projection (CTCDecoder.forward_window)
+        rows, outs = enc.forward_window([(mb[0], mb[1]) for mb in window], return_rows=True)
+        losses = dec.forward_window(rows, [(y.size(0), y.size(1), m.squeeze(1).sum(1), mb[2], mb[3]) for (y, m), mb in zip(outs, window)])
+        return list(losses.unbind(0))
 
     tr = T.DataParallelTrainer([enc, dec], loss_fn, lr=1e-3, warmup_steps=25000, accum_grad=2, grad_clip=4.0, bucket_mb=25.0,
                                window_loss_fn=window_loss_fn if os.environ.get("CFM_TRAIN_WINDOW", "1") != "0" else None)

@@ -830,3 +830,42 @@ class CTCLossFn(torch.autograd.Function):
         dW, db = cfm.gemm_tn(dlog, x2, want_colsum=True, mma_code=prec.w_code, split=prec.split)
         dx = _gemm(dlog, pk.wt, w_lo=pk.wt_lo, out_dtype=torch.float32)
         return dx.view(B, T, D), None, None, None, None, None, dW[:pk.V], db[:pk.V]
+
+
+class CTCWindowLossFn(torch.autograd.Function):
+    """The CTC heads of an accumulation window in one projection: the window's rows are one [M, D] matrix (ConformerEncoder.forward_window), so the
+    vocabulary projection, its weight gradient and its input gradient each run ONCE over all micro-batches' rows; the recursions and the per-row
+    gradients run per micro-batch on slices of the one logits matrix (each micro-batch has its own T', label width and normaliser).
+    Returns the micro-batches' losses (sum_b nll_b / padded label length each, decoder.py:19-22) as a 1-D tensor."""
+
+    @staticmethod
+    def forward(ctx, rows, mod, prec, groups, weight, bias):
+        """rows f32 [M, D]; groups: [(B, T, enc_lens i32 [B], labels i32 [B,U], label_lens i32 [B])], rows of micro-batch g at sum of earlier B*T."""
+        pk = packing.pack_ctc_train(mod, prec)
+        x2 = _f32c(rows)
+        logits = _gemm(x2, pk.w, bias=pk.b, w_lo=pk.w_lo, out_dtype=torch.float32)
+        losses, states, r0 = [], [], 0
+        for B, T, enc_lens, labels, label_lens in groups:
+            lg = logits[r0:r0 + B * T].view(B, T, pk.Vp)
+            nll, state = cfm.ctc_nll_train(lg, pk.V, enc_lens, labels, label_lens)
+            losses.append(nll.sum() / labels.size(1))
+            states.append(state)
+            r0 += B * T
+        if r0 != x2.shape[0]:
+            raise RuntimeError("CTCWindowLossFn: the micro-batches cover %d rows, the row matrix has %d" % (r0, x2.shape[0]))
+        ctx.args = (prec, pk, x2, logits, states, groups)
+        return torch.stack(losses)
+
+    @staticmethod
+    def backward(ctx, gout):
+        prec, pk, x2, logits, states, groups = ctx.args
+        gdev = _f32c(gout.reshape(-1))
+        dlog = torch.empty_like(logits)
+        r0 = 0
+        for gi, ((B, T, enc_lens, labels, label_lens), state) in enumerate(zip(groups, states)):
+            cfm.ctc_grad(logits[r0:r0 + B * T].view(B, T, pk.Vp), pk.V, enc_lens, labels, label_lens, state, gscale=1.0 / labels.size(1),
+                         gscale_dev=gdev[gi:gi + 1], out=dlog[r0:r0 + B * T].view(B, T, pk.Vp))
+            r0 += B * T
+        dW, db = cfm.gemm_tn(dlog, x2, want_colsum=True, mma_code=prec.w_code, split=prec.split)
+        dx = _gemm(dlog, pk.wt, w_lo=pk.wt_lo, out_dtype=torch.float32)
+        return dx, None, None, None, dW[:pk.V], db[:pk.V]

@@ -566,6 +566,11 @@ int plan_tn(const cfm_gemm_tn_desc* d, TnPlan& pl, int group_tiles) {
             // one round -- 8.44 against 8.33; the same with every product split in two: 9.64, the atomics of a split cost far more than the idle CUs;
             // splitting the SMALL products of a block's group in two so that they fill the last, partly filled round of the
             // grid with half passes -- 59 us by the round count against 70 -- costs more in atomics than it saves: 8.49 against 8.37 ms per step)
+        } else if (dma && tile == 128) {
+            // one workgroup per CU is resident (128 KB of LDS): the grid runs in rounds of 256, and a partly filled second round costs a whole pass.
+            // Fill ONE round: the front-end's second convolution (36 tiles, M = 38 k rows) 159 us with 7 splits against 220 with the 11 of the
+            // rule below (396 workgroups = two rounds) and 222 with 4 (scripts/bench_conv2_wgrad.py)
+            splits = tiles >= 256 ? 1 : 256 / tiles;
         } else if (dma) {
             // measured optimum at M = 2 380 / 1 300 rows (profiles/r02_gemm_tn_splits.txt): 4 splits for 16 tiles, 3 for 32, 2-3 for 48, 1-2 for 128;
             // a split's cost (atomics) is fixed and its gain shrinks with the rows it removes, so the optimum grows like sqrt(M)

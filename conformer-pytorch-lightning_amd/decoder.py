@@ -61,3 +61,18 @@ class CTCDecoder(nn.Module):
                                       self.ctc_lo.weight, self.ctc_lo.bias)
         loss = self.nll(encoder_out, encoder_out_lens, padded_labels, label_lengths).sum()
         return loss / padded_labels.size(1)
+
+    def forward_window(self, rows, groups):
+        """Train mode: the CTC losses of an accumulation window in one projection.  rows f32 [sum B_g*T'_g, D]: the encoder outputs of the window's
+        micro-batches as ONE row matrix (ConformerEncoder.forward_window(..., return_rows=True)); groups: [(B, T', encoder_out_lens, padded_labels,
+        label_lengths)] in row order.  Returns a 1-D tensor of the micro-batches' losses, entry g equal to forward() on micro-batch g alone
+        (decoder.py:18-23; the always-on F.dropout of :19 draws one mask over all rows instead of one per micro-batch)."""
+        if not self.training:
+            raise RuntimeError("CTCDecoder.forward_window is the train-mode path; in eval mode call forward per batch")
+        from cfm import autograd as ag
+        cfm.require_hip(rows)
+        dev = rows.device
+        i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+        x = nn.functional.dropout(rows, self.dropout)                    # training=True by default, as decoder.py:19 (quirk Q7)
+        gs = [(int(B), int(T), i32(el), i32(lab), i32(ll)) for B, T, el, lab, ll in groups]
+        return ag.CTCWindowLossFn.apply(x, self, cfm.resolve_precision(self), gs, self.ctc_lo.weight, self.ctc_lo.bias)

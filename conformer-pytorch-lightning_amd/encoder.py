@@ -147,14 +147,16 @@ class ConformerEncoder(nn.Module):
         y, _ = self._run_blocks(x, attn_mask, pos_embed, pad_mask, None, 0, streaming=bool(getattr(self, "split_small_batches", False)))
         return y.to(inputs.dtype), pad_mask
 
-    def forward_window(self, batches, decoding_chunk_size=0, num_decoding_chunk_size=-1):
+    def forward_window(self, batches, decoding_chunk_size=0, num_decoding_chunk_size=-1, return_rows=False):
         """Train mode: the micro-batches of ONE accumulation window (train.sh:36 accum_grad; the weights do not change between them) in a single
         pass.  batches: [(inputs (B_g,T_g,F), lengths (B_g,)), ...]; returns [(outputs (B_g,T'_g,D), pad mask (B_g,1,T'_g)), ...], item g equal to
         what `forward(*batches[g])` returns when the micro-batches are run one after the other as the reference does (encoder.py:54-75 called
         accum_grad times; BatchNorm batch statistics per micro-batch, running statistics updated in micro-batch order; dropout masks
         differ, as between any two calls).  The rows of all micro-batches go through the block stack TOGETHER (cfm/autograd.py EncoderStackFn:
         the dense products, LayerNorms and the weight gradients see one [sum B_g*T'_g, D] row matrix; attention, depthwise convolution and
-        BatchNorm run per micro-batch), so a window costs about half the launches of two passes and its weight gradient is one product."""
+        BatchNorm run per micro-batch), so a window costs about half the launches of two passes and its weight gradient is one product.
+        return_rows: also return the outputs as ONE row matrix f32 [sum B_g*T'_g, D] (what the per-micro-batch outputs are views of) -- a head that is
+        row-local up to its loss (CTCDecoder.forward_window) then projects all micro-batches in one launch: returns (rows, outs)."""
         if not self.training:
             raise RuntimeError("ConformerEncoder.forward_window is the train-mode pass over an accumulation window; in eval mode call forward per batch")
         from cfm import autograd as ag
@@ -175,6 +177,8 @@ class ConformerEncoder(nn.Module):
                     x, attn_mask, _, _ = block(x, attn_mask, pos_embed, pad_mask)
                 y = ag.LayerNormFn.apply(x, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
                 outs.append((y.to(inputs.dtype), pad_mask))
+            if return_rows:
+                return torch.cat([y.float().reshape(-1, y.size(-1)) for y, _ in outs], 0), outs
             return outs
         prec = cfm.resolve_precision(self)
         rows, groups, keeps, shapes, pads = [], [], [], [], []
@@ -203,7 +207,7 @@ class ConformerEncoder(nn.Module):
         for (B, T, dt), pad_mask in zip(shapes, pads):
             outs.append((y[r0:r0 + B * T].view(B, T, -1).to(dt), pad_mask))
             r0 += B * T
-        return outs
+        return (y, outs) if return_rows else outs
 
     def forward_chunk(self, inputs, offset, required_cache_size, attn_cache, cnn_cache, inputs_attn_mask=_NO_MASK, pos_rows=None, abs_rows=None):
         """One streaming step.  Batch 1 as in the reference: attn_cache (L,H,Tc,2dk) or empty; returns (chunk output, new attn

@@ -211,8 +211,8 @@ WINDOW_TOL = {"fp32": 3e-6, "fp16": 3e-6, "bf16": 3e-6}     # measured: outputs 
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["train_cfg1", "train_cfg1_chunk"])
-def test_accumulation_window_equals_sequential_micro_batches(pkg, name, mode):
+@pytest.mark.parametrize("name,window_head", [("train_cfg1", False), ("train_cfg1_chunk", False), ("train_cfg1", True)])
+def test_accumulation_window_equals_sequential_micro_batches(pkg, name, mode, window_head):
     """ConformerEncoder.forward_window: two micro-batches of DIFFERENT shapes in one pass (rows concatenated, attention / depthwise /
     BatchNorm per micro-batch) against the reference's procedure -- forward + backward per micro-batch, gradients accumulated
     (train.sh:36 accum_grad 2): losses, every accumulated gradient, BatchNorm running statistics (two momentum updates, in order) and
@@ -236,7 +236,11 @@ def test_accumulation_window_equals_sequential_micro_batches(pkg, name, mode):
     def run(window):
         enc.load_state_dict(state0)
         enc.zero_grad(), dec.zero_grad()
-        if window:
+        if window and window_head:                           # the CTC heads of the window in ONE vocabulary projection (CTCDecoder.forward_window)
+            rows, ((y1, m1), (y2, m2)) = enc.forward_window([(x, lens), (x2, lens2)], return_rows=True, **fw)
+            l1, l2 = dec.forward_window(rows, [(y1.size(0), y1.size(1), m1.squeeze(1).sum(1), lab1, ll1), (y2.size(0), y2.size(1), m2.squeeze(1).sum(1), lab2, ll2)]).unbind(0)
+            ((l1 + l2) / 2).backward()
+        elif window:
             (y1, m1), (y2, m2) = enc.forward_window([(x, lens), (x2, lens2)], **fw)
             l1 = dec(y1, m1.squeeze(1).sum(1), lab1, ll1)
             l2 = dec(y2, m2.squeeze(1).sum(1), lab2, ll2)
@@ -263,7 +267,8 @@ def test_accumulation_window_equals_sequential_micro_batches(pkg, name, mode):
             assert int(b[5][k]) == int(v) == int(state0[k]) + 2, k
         else:
             assert float((b[5][k] - v).abs().max()) <= max(tol, 1e-6) * max(1.0, float(v.abs().max())), k
-    print("  [%s] %s window of 2 micro-batches vs sequential accumulation: outputs %.3e, worst gradient %.3e (%s)" % (mode, name, e_y, worst[0], worst[1]))
+    print("  [%s] %s window of 2 micro-batches%s vs sequential accumulation: outputs %.3e, worst gradient %.3e (%s)" % (
+        mode, name, " + window CTC head" if window_head else "", e_y, worst[0], worst[1]))
     assert e_y < tol and worst[0] < tol * (6 if is_front(worst[1]) else 1), (e_y, worst)
 
 
