@@ -150,7 +150,8 @@ class LnBwdDesc(ctypes.Structure):
     _fields_ = [("x", c_p), ("dy", c_p), ("gamma", c_p), ("row_mask", c_p), ("dres", c_p), ("dx", c_p), ("dgamma", c_p), ("dbeta", c_p), ("ws", c_p),
                 ("dx2", c_p), ("M", c_i64), ("D", c_i32), ("dy_dtype", c_i32), ("dx2_dtype", c_i32), ("accumulate", c_i32),
                 ("eps", ctypes.c_float), ("alpha2", ctypes.c_float), ("p1", ctypes.c_float), ("p2", ctypes.c_float),
-                ("seed1", ctypes.c_uint32), ("seed2", ctypes.c_uint32), ("dx2_row_mask", c_p)]
+                ("seed1", ctypes.c_uint32), ("seed2", ctypes.c_uint32), ("dx2_row_mask", c_p),
+                ("chain_x", c_p), ("chain_gamma", c_p), ("chain_dgamma", c_p), ("chain_dbeta", c_p)]
 
 
 class GreedyDesc(ctypes.Structure):

@@ -115,19 +115,35 @@ __device__ __forceinline__ f32x4 ld4_t(const void* p, int64_t i) {
     }
 }
 
-template <int ITERS, int DYDT>
+// CHAIN: a SECOND LayerNorm backward on the same rows, in registers -- consecutive conformer blocks end / begin with one (block l+1's
+// norm_ff_macaron reads block l's norm_final output, encoder_layer.py:57,70), so the backward runs dLN_ffm then dLN_final on every row:
+//     d1 = dres + dLN(dy; x, gamma)            (stage 1, never stored)
+//     dx = dLN(d1; ch.x, ch.gamma)             (stage 2; dx and the optional second output o2 come from THIS)
+// one launch instead of two (each ~13 us at a training window, launch-latency-bound).  Parameter gradients of both norms by atomics.
+struct LnChain {
+    const float* x;
+    const float* gamma;
+    float *acc_g, *acc_b;
+};
+
+template <int ITERS, int DYDT, bool CHAIN>
 __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy, int dy_dt,
                                                                 const float* __restrict__ gamma, const uint8_t* __restrict__ mask,
                                                                 const float* dres, float* dx, float* __restrict__ ws, float eps, int64_t M, int D,
-                                                                float* acc_g, float* acc_b, LnBwd2 o2) {
-    __shared__ float red[LNB_WAVES][2][ITERS * 256];
+                                                                float* acc_g, float* acc_b, LnBwd2 o2, LnChain ch) {
+    __shared__ float red[LNB_WAVES][CHAIN ? 4 : 2][ITERS * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[ITERS], db[ITERS], gm[ITERS];
+    f32x4 dg2[CHAIN ? ITERS : 1], db2[CHAIN ? ITERS : 1], gm2[CHAIN ? ITERS : 1];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = (lane + 64 * it) * 4;
         dg[it] = db[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
         gm[it] = c < D ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (CHAIN) {
+            dg2[it] = db2[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gm2[it] = c < D ? *(const f32x4*)(ch.gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     const float invD = 1.0f / (float)D;
     // every load of the wavefront's two rows goes out first, unconditionally (clamped addresses, values selected afterwards): x, dy, the residual
@@ -135,6 +151,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const
     constexpr int NR = LNB_ROWS / LNB_WAVES;
     const f32x4 z4f = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 xa[NR][ITERS], da[NR][ITERS], ra[NR][ITERS];
+    f32x4 xb[CHAIN ? NR : 1][ITERS];                       // CHAIN: the second norm's input rows
     bool keep_a[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
@@ -148,6 +165,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const
             xa[rr][it] = *(const f32x4*)(x + row_c * D + cc);
             da[rr][it] = ld4_t<DYDT>(dy, row_c * D + cc);
             ra[rr][it] = dres ? *(const f32x4*)(dres + row_c * D + cc) : z4f;
+            if constexpr (CHAIN) xb[rr][it] = *(const f32x4*)(ch.x + row_c * D + cc);
         }
     }
 #pragma unroll
@@ -191,12 +209,59 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const
             }
         }
         const float m1 = wave_sum(a) * invD, m2 = wave_sum(b) * invD;
+        f32x4 och[CHAIN ? ITERS : 1];
+        if constexpr (CHAIN) {
+            // stage 1's result stays in registers and becomes stage 2's dy; then the same four reductions on the second norm's input row
+            f32x4 d1[ITERS], x2[ITERS];
+            float s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                const bool in = c < D;
+                d1[it] = in ? (gm[it] * dv[it] - m1 - xv[it] * m2) * rstd + ra[rr][it] : z4f;
+                x2[it] = in ? xb[rr][it] : z4f;
+                s2 += (x2[it].x + x2[it].y) + (x2[it].z + x2[it].w);
+            }
+            const float mean2 = wave_sum(s2) * invD;
+            float q2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                if (c < D) {
+                    const f32x4 d = x2[it] - mean2;
+                    q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+            }
+            const float rstd2 = 1.0f / sqrtf(wave_sum(q2) * invD + eps);
+            float a2 = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                if (c < D) {
+                    x2[it] = (x2[it] - mean2) * rstd2;
+                    const f32x4 gy = gm2[it] * d1[it];
+                    a2 += (gy.x + gy.y) + (gy.z + gy.w);
+                    const f32x4 t = gy * x2[it];
+                    b2 += (t.x + t.y) + (t.z + t.w);
+                    dg2[it] += d1[it] * x2[it];
+                    db2[it] += d1[it];
+                }
+            }
+            const float n1 = wave_sum(a2) * invD, n2 = wave_sum(b2) * invD;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) och[it] = (gm2[it] * d1[it] - n1 - x2[it] * n2) * rstd2;
+        }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = (lane + 64 * it) * 4;
             if (c < D) {
-                f32x4 o = (gm[it] * dv[it] - m1 - xv[it] * m2) * rstd;
-                o += ra[rr][it];
+                f32x4 o;
+                if constexpr (CHAIN) {
+                    o = och[it];
+                } else {
+                    o = (gm[it] * dv[it] - m1 - xv[it] * m2) * rstd;
+                    o += ra[rr][it];
+                }
                 *(f32x4*)(dx + row * D + c) = o;
                 if (o2.y) {
                     f32x4 t;
@@ -220,16 +285,24 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void cfm_layernorm_bwd_kernel(const
         for (int e = 0; e < 4; ++e) {
             red[wave][0][c + e] = dg[it][e];
             red[wave][1][c + e] = db[it][e];
+            if constexpr (CHAIN) {
+                red[wave][2][c + e] = dg2[it][e];
+                red[wave][3][c + e] = db2[it][e];
+            }
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < 2 * D; j += 64 * LNB_WAVES) {
+    for (int j = threadIdx.x; j < (CHAIN ? 4 : 2) * D; j += 64 * LNB_WAVES) {
         const int which = j / D, c = j - which * D;
         float v = 0.f;
 #pragma unroll
         for (int wv = 0; wv < LNB_WAVES; wv += 4) v += (red[wv][which][c] + red[wv + 1][which][c]) + (red[wv + 2][which][c] + red[wv + 3][which][c]);
-        if (acc_g) unsafeAtomicAdd((which ? acc_b : acc_g) + c, v);      // one pass: the workgroups meet in the (caller-zeroed or running) sums
-        else ws[((int64_t)blockIdx.x * 2 + which) * D + c] = v;
+        if constexpr (CHAIN) {
+            unsafeAtomicAdd((which == 0 ? acc_g : which == 1 ? acc_b : which == 2 ? ch.acc_g : ch.acc_b) + c, v);
+        } else {
+            if (acc_g) unsafeAtomicAdd((which ? acc_b : acc_g) + c, v);  // one pass: the workgroups meet in the (caller-zeroed or running) sums
+            else ws[((int64_t)blockIdx.x * 2 + which) * D + c] = v;
+        }
     }
 }
 
@@ -844,13 +917,20 @@ inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
 extern "C" int64_t cfm_layernorm_bwd_ws(int64_t M, int32_t D) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * (int64_t)D; }
 
 static int layernorm_bwd_impl(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres, float* dx,
-                              float* dgamma, float* dbeta, float* ws, bool accumulate, const LnBwd2& o2, float eps, int64_t M, int32_t D, hipStream_t s) {
+                              float* dgamma, float* dbeta, float* ws, bool accumulate, const LnBwd2& o2, float eps, int64_t M, int32_t D, hipStream_t s,
+                              const LnChain* chain = nullptr) {
     const int nblk = (int)((M + LNB_ROWS - 1) / LNB_ROWS);
     float *ag = accumulate ? dgamma : nullptr, *ab = accumulate ? dbeta : nullptr;
     {
         CfmProfScope prof("layernorm_bwd", s, 0.0, (double)M * D * (8.0 + cfm_elt_size(dy_dtype) + (dres ? 4 : 0) + (o2.y ? cfm_elt_size(o2.dt) : 0)));
         const dim3 grid((unsigned)nblk), block(64 * LNB_WAVES);
-#define CFM_LNB(IT, DT) CFM_LAUNCH((cfm_layernorm_bwd_kernel<IT, DT>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2)
+        LnChain ch = {};
+        if (chain) ch = *chain;
+#define CFM_LNB(IT, DT)                                                                                                                                    \
+    do {                                                                                                                                                   \
+        if (chain) CFM_LAUNCH((cfm_layernorm_bwd_kernel<IT, DT, true>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2, ch); \
+        else CFM_LAUNCH((cfm_layernorm_bwd_kernel<IT, DT, false>), grid, block, 0, s, x, dy, dy_dtype, gamma, row_mask, dres, dx, ws, eps, M, D, ag, ab, o2, ch);  \
+    } while (0)
 #define CFM_LNB_DT(IT)                                        \
     do {                                                      \
         if (dy_dtype == CFM_F32) CFM_LNB(IT, CFM_F32);        \
@@ -884,8 +964,13 @@ extern "C" int cfm_layernorm_bwd_fused(const cfm_ln_bwd_desc* d, cfm_stream_t st
     CFM_CHECK_ARG(d->p1 >= 0.f && d->p1 < 1.f && d->p2 >= 0.f && d->p2 < 1.f && d->M * d->D < ((int64_t)1 << 32), "cfm_layernorm_bwd_fused: p in [0,1), fewer than 2^32 elements");
     LnBwd2 o2 = {};
     if (d->dx2) { o2.y = d->dx2; o2.dt = d->dx2_dtype; o2.alpha = d->alpha2; o2.d1 = cfm_make_drop(d->p1, d->seed1); o2.d2 = cfm_make_drop(d->p2, d->seed2); o2.mask = d->dx2_row_mask; }
+    LnChain ch = {};
+    if (d->chain_x) {
+        CFM_CHECK_ARG(d->chain_gamma && d->chain_dgamma && d->chain_dbeta && d->accumulate, "cfm_layernorm_bwd_fused: a chained second norm needs its gamma / gradient pointers and accumulate = 1");
+        ch.x = d->chain_x; ch.gamma = d->chain_gamma; ch.acc_g = d->chain_dgamma; ch.acc_b = d->chain_dbeta;
+    }
     return layernorm_bwd_impl(d->x, d->dy, d->dy_dtype, d->gamma, d->row_mask, d->dres, d->dx, d->dgamma, d->dbeta, d->ws, d->accumulate != 0, o2, d->eps, d->M,
-                              d->D, (hipStream_t)stream);
+                              d->D, (hipStream_t)stream, d->chain_x ? &ch : nullptr);
 }
 
 extern "C" int cfm_glu_bwd(const void* u, int32_t u_dtype, const void* dg, int32_t dg_dtype, void* du, int32_t du_dtype, int64_t M, int32_t D,

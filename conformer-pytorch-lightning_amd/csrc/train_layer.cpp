@@ -171,8 +171,8 @@ int ln_fwd(const TCtx& c, const float* x, const float* g, const float* b, void* 
 
 // ---- feed-forward sub-block: x_out = x + 1/2 drop_o(W2 drop_h(silu(W1 LN(x) + b1)) + b2) -------------------------------------------------
 int ffn_fwd(const TCtx& c, const float* x, const float* lg, const float* lb, const void* w1, const void* w1l, const float* b1, const void* w2, const void* w2l,
-            const float* b2, void* xn, void* z, void* h, float* x_out, float p_h, uint32_t s_h, float p_o, uint32_t s_o) {
-    CFM_TRY(ln_fwd(c, x, lg, lb, xn, c.adt, nullptr));
+            const float* b2, void* xn, void* z, void* h, float* x_out, float p_h, uint32_t s_h, float p_o, uint32_t s_o, bool xn_ready = false) {
+    if (!xn_ready) CFM_TRY(ln_fwd(c, x, lg, lb, xn, c.adt, nullptr));
     CFM_TRY(gemm(c, xn, c.adt, c.D, w1, w1l, b1, h, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_SILU, nullptr, 0.f, nullptr, 0, z, nullptr, p_h, s_h));
     return gemm(c, h, c.adt, c.FF, w2, w2l, b2, x_out, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, x, 0.5f, nullptr, 0, nullptr, nullptr, p_o, s_o);
 }
@@ -188,12 +188,26 @@ struct Next {
     const uint8_t* mask;   // the consumer's row mask, applied to the operand itself (its GEMMs then take the unmasked, LDS-DMA paths)
 };
 
+// A LayerNorm backward that has NOT been launched: block l+1's norm_ff_macaron, left for block l's first launch, which runs it chained with its
+// own norm_final (cfm_ln_bwd_desc.chain_*: the two norms are applied one after the other to the same rows, encoder_layer.py:70,57)
+struct PendingLn {
+    const float* x;        // the norm's input rows (= block l's output)
+    const float* dy;       // f32 gradient of its output (the macaron feed-forward's input gradient, scratch dxn)
+    const float* gamma;
+    const float* dres;     // the residual stream's gradient at that point (block l+1's d)
+    float *gg, *gb;        // where its parameter gradients go (block l+1's slab)
+};
+
 // LayerNorm backward of a sub-block: dx = dres + dLN(dy) in place on the residual gradient, parameter gradients into the (zero-filled,
 // accumulating) slab -- with atomics in one launch unless the caller asked for reproducible sums -- and the next sub-block's operand
 int ln_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const float* x, const void* dy, const float* gamma, const uint8_t* mask, const float* dres, float* dx,
-           float* gg, float* gb, const Next& nx) {
+           float* gg, float* gb, const Next& nx, const PendingLn* first = nullptr) {
     cfm_ln_bwd_desc d = {};
     d.x = x; d.dy = dy; d.dy_dtype = CFM_F32; d.gamma = gamma; d.row_mask = mask; d.dres = dres; d.dx = dx; d.dgamma = gg; d.dbeta = gb; d.ws = t->ln_ws;
+    if (first) {        // chained: stage 1 = the pending norm, stage 2 = this one (x, gamma, gg, gb as passed; its dy is stage 1's result)
+        d.x = first->x; d.dy = first->dy; d.gamma = first->gamma; d.dres = first->dres; d.dgamma = first->gg; d.dbeta = first->gb; d.row_mask = nullptr;
+        d.chain_x = x; d.chain_gamma = gamma; d.chain_dgamma = gg; d.chain_dbeta = gb;
+    }
     d.accumulate = c.io->deterministic ? 0 : 1;
     d.dx2 = nx.buf; d.dx2_dtype = c.adt; d.alpha2 = nx.alpha; d.p1 = nx.p1; d.seed1 = nx.s1; d.p2 = nx.p2; d.seed2 = nx.s2; d.dx2_row_mask = nx.mask;
     d.eps = 1e-5f; d.M = c.M; d.D = c.D;
@@ -204,7 +218,7 @@ int ln_bwd(const TCtx& c, const cfm_layer_train_scratch* t, const float* x, cons
 // gradient through the output dropout is already there (written by the previous LayerNorm backward, see Next)
 int ffn_bwd(TCtx& c, const cfm_layer_train_scratch* t, const void* dyb_buf, void* dz_buf, float* d, const float* x, const float* lg, const void* xn, const void* z,
             const void* h, const void* w1t, const void* w1tl, const void* w2t, const void* w2tl, float* gW1, float* gb1, float* gW2, float* gb2, float* glg,
-            float* glb, float p_h, uint32_t s_h, const Next& nx) {
+            float* glb, float p_h, uint32_t s_h, const Next& nx, PendingLn* leave = nullptr) {
     const void* dyb = d;
     int dyb_dt = CFM_F32;
     float alpha = 0.5f;
@@ -213,10 +227,17 @@ int ffn_bwd(TCtx& c, const cfm_layer_train_scratch* t, const void* dyb_buf, void
     CFM_TRY(gemm(c, dyb, dyb_dt, c.D, w2t, w2tl, nullptr, dz_buf, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_DSILU, nullptr, alpha, nullptr, 0, nullptr, z, p_h, s_h));
     CFM_TRY(wgrad(c, dz_buf, c.adt, c.FF, xn, c.adt, c.D, gW1, gb1, c.M, c.FF, c.D, 1.0f, nullptr, nullptr, nullptr));
     CFM_TRY(gemm(c, dz_buf, c.adt, c.FF, w1t, w1tl, nullptr, t->dxn, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
+    if (leave) {                                          // the block below runs this norm's backward chained with its own norm_final
+        *leave = {x, t->dxn, lg, d, glg, glb};
+        return CFM_OK;
+    }
     return ln_bwd(c, t, x, t->dxn, lg, nullptr, d, d, glg, glb, nx);
 }
 
-int layer_forward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_train_scratch* t, const float* x_in, float* y_out) {
+// xn1_ready: the previous block's last launch already wrote this block's norm_ff_macaron output (sv->xn1); next_w / next_sv: the NEXT block, whose
+// norm_ff_macaron is chained onto this block's norm_final in one launch (the two LayerNorms of consecutive blocks, encoder_layer.py:70,57)
+int layer_forward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_train_scratch* t, const float* x_in, float* y_out, bool xn1_ready = false,
+                  const cfm_layer_train_weights* next_w = nullptr, const cfm_layer_train_saved* next_sv = nullptr) {
     const cfm_layer_train_weights* w = c.w;
     const cfm_layer_train_io* io = c.io;
     cfm_stream_t stream = c.st;
@@ -224,7 +245,7 @@ int layer_forward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_trai
     const uint32_t sd = io->seed;
     // (1) macaron feed-forward
     CFM_TRY(ffn_fwd(c, x_in, w->ln_ffm_g, w->ln_ffm_b, w->ffm_w1, w->ffm_w1_lo, w->ffm_b1, w->ffm_w2, w->ffm_w2_lo, w->ffm_b2, sv->xn1, sv->z1, sv->h1, sv->x1,
-                    io->p_hidden_m, site_seed(sd, 1), io->p_branch, site_seed(sd, 2)));
+                    io->p_hidden_m, site_seed(sd, 1), io->p_branch, site_seed(sd, 2), xn1_ready));
     // (2) self-attention: q + pos_bias_u rides in the projection's bias; the batch path's positional term is softmax-invariant
     CFM_TRY(ln_fwd(c, sv->x1, w->ln_mha_g, w->ln_mha_b, sv->xn2, adt, nullptr));
     CFM_TRY(gemm(c, sv->xn2, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, sv->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
@@ -261,11 +282,15 @@ int layer_forward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_trai
     // (4) feed-forward, (5) norm_final
     CFM_TRY(ffn_fwd(c, sv->x3, w->ln_ff_g, w->ln_ff_b, w->ff_w1, w->ff_w1_lo, w->ff_b1, w->ff_w2, w->ff_w2_lo, w->ff_b2, sv->xn4, sv->z2, sv->h2, sv->x4, io->p_hidden,
                     site_seed(sd, 7), io->p_branch, site_seed(sd, 8)));
+    if (next_w && next_sv)
+        return cfm_layernorm(sv->x4, w->ln_final_g, w->ln_final_b, y_out, CFM_F32, next_w->ln_ffm_g, next_w->ln_ffm_b, next_sv->xn1, adt, nullptr, 1e-5f, M, D, stream);
     return cfm_layernorm(sv->x4, w->ln_final_g, w->ln_final_b, y_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, 1e-5f, M, D, stream);
 }
 
+// first: the block above left its norm_ff_macaron backward pending (dy is then that block's residual gradient, first->dres); leave: leave THIS
+// block's norm_ff_macaron backward to the block below (dx then holds the gradient BEFORE that norm: the caller passes it on as first->dres)
 int layer_backward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_train_scratch* t, const cfm_layer_train_grads* g, const float* x_in, const float* dy,
-                   float* dx) {
+                   float* dx, const PendingLn* first = nullptr, PendingLn* leave = nullptr) {
     const cfm_layer_train_weights* w = c.w;
     const cfm_layer_train_io* io = c.io;
     cfm_stream_t stream = c.st;
@@ -295,7 +320,7 @@ int layer_backward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_tra
     const Next n_ffm = {br ? (keep_ops ? t->dyb4 : t->dyb) : nullptr, 0.5f, io->p_branch, site_seed(sd, 2), 0.f, 0, nullptr};
     const Next n_none = {nullptr, 0.f, 0.f, 0, 0.f, 0, nullptr};
     // (5) norm_final
-    CFM_TRY(ln_bwd(c, t, sv->x4, dy, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, n_ff));
+    CFM_TRY(ln_bwd(c, t, sv->x4, dy, w->ln_final_g, nullptr, nullptr, d, g->ln_final_g, g->ln_final_b, n_ff, first));
     // (4) feed-forward
     CFM_TRY(ffn_bwd(c, t, n_ff.buf, t->dz, d, sv->x3, w->ln_ff_g, sv->xn4, sv->z2, sv->h2, w->ff_w1t, w->ff_w1t_lo, w->ff_w2t, w->ff_w2t_lo, g->ff_w1, g->ff_b1, g->ff_w2, g->ff_b2,
                     g->ln_ff_g, g->ln_ff_b, io->p_hidden, site_seed(sd, 7), n_conv));
@@ -353,7 +378,7 @@ int layer_backward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_tra
     }
     // (1) macaron feed-forward
     CFM_TRY(ffn_bwd(c, t, n_ffm.buf, keep_ops ? t->dz2 : t->dz, d, x_in, w->ln_ffm_g, sv->xn1, sv->z1, sv->h1, w->ffm_w1t, w->ffm_w1t_lo, w->ffm_w2t,
-                    w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2, g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), n_none));
+                    w->ffm_w2t_lo, g->ffm_w1, g->ffm_b1, g->ffm_w2, g->ffm_b2, g->ln_ffm_g, g->ln_ffm_b, io->p_hidden_m, site_seed(sd, 1), n_none, leave));
     CFM_TRY(flush_wgrads(c));                            // deferred: the block's eight weight-gradient products, one launch
     if (c.side) return stream_after(c.side, c.st);       // join: the block's gradients are complete when the main stream gets past this point
     return CFM_OK;                                       // (c.wg_stream: the caller joins -- cfm_encoder_layer_train_backward at once, the stack one block later)
@@ -402,7 +427,8 @@ extern "C" int cfm_encoder_train_forward(int32_t n_layers, const cfm_layer_train
         iol.seed = layer_seed(io->seed, l);
         TCtx c;
         CFM_TRY(init_ctx(c, &w[l], &iol, stream));
-        CFM_TRY(layer_forward(c, &sv[l], t, xs[l], xs[l + 1]));
+        const bool chain = l + 1 < n_layers;              // norm_final of block l and norm_ff_macaron of block l+1: one launch
+        CFM_TRY(layer_forward(c, &sv[l], t, xs[l], xs[l + 1], l > 0, chain ? &w[l + 1] : nullptr, chain ? &sv[l + 1] : nullptr));
     }
     return CFM_OK;
 }
@@ -425,9 +451,14 @@ extern "C" int cfm_encoder_train_backward(int32_t n_layers, const cfm_layer_trai
         for (int i = 0; i < 2; ++i)
             if (!wg_done[i] && hipEventCreateWithFlags(&wg_done[i], hipEventDisableTiming) != hipSuccess)
                 return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: event creation failed");
+    // consecutive blocks: block l+1's last LayerNorm backward (norm_ff_macaron) and block l's first (norm_final) act on the same rows one after the
+    // other -- block l+1 leaves its own pending and block l's first launch runs both (cfm_ln_bwd_desc.chain_*); needs the atomic parameter sums
+    const bool chain_ln = !io->deterministic;
     const float* cur = dy;
     float* bufs[2] = {dbuf0, dbuf1};
-    int k = 0;
+    int k = 0, report = -1;                               // report: a block whose gradients are complete only after the NEXT block's first launch(es)
+    PendingLn pend = {}, left = {};
+    bool have = false;
     for (int l = n_layers - 1; l >= 0; --l) {
         cfm_layer_train_io iol = *io;
         iol.seed = layer_seed(io->seed, l);
@@ -436,23 +467,25 @@ extern "C" int cfm_encoder_train_backward(int32_t n_layers, const cfm_layer_trai
         const int set = n_scratch == 2 ? (l & 1) : 0;
         if (beside && l + 2 < n_layers && hipStreamWaitEvent((hipStream_t)stream, wg_done[set], 0) != hipSuccess)       // block l+2's products have read this set
             return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: stream wait failed");
-        CFM_TRY(layer_backward(c, &sv[l], &t[set], &g[l], xs[l], cur, bufs[k]));
+        const bool leave = chain_ln && l > 0;
+        CFM_TRY(layer_backward(c, &sv[l], &t[set], &g[l], xs[l], cur, bufs[k], have ? &pend : nullptr, leave ? &left : nullptr));
         cur = bufs[k];
         k ^= 1;
-        if (beside) {
-            if (hipEventRecord(wg_done[set], (hipStream_t)io->side_stream) != hipSuccess) return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: event record failed");
-            if (l + 1 < n_layers) {
-                if (hipStreamWaitEvent((hipStream_t)stream, wg_done[set ^ 1], 0) != hipSuccess) return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: stream wait failed");
-                if (done) done(l + 1, user);
-            }
-        } else if (done) {
-            done(l, user);                                // every launch of block l's backward is enqueued: its gradients may be reduced
+        have = leave;
+        pend = left;
+        if (beside && hipEventRecord(wg_done[set], (hipStream_t)io->side_stream) != hipSuccess)
+            return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: event record failed");
+        if (report >= 0) {                                // block l+1: its pending LayerNorm sums and (beside) its weight gradients are now enqueued / awaited
+            if (beside && hipStreamWaitEvent((hipStream_t)stream, wg_done[set ^ 1], 0) != hipSuccess) return cfm_fail(CFM_ERR_LAUNCH, "cfm_encoder_train_backward: stream wait failed");
+            if (done) done(report, user);
+            report = -1;
         }
+        if (beside || leave) report = l;
+        else if (done) done(l, user);                     // every launch of block l's backward is enqueued: its gradients may be reduced
     }
-    if (beside) {
+    if (beside)
         if (int rc = stream_after(io->side_stream, stream)) return rc;     // join: block 0's (and, with it, every) weight gradient
-        if (done) done(0, user);
-    }
+    if (report >= 0 && done) done(report, user);
     *dx_out = (float*)cur;
     return CFM_OK;
 }

@@ -541,6 +541,11 @@ typedef struct {
     float eps, alpha2, p1, p2;
     uint32_t seed1, seed2;
     const uint8_t* dx2_row_mask; /* optional: rows of dx2 with mask == 0 are written as zeros (cfm_dropout_rows' row_mask) */
+    /* optional CHAINED second norm (needs accumulate = 1): dx = dLN( dres + dLN(dy; x, gamma) ; chain_x, chain_gamma ) -- the backward of two
+     * LayerNorms applied one after the other to the same rows (block l's norm_final feeding block l+1's norm_ff_macaron, encoder_layer.py:70,57)
+     * in one launch; the intermediate gradient is never stored, dx / dx2 come from the second stage, chain_dgamma / chain_dbeta get its sums. */
+    const float *chain_x, *chain_gamma;
+    float *chain_dgamma, *chain_dbeta;
 } cfm_ln_bwd_desc;
 int cfm_layernorm_bwd_fused(const cfm_ln_bwd_desc* d, cfm_stream_t stream);
 int cfm_layernorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* gamma, const uint8_t* row_mask, const float* dres,
