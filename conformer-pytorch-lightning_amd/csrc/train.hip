@@ -528,11 +528,21 @@ __global__ __launch_bounds__(256) void cfm_bn_silu_bwd_kernel(const void* __rest
 
 // dc = gamma*rstd * (dy - k1 - chat*k2), then the depthwise conv's backward: dg[t] = sum_k w[k] dc[t-k+7] and per-workgroup partials of
 // dw[k] = sum dc[t] g[t+k-7], db = sum dc  -> ws[blk][16][D]
-template <int GDT, int ODT>
+// GLU: the GLU backward (convolution.py:42) in the same launch -- the depthwise input gradient dg[t, ch] is rounded to the output type (what the
+// separate cfm_glu_bwd would have read back) and turned into the two columns of du [M, 2D] it belongs to (value / gate blocks of 16 interleaved,
+// the pointwise-conv-1 GEMM's C_pre layout); dg itself is then not stored.
+template <int ODT>
+__device__ __forceinline__ float round_as(float v) {
+    if constexpr (ODT == CFM_F32) return v;
+    else if constexpr (ODT == CFM_BF16) return BF16::to_f32((u16)(pack2<BF16>(v, 0.f) & 0xffffu));
+    else return F16::to_f32((u16)(pack2<F16>(v, 0.f) & 0xffffu));
+}
+
+template <int GDT, int ODT, bool GLU>
 __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ c, const float* __restrict__ stats_all,
                                                              const float* __restrict__ coef_all, const void* __restrict__ g,
                                                              const float* __restrict__ w, void* __restrict__ dg_out, float* __restrict__ ws,
-                                                             const DwGroups G, int D) {
+                                                             const DwGroups G, int D, const void* __restrict__ u, void* __restrict__ du) {
     const int gi = dw_pick_blk(G, (int)blockIdx.x);
     const DwGroup& gr = G.g[gi];
     const float* stats = stats_all + (int64_t)gi * 4 * D;
@@ -564,7 +574,15 @@ __global__ __launch_bounds__(256) void cfm_dwconv_bwd_kernel(const float* __rest
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < DWK; ++k) a = fmaf(wk[k], dcw[j + DWK - 1 - k], a);
-                st_t<ODT>(dg_out, ub + (int64_t)t * D + ch, a);
+                if constexpr (GLU) {
+                    const int64_t ua = (ub / D + t) * 2 * D + (ch >> 4) * 32 + (ch & 15);
+                    const float dv = round_as<ODT>(a), av = ld_t<ODT>(u, ua), gt = ld_t<ODT>(u, ua + 16);
+                    const float sg = sigmoidf_(gt);
+                    st_t<ODT>(du, ua, dv * sg);
+                    st_t<ODT>(du, ua + 16, dv * av * sg * (1.f - sg));
+                } else {
+                    st_t<ODT>(dg_out, ub + (int64_t)t * D + ch, a);
+                }
             }
         }
         float db = 0.f;
@@ -1059,8 +1077,10 @@ extern "C" int cfm_dwconv_bn_train_bwd(const void* ds, int32_t ds_dtype, const f
 
 extern "C" int cfm_dwconv_bn_train_bwd_groups(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
                                               void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
-                                              const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream) {
-    CFM_CHECK_ARG(ds && c && stats && g && w && dg_out && dw_w && dw_b && dgamma && dbeta && dy_ws && ws, "cfm_dwconv_bn_train_bwd: null pointer");
+                                              const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, int32_t accumulate, const void* glu_u,
+                                              void* glu_du, cfm_stream_t stream) {
+    CFM_CHECK_ARG(ds && c && stats && g && w && (dg_out || (glu_u && glu_du)) && dw_w && dw_b && dgamma && dbeta && dy_ws && ws, "cfm_dwconv_bn_train_bwd: null pointer");
+    CFM_CHECK_ARG(!glu_u == !glu_du && (!glu_u || (g_dtype == dg_dtype && D % 16 == 0)), "cfm_dwconv_bn_train_bwd: the fused GLU backward needs u and du, g / dg of one dtype and D %% 16 == 0");
     CFM_CHECK_ARG(ktaps == DWK, "cfm_dwconv_bn_train_bwd: %d taps (only %d is built)", ktaps, DWK);
     DwGroups G;
     int blks, bnbs;
@@ -1084,8 +1104,12 @@ extern "C" int cfm_dwconv_bn_train_bwd_groups(const void* ds, int32_t ds_dtype, 
     {
         CfmProfScope prof("dwconv_bwd", s, 4.0 * M * D * DWK, (double)M * D * (8.0 + cfm_elt_size(g_dtype) + cfm_elt_size(dg_dtype)));
         const dim3 grid((unsigned)blks);
-#define CFM_DWB(GD, OD) CFM_LAUNCH((cfm_dwconv_bwd_kernel<GD, OD>), grid, dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, w, dg_out, part, G, D)
-        if (g_dtype == CFM_BF16 && dg_dtype == CFM_BF16) CFM_DWB(CFM_BF16, CFM_BF16);
+#define CFM_DWB(GD, OD) CFM_LAUNCH((cfm_dwconv_bwd_kernel<GD, OD, false>), grid, dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, w, dg_out, part, G, D, nullptr, nullptr)
+#define CFM_DWG(GD) CFM_LAUNCH((cfm_dwconv_bwd_kernel<GD, GD, true>), grid, dim3(256), 0, s, (const float*)dy_ws, c, stats, (const float*)coef, g, w, dg_out, part, G, D, glu_u, glu_du)
+        if (glu_u && g_dtype == CFM_BF16) CFM_DWG(CFM_BF16);
+        else if (glu_u && g_dtype == CFM_F16) CFM_DWG(CFM_F16);
+        else if (glu_u) CFM_DWG(CFM_F32);
+        else if (g_dtype == CFM_BF16 && dg_dtype == CFM_BF16) CFM_DWB(CFM_BF16, CFM_BF16);
         else if (g_dtype == CFM_F16 && dg_dtype == CFM_F16) CFM_DWB(CFM_F16, CFM_F16);
         else if (g_dtype == CFM_F32 && dg_dtype == CFM_F32) CFM_DWB(CFM_F32, CFM_F32);
         else if (g_dtype == CFM_BF16 && dg_dtype == CFM_F32) CFM_DWB(CFM_BF16, CFM_F32);
@@ -1094,6 +1118,7 @@ extern "C" int cfm_dwconv_bn_train_bwd_groups(const void* ds, int32_t ds_dtype, 
         else if (g_dtype == CFM_F32 && dg_dtype == CFM_F16) CFM_DWB(CFM_F32, CFM_F16);
         else return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_dwconv_bn_train_bwd: g / dg dtype pair %d / %d", g_dtype, dg_dtype);
 #undef CFM_DWB
+#undef CFM_DWG
         if (int rc = cfm_launch_status("cfm_dwconv_bn_train_bwd (conv)")) return rc;
     }
     CfmProfScope prof("dwconv_bwd_finalize", s, 0.0, (double)blks * 16 * D * 4);
@@ -1107,7 +1132,7 @@ extern "C" int cfm_dwconv_bn_train_bwd_acc(const void* ds, int32_t ds_dtype, con
     cfm_train_group one = {};
     one.B = B; one.T = T; one.row0 = 0;
     return cfm_dwconv_bn_train_bwd_groups(ds, ds_dtype, c, stats, g, g_dtype, w, dg_out, dg_dtype, dw_w, dw_b, dgamma, dbeta, dy_ws, ws, &one, 1, D, ktaps, accumulate,
-                                          stream);
+                                          nullptr, nullptr, stream);
 }
 
 extern "C" int cfm_col2im_relu_bwd(const void* dcol, int32_t dcol_dtype, const void* h1, int32_t h1_dtype, void* dh1, int32_t dh1_dtype, int32_t B, int32_t T1,

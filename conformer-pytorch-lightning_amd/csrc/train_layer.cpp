@@ -333,9 +333,9 @@ int layer_backward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_tra
         CFM_TRY(wgrad(c, dyb, dyb_dt, D, sv->s, adt, D, g->pw2_w, g->pw2_b, M, D, D, 1.0f, pm, nullptr, nullptr));
         CFM_TRY(gemm(c, dyb, dyb_dt, D, w->pw2_t, w->pw2_t_lo, nullptr, t->ds, adt, D, M, D, D, CFM_ACT_NONE, nullptr, 0.f, pm, pm ? 1 : 0, nullptr, nullptr, 0.f, 0));
         // per micro-batch its own BatchNorm statistics, one launch per stage for all of them; the parameter gradients are summed over the micro-batches
+        // ... and the GLU backward rides in the depthwise launch (du straight from the rounded dg; the separate elementwise pass is gone)
         CFM_TRY(cfm_dwconv_bn_train_bwd_groups(t->ds, adt, sv->c, sv->stats, sv->glu, adt, w->dw_w, t->dglu, adt, g->dw_w, g->dw_b, g->bn_g, g->bn_b, t->dy_ws, t->dwbn_ws,
-                                               c.cg, c.ng, D, io->ktaps, io->grads_accumulate ? 1 : 0, stream));
-        CFM_TRY(cfm_glu_bwd(sv->u, adt, t->dglu, adt, t->du, adt, M, D, stream));
+                                               c.cg, c.ng, D, io->ktaps, io->grads_accumulate ? 1 : 0, sv->u, t->du, stream));
         CFM_TRY(wgrad(c, t->du, adt, 2 * D, sv->xn3, adt, D, g->slab, g->slab, M, 2 * D, D, 1.0f, nullptr, g->pw1_row_off, g->pw1_bias_off));
         CFM_TRY(gemm(c, t->du, adt, 2 * D, w->pw1_t, w->pw1_t_lo, nullptr, t->dxn, CFM_F32, D, M, D, 2 * D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
         CFM_TRY(ln_bwd(c, t, sv->x2, t->dxn, w->ln_conv_g, io->pad_valid, d, d, g->ln_conv_g, g->ln_conv_b, n_att));

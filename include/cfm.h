@@ -597,7 +597,11 @@ int cfm_dwconv_bn_train_groups(const void* g, int32_t g_dtype, const float* w, c
                                int32_t s_dtype, float* ws, const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, cfm_stream_t stream);
 int cfm_dwconv_bn_train_bwd_groups(const void* ds, int32_t ds_dtype, const float* c, const float* stats, const void* g, int32_t g_dtype, const float* w,
                                    void* dg_out, int32_t dg_dtype, float* dw_w, float* dw_b, float* dgamma, float* dbeta, float* dy_ws, float* ws,
-                                   const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, int32_t accumulate, cfm_stream_t stream);
+                                   const cfm_train_group* groups, int32_t n_groups, int32_t D, int32_t ktaps, int32_t accumulate, const void* glu_u,
+                                   void* glu_du, cfm_stream_t stream);
+/* glu_u / glu_du (both or neither; dtype = g_dtype = dg_dtype): the GLU backward of convolution.py:42 in the depthwise launch -- u [M,2D] the
+ * pre-GLU columns (cfm_gemm_desc.C_pre layout), du [M,2D] their gradient; dg_out is then not written (may be NULL).  Same values as
+ * cfm_glu_bwd on the rounded dg. */
 int cfm_col2im_relu_bwd(const void* dcol, int32_t dcol_dtype, const void* h1, int32_t h1_dtype, void* dh1, int32_t dh1_dtype, int32_t B, int32_t T1,
                         int32_t F1, int32_t C, cfm_stream_t stream);
 int64_t cfm_conv1_wgrad_ws(int32_t B, int32_t T, int32_t C);
