@@ -146,6 +146,11 @@ class LayerWeights(ctypes.Structure):
     _fields_ = [(n, c_p) for n in _LAYER_W_FIELDS]
 
 
+class CtcGroup(ctypes.Structure):
+    _fields_ = [("logits", c_p), ("ld", c_i64), ("B", c_i32), ("T", c_i32), ("Umax", c_i32), ("enc_lens", c_p), ("labels", c_p), ("label_lens", c_p),
+                ("work", c_p), ("alpha", c_p), ("lse", c_p), ("nll", c_p), ("nll_shifted", c_p), ("beta", c_p)]
+
+
 class LnBwdDesc(ctypes.Structure):
     _fields_ = [("x", c_p), ("dy", c_p), ("gamma", c_p), ("row_mask", c_p), ("dres", c_p), ("dx", c_p), ("dgamma", c_p), ("dbeta", c_p), ("ws", c_p),
                 ("dx2", c_p), ("M", c_i64), ("D", c_i32), ("dy_dtype", c_i32), ("dx2_dtype", c_i32), ("accumulate", c_i32),
@@ -248,6 +253,7 @@ def lib():
         L.cfm_conv1_wgrad_ws.argtypes = [c_i32, c_i32, c_i32]
         L.cfm_conv1_wgrad.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_ctc_nll_train.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+        L.cfm_ctc_nll_train_groups.argtypes = [ctypes.POINTER(CtcGroup), c_i32, c_i32, c_p]
         L.cfm_ctc_grad.argtypes = [c_p, c_i64, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]
         L.cfm_adam_step.argtypes = [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p, c_p]
         L.cfm_sumsq.argtypes = [c_p, c_i64, c_p, c_i32, c_p, c_p]
@@ -280,7 +286,7 @@ def lib():
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_gemm_tn_group", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",
-                     "cfm_ctc_nll_train", "cfm_ctc_grad", "cfm_adam_step", "cfm_adam_clip_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_pack_vectors", "cfm_greedy_step", "cfm_ffn_split", "cfm_ffn_split_supported", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
+                     "cfm_ctc_nll_train", "cfm_ctc_nll_train_groups", "cfm_ctc_grad", "cfm_adam_step", "cfm_adam_clip_step", "cfm_sumsq", "cfm_dropout_rows", "cfm_dropout_mask", "cfm_pack_matrices", "cfm_pack_vectors", "cfm_greedy_step", "cfm_ffn_split", "cfm_ffn_split_supported", "cfm_layernorm_bwd_fused", "cfm_dwconv_bn_train_bwd_acc",
                      "cfm_encoder_layer_train_forward", "cfm_encoder_layer_train_backward", "cfm_encoder_train_forward", "cfm_encoder_train_backward", "cfm_stream_prep", "cfm_kv_ring_write", "cfm_stream_advance", "cfm_dwconv_causal_bn_silu", "cfm_conv_cache_update"):
             getattr(L, name).restype = ctypes.c_int
         _lib = L

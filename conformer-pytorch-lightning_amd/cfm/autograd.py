@@ -844,13 +844,13 @@ class CTCWindowLossFn(torch.autograd.Function):
         pk = packing.pack_ctc_train(mod, prec)
         x2 = _f32c(rows)
         logits = _gemm(x2, pk.w, bias=pk.b, w_lo=pk.w_lo, out_dtype=torch.float32)
-        losses, states, r0 = [], [], 0
+        problems, r0 = [], 0
         for B, T, enc_lens, labels, label_lens in groups:
-            lg = logits[r0:r0 + B * T].view(B, T, pk.Vp)
-            nll, state = cfm.ctc_nll_train(lg, pk.V, enc_lens, labels, label_lens)
-            losses.append(nll.sum() / labels.size(1))
-            states.append(state)
+            problems.append((logits[r0:r0 + B * T].view(B, T, pk.Vp), enc_lens, labels, label_lens))
             r0 += B * T
+        res = cfm.ctc_nll_train_groups(problems, pk.V)         # the recursions of all micro-batches in one launch
+        losses = [nll.sum() / pr[2].size(1) for (nll, _), pr in zip(res, problems)]
+        states = [st for _, st in res]
         if r0 != x2.shape[0]:
             raise RuntimeError("CTCWindowLossFn: the micro-batches cover %d rows, the row matrix has %d" % (r0, x2.shape[0]))
         ctx.args = (prec, pk, x2, logits, states, groups)

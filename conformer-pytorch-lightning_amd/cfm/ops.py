@@ -9,7 +9,7 @@ import torch
 import cfm as _c
 
 __all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "gemm_tn_group", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
-           "ctc_nll_train", "ctc_grad", "ffn_split", "adam_step", "adam_clip_step", "sumsq", "scratch_stats",
+           "ctc_nll_train", "ctc_nll_train_groups", "ctc_grad", "ffn_split", "adam_step", "adam_clip_step", "sumsq", "scratch_stats",
            "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "conv12_relu", "conv12_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
@@ -683,6 +683,29 @@ def ctc_nll_train(logits, V, enc_lens, labels, label_lens, beta_now=None):
     _c.check(_c.lib().cfm_ctc_nll_train(_c.ptr(logits), logits.stride(1), B, T, V, _c.ptr(enc_lens), _c.ptr(labels), labels.size(1), _c.ptr(label_lens),
                                         _c.ptr(work), _c.ptr(alpha), _c.ptr(lse), _c.ptr(nll), _c.ptr(nllp), _c.ptr(beta), _c.stream()), "cfm_ctc_nll_train")
     return nll, (work, alpha, lse, nllp, beta)
+
+
+def ctc_nll_train_groups(problems, V):
+    """ctc_nll_train for several micro-batches with ONE launch for all their recursions (include/cfm.h cfm_ctc_nll_train_groups).
+    problems: [(logits [B,T,ld], enc_lens, labels, label_lens)]; returns [(nll [B], state)] as ctc_nll_train does."""
+    n = len(problems)
+    arr = (_c.CtcGroup * n)()
+    outs = []
+    for g, (logits, enc_lens, labels, label_lens) in zip(arr, problems):
+        _c.require_hip(logits, enc_lens, labels, label_lens)
+        _ctc_args(logits, enc_lens, labels, label_lens)
+        B, T = logits.shape[:2]
+        SM = 2 * labels.size(1) + 2
+        dev = logits.device
+        nll, nllp = torch.empty((B,), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.float32, device=dev)
+        work, alpha, beta = (torch.empty((B, T, SM), dtype=torch.float32, device=dev) for _ in range(3))
+        lse = torch.empty((B, T), dtype=torch.float32, device=dev)
+        g.logits, g.ld, g.B, g.T, g.Umax = logits.data_ptr(), logits.stride(1), B, T, labels.size(1)
+        g.enc_lens, g.labels, g.label_lens = enc_lens.data_ptr(), labels.data_ptr(), label_lens.data_ptr()
+        g.work, g.alpha, g.lse, g.nll, g.nll_shifted, g.beta = work.data_ptr(), alpha.data_ptr(), lse.data_ptr(), nll.data_ptr(), nllp.data_ptr(), beta.data_ptr()
+        outs.append((nll, (work, alpha, lse, nllp, beta)))
+    _c.check(_c.lib().cfm_ctc_nll_train_groups(arr, n, V, _c.stream()), "cfm_ctc_nll_train_groups")
+    return outs
 
 
 def ctc_grad(logits, V, enc_lens, labels, label_lens, state, gscale=1.0, gscale_dev=None, out=None):

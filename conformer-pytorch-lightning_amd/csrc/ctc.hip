@@ -287,6 +287,34 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_beta_kernel(const float*
     else ctc_beta_body<true>((int)blockIdx.x - B, work, bml, T, V, enc_lens, labels, Umax, label_lens);
 }
 
+// the same for the micro-batches of a training window (cfm_ctc_nll_train_groups): each recursion is a serial chain of T' steps on one CU and a
+// micro-batch has 5..40 utterances, so two micro-batches' launches ran one after the other on a nearly empty chip (2 x 113 us at config 3)
+constexpr int CTC_GROUPS_MAX = 8;
+struct CtcGroupArgs {
+    const float* work[CTC_GROUPS_MAX];
+    const int* enc_lens[CTC_GROUPS_MAX];
+    const int* labels[CTC_GROUPS_MAX];
+    const int* label_lens[CTC_GROUPS_MAX];
+    float* nll[CTC_GROUPS_MAX];
+    float* alpha[CTC_GROUPS_MAX];
+    float* nllp[CTC_GROUPS_MAX];
+    float* beta[CTC_GROUPS_MAX];
+    int B[CTC_GROUPS_MAX], T[CTC_GROUPS_MAX], Umax[CTC_GROUPS_MAX];
+    int first[CTC_GROUPS_MAX + 1];      // first workgroup of each micro-batch (2 * B workgroups each)
+    int n, V;
+};
+
+__global__ __launch_bounds__(CTC_NT) void cfm_ctc_alpha_beta_group_kernel(const CtcGroupArgs G) {
+    const int wg = (int)blockIdx.x;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < CTC_GROUPS_MAX; ++i)
+        if (i < G.n && wg >= G.first[i]) gi = i;            // uniform
+    const int rel = wg - G.first[gi], B = G.B[gi];
+    if (rel < B) ctc_alpha_body(rel, G.work[gi], G.T[gi], G.V, G.enc_lens[gi], G.labels[gi], G.Umax[gi], G.label_lens[gi], G.nll[gi], G.alpha[gi], G.nllp[gi]);
+    else ctc_beta_body<true>(rel - B, G.work[gi], G.beta[gi], G.T[gi], G.V, G.enc_lens[gi], G.labels[gi], G.Umax[gi], G.label_lens[gi]);
+}
+
 // d nll / d logits, one wavefront per frame, persistent over frames.  Each wavefront keeps an occupancy table over the vocabulary in LDS:
 // the <= 2U+1 state posteriors exp(ab + nll) of a frame are scattered into it (several states share a class: blank, repeated labels),
 // the row is written as gs * (softmax - occupancy), and the touched entries are cleared again.
@@ -343,7 +371,8 @@ __global__ __launch_bounds__(CTC_NT) void cfm_ctc_grad_kernel(const float* __res
 }  // namespace
 
 static int ctc_forward(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
-                       const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nllp, float* beta, cfm_stream_t stream) {
+                       const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nllp, float* beta, cfm_stream_t stream,
+                       bool rows_only = false) {
     CFM_CHECK_ARG(logits && enc_lens && labels && label_lens && work && nll, "cfm_ctc_nll: null pointer");
     CFM_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0, "cfm_ctc_nll: bad shape B=%d T=%d V=%d Umax=%d", B, T, V, Umax);
     CFM_CHECK_ARG(2 * Umax + 1 <= CTC_MAXS, "cfm_ctc_nll: Umax=%d labels exceeds %d", Umax, (CTC_MAXS - 1) / 2);
@@ -356,6 +385,7 @@ static int ctc_forward(const float* logits, int64_t ld, int32_t B, int32_t T, in
                    labels, Umax, label_lens, work, lse);
         if (int rc = cfm_launch_status("cfm_ctc_nll (rows)")) return rc;
     }
+    if (rows_only) return CFM_OK;
     if (beta) {
         CfmProfScope prof("ctc_alpha_beta", s, 0.0, (double)B * T * (2 * Umax + 1) * 16);
         CFM_LAUNCH(cfm_ctc_alpha_beta_kernel, dim3(2 * B), dim3(CTC_NT), 0, s, (const float*)work, B, T, V, enc_lens, labels, Umax, label_lens, nll, alpha, nllp, beta);
@@ -375,6 +405,33 @@ extern "C" int cfm_ctc_nll_train(const float* logits, int64_t ld, int32_t B, int
                                  const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, float* beta, cfm_stream_t stream) {
     CFM_CHECK_ARG(alpha && lse && nll_shifted, "cfm_ctc_nll_train: null pointer");
     return ctc_forward(logits, ld, B, T, V, enc_lens, labels, Umax, label_lens, work, alpha, lse, nll, nll_shifted, beta, stream);
+}
+
+extern "C" int cfm_ctc_nll_train_groups(const cfm_ctc_group* groups, int32_t n, int32_t V, cfm_stream_t stream) {
+    CFM_CHECK_ARG(groups && n > 0 && n <= CTC_GROUPS_MAX, "cfm_ctc_nll_train_groups: 1 .. %d micro-batches", CTC_GROUPS_MAX);
+    CtcGroupArgs G;
+    G.n = n; G.V = V;
+    int first = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const cfm_ctc_group& g = groups[i];
+        CFM_CHECK_ARG(g.alpha && g.lse && g.nll_shifted && g.beta, "cfm_ctc_nll_train_groups: null pointer");
+        if (int rc = ctc_forward(g.logits, g.ld, g.B, g.T, V, g.enc_lens, g.labels, g.Umax, g.label_lens, g.work, g.alpha, g.lse, g.nll, g.nll_shifted, g.beta, stream, true))
+            return rc;
+        G.work[i] = g.work; G.enc_lens[i] = g.enc_lens; G.labels[i] = g.labels; G.label_lens[i] = g.label_lens; G.nll[i] = g.nll; G.alpha[i] = g.alpha;
+        G.nllp[i] = g.nll_shifted; G.beta[i] = g.beta; G.B[i] = g.B; G.T[i] = g.T; G.Umax[i] = g.Umax; G.first[i] = first;
+        first += 2 * g.B;
+        bytes += (double)g.B * g.T * (2 * g.Umax + 1) * 16;
+    }
+    for (int i = n; i < CTC_GROUPS_MAX; ++i) {
+        G.work[i] = G.work[0]; G.enc_lens[i] = G.enc_lens[0]; G.labels[i] = G.labels[0]; G.label_lens[i] = G.label_lens[0]; G.nll[i] = G.nll[0]; G.alpha[i] = G.alpha[0];
+        G.nllp[i] = G.nllp[0]; G.beta[i] = G.beta[0]; G.B[i] = G.B[0]; G.T[i] = G.T[0]; G.Umax[i] = G.Umax[0];
+    }
+    for (int i = n; i <= CTC_GROUPS_MAX; ++i) G.first[i] = first;
+    hipStream_t s = (hipStream_t)stream;
+    CfmProfScope prof("ctc_alpha_beta_group", s, 0.0, bytes);
+    CFM_LAUNCH(cfm_ctc_alpha_beta_group_kernel, dim3((unsigned)first), dim3(CTC_NT), 0, s, G);
+    return cfm_launch_status("cfm_ctc_nll_train_groups (alpha | beta)");
 }
 
 extern "C" int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,

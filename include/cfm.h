@@ -688,6 +688,16 @@ int cfm_ffn_split_supported(int32_t D, int32_t FF);
  * An utterance with no valid alignment (nll = inf) gets a zero gradient (torch's is undefined without zero_infinity).  V <= 8192. */
 int cfm_ctc_nll_train(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
                       const int32_t* label_lens, float* work, float* alpha, float* lse, float* nll, float* nll_shifted, float* beta, cfm_stream_t stream);
+/* cfm_ctc_nll_train for the micro-batches of a training window: the per-frame row passes per micro-batch, then BOTH recursions of ALL micro-batches in
+ * one launch (each is a serial chain on one CU; 2 * B workgroups per micro-batch).  Fields as cfm_ctc_nll_train's arguments; beta is required. */
+typedef struct {
+    const float* logits;
+    int64_t ld;
+    int32_t B, T, Umax;
+    const int32_t *enc_lens, *labels, *label_lens;
+    float *work, *alpha, *lse, *nll, *nll_shifted, *beta;
+} cfm_ctc_group;
+int cfm_ctc_nll_train_groups(const cfm_ctc_group* groups, int32_t n, int32_t V, cfm_stream_t stream);
 int cfm_ctc_grad(const float* logits, int64_t ld, int32_t B, int32_t T, int32_t V, const int32_t* enc_lens, const int32_t* labels, int32_t Umax,
                  const int32_t* label_lens, const float* work, float* alpha_beta, const float* beta, const float* lse, const float* nll_shifted,
                  float gscale, const float* gscale_dev, float* dlogits, cfm_stream_t stream);
