@@ -115,7 +115,8 @@ def build_train_job(device, rank, precision, n_micro=8):
         return list(losses.unbind(0))
 
     tr = T.DataParallelTrainer([enc, dec], loss_fn, lr=1e-3, warmup_steps=25000, accum_grad=2, grad_clip=4.0, bucket_mb=25.0,
-                               window_loss_fn=window_loss_fn if os.environ.get("CFM_TRAIN_WINDOW", "1") != "0" else None)
+                               window_loss_fn=window_loss_fn if os.environ.get("CFM_TRAIN_WINDOW", "1") != "0" else None,
+                               always_reduce=os.environ.get("CFM_BENCH_FORCE_DIST") == "1")      # one-rank rehearsal of the broadcast / all-reduce path
     return enc, dec, tr, mbs, frames
 
 
@@ -170,7 +171,10 @@ def rank_devices(dist, world, rank, device):
     """One string per rank: which physical GPU it runs on (index, name, PCI address / uuid).  N ranks must sit on N DIFFERENT GPUs --
     two ranks sharing a card would still print n_gpus = N -- so a duplicate aborts the run on every rank."""
     pr = torch.cuda.get_device_properties(device)
-    ident = str(getattr(pr, "uuid", "")) or "%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))
+    ident = str(getattr(pr, "uuid", "") or "")
+    if not ident.strip("0-"):                               # no uuid reported: the PCI address, and failing that the device index (one process per index)
+        pci = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        ident = "pci %s:%s:%s" % tuple(pci) if all(v is not None for v in pci) else "index %d" % device.index
     mine = "rank%d=cuda:%d %s [%s]" % (rank, device.index, pr.name, ident)
     if dist is None:
         return [mine]
@@ -401,6 +405,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "RANK" not in os.environ:                        # the one-rank rehearsal outside a launcher
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_PORT=str(free_port()))
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
     else:
