@@ -7,6 +7,8 @@
 // residual stream kept in f32.  Layer norms write the GEMM operand dtype directly.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "cfm_common.h"
 
 namespace {
@@ -96,7 +98,8 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
     // few rows (a streaming step): both feed-forwards split over FF / 256 workgroups per 32-row tile (ffnsplit.hip) instead of inside the row
     // chains, where every tile's workgroup streams all 2 MB of a feed-forward's weights whatever the row count
     bool ring_written = false;                            // the split path's q|k|v launch also filled the K/V ring
-    const bool ffsplit = chains && s->psum && M <= CFM_FFSPLIT_MAX_ROWS && cfm_ffn_split_supported(D, FF) && s->psum_splits >= FF / 256 && !merged &&
+    static const int ffsplit_rows = getenv("CFM_FFSPLIT_MAX_ROWS") ? atoi(getenv("CFM_FFSPLIT_MAX_ROWS")) : CFM_FFSPLIT_MAX_ROWS;   // experiments (scripts/bench_small_batch.py)
+    const bool ffsplit = chains && s->psum && M <= ffsplit_rows && cfm_ffn_split_supported(D, FF) && s->psum_splits >= FF / 256 && !merged &&
                          !io->macaron_done && !io->next_w && w->pw2_w && io->ktaps == 15;
     auto split_desc = [&](int mode) {
         cfm_ffn_split_desc f = {};

@@ -27,9 +27,13 @@ SPLIT_FFN_FEW_ROWS = True  # STREAMING steps of <= 1536 rows run their feed-forw
 # reproduces the batch bit for bit
 
 
+import os as _os
+_SPLIT_MAX_ROWS = int(_os.environ.get("CFM_FFSPLIT_MAX_ROWS", "1536"))     # the library reads the same variable (csrc/encoder.cpp): experiments only
+
+
 def split_rows(M, D, FF):
     """True where cfm_encoder_layer_forward takes the split feed-forward when given the slabs (cfm.h CFM_FFSPLIT_MAX_ROWS)."""
-    return M <= 1536 and D == 256 and FF % 256 == 0 and FF > 0        # measured crossover (scripts/bench_small_batch.py): 996 rows -21 %, 1992 rows +4 %
+    return M <= _SPLIT_MAX_ROWS and D == 256 and FF % 256 == 0 and FF > 0        # measured crossover (scripts/bench_small_batch.py): 996 rows -21 %, 1992 rows +4 %
 
 
 CHAIN_BLOCKS = True        # the final chain of block i also runs the macaron chain of block i+1 (one launch and one residual round trip less)

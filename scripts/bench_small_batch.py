@@ -17,7 +17,7 @@ def main():
     import cfm
     cfm.set_precision("bf16")
     enc = bench.build_encoder(dev)
-    for B in (1, 2, 4, 8):
+    for B in ((1, 2, 4, 8) if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):     # e.g. CFM_FFSPLIT_MAX_ROWS=100000 ... 16 32: the split path at full size
         x = torch.from_numpy(np.random.RandomState(B).standard_normal((B, 1000, 80)).astype(np.float32)).to(dev)
         lens = torch.full((B,), 1000, dtype=torch.int32, device=dev)
         res, outs = [], []
