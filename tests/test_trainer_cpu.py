@@ -50,7 +50,7 @@ def reference_run(world, steps, accum, clip, lr, warmup):
     return [p.detach().clone() for p in model.parameters()], norms
 
 
-def worker(rank, world, port, steps, accum, clip, lr, warmup, out):
+def worker(rank, world, port, steps, accum, clip, lr, warmup, out, window=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import trainer as T
@@ -59,8 +59,10 @@ def worker(rank, world, port, steps, accum, clip, lr, warmup, out):
     model = make_model()
     mods = [model[0], model[2], model[4]]                                 # forward order
     kern = TorchStepKernels()
+    # window: the whole accumulation window in ONE forward / backward (window_loss_fn), the gradients reduced as that single backward completes buckets
+    wfn = (lambda mbs: [torch.nn.functional.mse_loss(model(x), y) for x, y in mbs]) if window else None
     tr = T.DataParallelTrainer(mods, lambda b: torch.nn.functional.mse_loss(model(b[0]), b[1]), lr=lr, warmup_steps=warmup, accum_grad=accum,
-                               grad_clip=clip, bucket_mb=64 * 64 * 4 / (1 << 20), kernels=kern)
+                               grad_clip=clip, bucket_mb=64 * 64 * 4 / (1 << 20), kernels=kern, window_loss_fn=wfn)
     # layout: gradient-ready order = reverse of forward order; every grad is a view into the flat buffer
     assert tr.params[0] is model[4].bias and tr.params[-1] is model[0].weight
     assert all(p.grad.data_ptr() >= tr.flat_g.data_ptr() and p.grad.data_ptr() < tr.flat_g.data_ptr() + tr.numel * 4 for p in model.parameters())
@@ -94,12 +96,12 @@ def worker(rank, world, port, steps, accum, clip, lr, warmup, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_trainer_two_ranks_gloo_matches_single_process_reference(tmp_path, world):
+@pytest.mark.parametrize("world,window", [(2, False), (2, True)])
+def test_trainer_two_ranks_gloo_matches_single_process_reference(tmp_path, world, window):
     steps, accum, clip, lr, warmup = 3, 2, 4.0, 1e-2, 2
     out = str(tmp_path / "r0.pt")
-    port = 29600 + (os.getpid() % 200)
-    mp.spawn(worker, args=(world, port, steps, accum, clip, lr, warmup, out), nprocs=world, join=True)
+    port = 29600 + (os.getpid() % 200) + (300 if window else 0)
+    mp.spawn(worker, args=(world, port, steps, accum, clip, lr, warmup, out, window), nprocs=world, join=True)
     got = torch.load(out, weights_only=True)
     ref_params, ref_norms = reference_run(world, steps, accum, clip, lr, warmup)
     assert max(ref_norms) > clip, "the test data must actually trigger the clip"
