@@ -644,7 +644,11 @@ int pick_tile(const GemmArgs& a, int tile, hipStream_t s, const char* base) {
             // deep K and about one 64 x 128 workgroup per CU (the front-end Linear: M = 7 968, N = 256, K = 4 864 -> 250 workgroups of 76 K steps,
             // each alone on its CU and bound by its own load -> LDS -> MFMA chain): two 64 x 64 workgroups per CU overlap; measured 40.8 vs 44.8 us
             // there and 75.8 vs 83.2 us at M = 3 984, N = 512, K = 9 728 (config 4); 32 x 64 is slower again (L2 bytes per FLOP)
-            if (tile == 2 && a.K >= 4096 && t64x128 < 384 && t64 >= 448) tile = 3;
+            if (tile == 2 && a.K >= 2048 && t64x128 < 384 && t64 >= 448) tile = 3;      // (round 3: also at K = 2 048 -- config 4's second feed-forward product, M = 3 984, N = 512: 19.7 vs 21.8 us)
+            // one to two rounds of 128 x 128 tiles over a short K (config 4, M = 3 984, K = 512; scripts/bench_gemm_tiles.py): more, smaller tiles overlap
+            // their prologues -- q|k|v (N = 1 536) 15.8 us on 128 x 64 against 19.7, pointwise-conv-1 (N = 1 024) 12.4 us on 64 x 64 against 15.9; at two
+            // full rounds (N = 2 048: 512 tiles) 128 x 128 stays best.  Tiles without K groups keep the K order: the bits do not depend on the choice
+            if (tile == 1 && a.K > 256 && a.K <= 512 && t128 < 448) tile = t128 >= 320 ? 4 : 3;
             // short K at a training micro-batch (M ~ 2 400: q|k|v 7.5 -> 6.3 us, pointwise-conv-1 6.5 -> 5.5 us): 32 x 64 tiles up to ~10 per CU
             if (tile != 5 && a.K <= 768 && t32x64 >= 96 && t32x64 <= 2560) tile = 5;
             // long K on few tiles (a feed-forward's second product and its input gradient at a training micro-batch: N = 256, K = 2 048):
