@@ -105,7 +105,14 @@ _TRAIN_W_PTRS = ["ln_ffm_g", "ln_ffm_b", "ln_mha_g", "ln_mha_b", "ln_conv_g", "l
 
 
 class LayerTrainWeights(ctypes.Structure):
-    _fields_ = [(n, c_p) for n in _TRAIN_W_PTRS] + [("bn_momentum", ctypes.c_float), ("bn_eps", ctypes.c_float)]
+    _fields_ = [(n, c_p) for n in _TRAIN_W_PTRS] + [("bn_momentum", ctypes.c_float), ("bn_eps", ctypes.c_float)] + \
+               [(n, c_p) for n in ("ffm_w1f", "ffm_w2f", "ff_w1f", "ff_w2f")]
+
+
+class FfnTrainDesc(ctypes.Structure):
+    _fields_ = [("x", c_p), ("ln_g", c_p), ("ln_b", c_p), ("w1f", c_p), ("w2f", c_p), ("b1", c_p), ("b2", c_p), ("y", c_p), ("xn_out", c_p), ("z_out", c_p),
+                ("h_out", c_p), ("M", c_i64), ("D", c_i32), ("FF", c_i32), ("w_dtype", c_i32), ("alpha", c_f), ("eps", c_f), ("p_hidden", c_f), ("p_out", c_f),
+                ("seed_hidden", ctypes.c_uint32), ("seed_out", ctypes.c_uint32)]
 
 
 class TrainGroup(ctypes.Structure):
@@ -212,6 +219,9 @@ def lib():
         L.cfm_gemm.argtypes = [ctypes.POINTER(GemmDesc), c_p]
         L.cfm_attention.argtypes = [ctypes.POINTER(AttnDesc), c_p]
         L.cfm_ffn_fused.argtypes = [ctypes.POINTER(FfnDesc), c_p]
+        L.cfm_ffn_train_forward.argtypes = [ctypes.POINTER(FfnTrainDesc), c_p]
+        L.cfm_ffn_train_supported.argtypes = [c_i32, c_i32]
+        L.cfm_pack_ffn_fragments.argtypes = [c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_rowchain.argtypes = [ctypes.POINTER(RowChainDesc), c_p]
         L.cfm_rowchain_supported.argtypes = [c_i32, c_i32]
         L.cfm_layernorm.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, ctypes.c_float, c_i64, c_i32, c_p]
@@ -282,7 +292,7 @@ def lib():
         L.cfm_prof_collect.restype = ctypes.c_int
         L.cfm_prof_entry.argtypes = [c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_rowchain", "cfm_rowchain_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma", "cfm_conv12_relu", "cfm_conv12_supported",
+        for name in ("cfm_gemm", "cfm_ffn_fused", "cfm_ffn_train_forward", "cfm_ffn_train_supported", "cfm_pack_ffn_fragments", "cfm_rowchain", "cfm_rowchain_supported", "cfm_attention", "cfm_layernorm", "cfm_kv_cache_pack", "cfm_dwconv_bn_silu", "cfm_conv1_relu", "cfm_conv1_relu_mma", "cfm_conv12_relu", "cfm_conv12_supported",
                      "cfm_valid_mask", "cfm_chunk_mask", "cfm_attn_mask", "cfm_cast", "cfm_add_rows",
                      "cfm_encoder_layer_forward", "cfm_ctc_nll", "cfm_joint_act", "cfm_prof_entry", "cfm_gemm_tn", "cfm_gemm_tn_group", "cfm_attention_bwd",
                      "cfm_layernorm_bwd", "cfm_glu_bwd", "cfm_dwconv_bn_train", "cfm_dwconv_bn_train_bwd", "cfm_col2im_relu_bwd", "cfm_conv1_wgrad",

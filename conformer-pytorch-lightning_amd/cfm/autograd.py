@@ -421,6 +421,8 @@ def _build_train_weights_struct(layer, pks):
     for pre, pk in (("ffm", ffm), ("ff", ff)):
         for f in ("w1", "w1_lo", "w2", "w2_lo", "w1t", "w1t_lo", "w2t", "w2t_lo", "b1", "b2"):
             setattr(w, pre + "_" + f, cfm.ptr(getattr(pk, f)))
+        for f in ("w1f", "w2f"):                            # fragment-major packs (the stack pack builds them): the one-launch feed-forward forward
+            setattr(w, pre + "_" + f, cfm.ptr(getattr(pk, f, None)))
     for f in ("qkv_w", "qkv_w_lo", "qkv_t", "qkv_t_lo", "out_w", "out_w_lo", "out_t", "out_t_lo", "qkv_b", "out_b"):
         setattr(w, f, cfm.ptr(getattr(att, f)))
     for f in ("pw1_w", "pw1_w_lo", "pw1_t", "pw1_t_lo", "pw2_w", "pw2_w_lo", "pw2_t", "pw2_t_lo", "pw1_b", "pw2_b", "dw_w", "dw_b"):

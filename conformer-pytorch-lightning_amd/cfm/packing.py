@@ -399,6 +399,13 @@ def pack_layer_train(layer, prec, relative):
     return val
 
 
+import os as _os
+# each feed-forward's training forward as ONE launch (csrc/ffn.hip cfm_ffn_train_forward): built, parity-tested (the reference gradient goldens pass through
+# it), and measured SLOWER inside the config-3 step -- 8.16 against 7.94 ms per optimizer step: alone the launch is 25 us against 41 for LayerNorm + W1 + W2,
+# but with the 8.7 KB per row it must write for the backward (pre-activation, activation, LayerNorm output) from 107 workgroups' main loops it loses -- opt-in
+FFN_TRAIN_FUSED = _os.environ.get("CFM_FFN_TRAIN_FUSED", "0") != "0"
+
+
 class _StackPackPlan:
     """The training packs of ALL blocks of an encoder in two launches per optimizer step -- the blocks' matrix jobs in one table
     (cfm_pack_matrices), their two small gathered vectors (fused q|k|v bias + pos_bias_u, interleaved pointwise-conv-1 bias) through
@@ -431,6 +438,15 @@ class _StackPackPlan:
         self.vec = torch.empty(n, dtype=torch.float32, device=dev)
         self.prec, self.layers, self.val = prec, list(layers), None
         self.srcs = [t for pl in self.plans for t in pl.srcs]
+        # fragment-major packs of the feed-forwards for the one-launch training forward (csrc/ffn.hip cfm_ffn_train_forward): all of them in one launch
+        self.frag_jobs, self.frags = None, None
+        ffns = [f for l in layers for f in (l.feed_forward_macaron, l.feed_forward)]
+        FF, D = ffns[0].w_1.weight.shape
+        if FFN_TRAIN_FUSED and not prec.split and _c.lib().cfm_ffn_train_supported(D, FF) == 1 and all(tuple(f.w_1.weight.shape) == (FF, D) for f in ffns):
+            self.frags = [(torch.empty(FF * D, dtype=prec.w_dtype, device=dev), torch.empty(FF * D, dtype=prec.w_dtype, device=dev)) for _ in ffns]
+            self.frag_jobs = torch.tensor([[f.w_1.weight.data_ptr(), f.w_2.weight.data_ptr(), a.data_ptr(), b.data_ptr()] for f, (a, b) in zip(ffns, self.frags)],
+                                          dtype=torch.int64).to(dev)
+            self.frag_dims = (D, FF)
         self.ptrs = tuple(t.data_ptr() for l in layers for t in l.parameters())
 
     def valid_for(self, layers, prec):
@@ -442,9 +458,16 @@ class _StackPackPlan:
         _c.check(_c.lib().cfm_pack_matrices(self.jobs.data_ptr(), self.jobs.shape[0], self.tiles, _c.BF16 if prec.split else prec.w_code, 1 if prec.split else 0,
                                             _c.stream()), "cfm_pack_matrices")
         _c.check(_c.lib().cfm_pack_vectors(self.pa.data_ptr(), self.pb.data_ptr(), self.vec.data_ptr(), self.vec.numel(), _c.stream()), "cfm_pack_vectors")
+        if self.frag_jobs is not None:
+            _c.check(_c.lib().cfm_pack_ffn_fragments(self.frag_jobs.data_ptr(), self.frag_jobs.shape[0], self.frag_dims[0], self.frag_dims[1], prec.w_code,
+                                                     _c.stream()), "cfm_pack_ffn_fragments")
         if self.val is None:        # the destinations never move (valid_for checks the sources' addresses): the same Packed objects every step, so
             # whoever caches on their identity (the stack's ctypes weight structs, cfm/autograd.py) keeps its cache across optimizer steps
             self.val = tuple(pl.run(l, launch=False, vectors=(self.vec[a:b], self.vec[b:c])) for l, pl, (a, b, c) in zip(self.layers, self.plans, self.vec_slices))
+            if self.frags is not None:
+                for i, pks in enumerate(self.val):                         # (macaron FFN, attention, conv module, FFN)
+                    pks[0].w1f, pks[0].w2f = self.frags[2 * i]
+                    pks[3].w1f, pks[3].w2f = self.frags[2 * i + 1]
         return self.val
 
 

@@ -43,13 +43,18 @@ struct FfnArgs {
     int FF;
     int act, out16_dtype, add_x;
     float alpha, eps;
+    // TRAIN (cfm_ffn_train_forward): what the backward needs is written on the way -- the LayerNorm output (operand of dW1), the pre-activation
+    // (silu'), the hidden activation after its dropout (operand of dW2) -- and both dropout sites of feedforward.py:19 / encoder_layer.py:58,69 are
+    // applied here with the element indices the unfused products use (row * FF + column, row * D + column: the backward regenerates the masks)
+    u16 *xn_out, *z_out, *h_out;
+    CfmDrop drop_h, drop_o;
 };
 
 namespace {
 
 constexpr int FBM = 32;  // rows per workgroup
 
-template <typename HT, int D, int NSTEPS, int ACT>
+template <typename HT, int D, int NSTEPS, int ACT, bool TRAIN = false>
 __global__ __launch_bounds__(256) void cfm_ffn_kernel(const FfnArgs a) {
     constexpr int KS1 = (D + 31) / 32;   // k-steps of the first product (K zero-padded to a multiple of 32)
     constexpr int KP = KS1 * 32;
@@ -109,7 +114,11 @@ __global__ __launch_bounds__(256) void cfm_ffn_kernel(const FfnArgs a) {
             const int c = (lane + 64 * it) * 4;
             if (c < KP) {
                 const f32x4 o = c < D ? v[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                *(u32x2*)(xn + r * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
+                const u32x2 pk = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
+                *(u32x2*)(xn + r * XN_STRIDE + c) = pk;
+                if constexpr (TRAIN) {
+                    if (c < D && row0 + r < a.M) *(u32x2*)(a.xn_out + (row0 + r) * D + c) = pk;
+                }
             }
         }
     }
@@ -182,13 +191,38 @@ __global__ __launch_bounds__(256) void cfm_ffn_kernel(const FfnArgs a) {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             f32x4 h0 = acc1[mf][0] + bb0, h1 = acc1[mf][1] + bb1;
+            const int64_t trow = row0 + mf * 16 + l15;
+            const int tcol = fs_raw * 32 + 4 * g;         // this lane's 4 columns of fragment 0; fragment 1 sits 16 columns on
+            if constexpr (TRAIN) {
+                if (valid && trow < a.M) {
+                    const u32x4 zp = pack8<HT>(h0, h1);
+                    *(u32x2*)(a.z_out + trow * a.FF + tcol) = (u32x2){zp.x, zp.y};
+                    *(u32x2*)(a.z_out + trow * a.FF + tcol + 16) = (u32x2){zp.z, zp.w};
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 h0[r] = ACT == CFM_ACT_SILU ? siluf_(h0[r]) : fmaxf(h0[r], 0.f);
                 h1[r] = ACT == CFM_ACT_SILU ? siluf_(h1[r]) : fmaxf(h1[r], 0.f);
             }
+            if constexpr (TRAIN) {
+                if (a.drop_h.thresh) {
+                    const unsigned e0 = (unsigned)trow * (unsigned)a.FF + (unsigned)tcol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h0[r] = cfm_drop(a.drop_h, e0 + r, h0[r]);
+                        h1[r] = cfm_drop(a.drop_h, e0 + 16 + r, h1[r]);
+                    }
+                }
+            }
             hf[mf] = pack8<HT>(h0, h1);
             if (!valid) hf[mf] = (u32x4){0u, 0u, 0u, 0u};
+            if constexpr (TRAIN) {
+                if (valid && trow < a.M) {
+                    *(u32x2*)(a.h_out + trow * a.FF + tcol) = (u32x2){hf[mf].x, hf[mf].y};
+                    *(u32x2*)(a.h_out + trow * a.FF + tcol + 16) = (u32x2){hf[mf].z, hf[mf].w};
+                }
+            }
         }
 #pragma unroll
         for (int nf = 0; nf < NF2; ++nf) {
@@ -248,7 +282,14 @@ __global__ __launch_bounds__(256) void cfm_ffn_kernel(const FfnArgs a) {
             v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (c < D) {
                 const f32x4 y = *(const f32x4*)(slab + r * XS_STRIDE + c) + *(const f32x4*)(slab + FBM * XS_STRIDE + r * XS_STRIDE + c);
-                v[it] = a.alpha * (y + *(const f32x4*)(a.b2 + c));
+                f32x4 br = y + *(const f32x4*)(a.b2 + c);
+                if constexpr (TRAIN) {
+                    if (a.drop_o.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) br[e] = cfm_drop(a.drop_o, (unsigned)grow * (unsigned)D + (unsigned)(c + e), br[e]);
+                    }
+                }
+                v[it] = a.alpha * br;
                 if (a.add_x) v[it] += *(const f32x4*)(xs + r * XS_STRIDE + c);
             }
         }
@@ -321,7 +362,84 @@ int launch_ffn(const FfnArgs& a, hipStream_t s, const char* name) {
     return cfm_launch_status(name);
 }
 
+template <typename HT>
+int launch_ffn_train(const FfnArgs& a, hipStream_t s, const char* name) {
+    constexpr int D = 256;
+    const int steps = (a.FF / 32 + 3) / 4;
+    const unsigned grid = (unsigned)((a.M + FBM - 1) / FBM);
+    CfmProfScope prof(name, s, 4.0 * (double)a.M * D * a.FF, (double)a.M * (D * 10.0 + 4.0 * a.FF) + 4.0 * D * a.FF);
+    if (steps <= 8) CFM_LAUNCH((cfm_ffn_kernel<HT, D, 8, CFM_ACT_SILU, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (steps <= 16) CFM_LAUNCH((cfm_ffn_kernel<HT, D, 16, CFM_ACT_SILU, true>), dim3(grid), dim3(256), 0, s, a);
+    else return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_ffn_train_forward: FF=%d needs more than 16 steps per wavefront (max FF 2048)", a.FF);
+    return cfm_launch_status(name);
+}
+
 }  // namespace
+
+extern "C" int cfm_ffn_train_supported(int32_t D, int32_t FF) { return D == 256 && FF > 0 && FF % 128 == 0 && FF <= 2048; }
+
+extern "C" int cfm_ffn_train_forward(const cfm_ffn_train_desc* d, cfm_stream_t stream) {
+    CFM_CHECK_ARG(d && d->x && d->ln_g && d->ln_b && d->w1f && d->w2f && d->b1 && d->b2 && d->y && d->xn_out && d->z_out && d->h_out, "cfm_ffn_train_forward: null pointer");
+    CFM_CHECK_ARG(cfm_ffn_train_supported(d->D, d->FF), "cfm_ffn_train_forward: D=%d FF=%d has no instance (D = 256, FF %% 128 == 0, FF <= 2048)", d->D, d->FF);
+    CFM_CHECK_ARG(d->M > 0 && d->M * (int64_t)d->FF < ((int64_t)1 << 32), "cfm_ffn_train_forward: fewer than 2^32 hidden elements (dropout index)");
+    CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_ffn_train_forward: w_dtype must be bf16 or fp16");
+    CFM_CHECK_ARG(d->p_hidden >= 0.f && d->p_hidden < 1.f && d->p_out >= 0.f && d->p_out < 1.f, "cfm_ffn_train_forward: dropout probabilities in [0, 1)");
+    FfnArgs a = {};
+    a.x = d->x; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.w1f = (const u16*)d->w1f; a.w2f = (const u16*)d->w2f; a.b1 = d->b1; a.b2 = d->b2;
+    a.out_f32 = d->y; a.M = d->M; a.FF = d->FF; a.act = CFM_ACT_SILU; a.add_x = 1; a.alpha = d->alpha; a.eps = d->eps;
+    a.xn_out = (u16*)d->xn_out; a.z_out = (u16*)d->z_out; a.h_out = (u16*)d->h_out;
+    a.drop_h = cfm_make_drop(d->p_hidden, d->seed_hidden); a.drop_o = cfm_make_drop(d->p_out, d->seed_out);
+    hipStream_t s = (hipStream_t)stream;
+    return d->w_dtype == CFM_BF16 ? launch_ffn_train<BF16>(a, s, "ffn_train_fwd_bf16_d256") : launch_ffn_train<F16>(a, s, "ffn_train_fwd_f16_d256");
+}
+
+// Fragment-major weight packs of the fused feed-forward for a whole stack in one launch (cfm/packing.py pack_ffn_fragments on the device):
+//   w1f[((ffb*KS1 + kk)*64 + lane)*8 + j] = W1[ffb*16 + (lane&15)][kk*32 + 8*(lane>>4) + j]
+//   w2f[((fs*NF2 + nf)*64 + lane)*8 + j]  = W2[nf*16 + (lane&15)][fs*32 + (j<4 ? 0 : 16) + 4*(lane>>4) + (j&3)]
+// job = 4 x int64: W1 f32 [FF, D], W2 f32 [D, FF], w1f, w2f (16-bit); D % 32 == 0.
+namespace {
+template <typename HT>
+__global__ void cfm_pack_ffn_frag_kernel(const int64_t* __restrict__ jobs, int D, int FF) {
+    const int64_t* job = jobs + (int64_t)blockIdx.y * 4;
+    const float* W1 = (const float*)job[0];
+    const float* W2 = (const float*)job[1];
+    u16* w1f = (u16*)job[2];
+    u16* w2f = (u16*)job[3];
+    const int KS1 = D / 32, NF2 = D / 16;
+    const int64_t n1 = (int64_t)(FF / 16) * KS1 * 64;       // 16-byte pieces of w1f; w2f has (FF/32) * NF2 * 64 = the same count
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < 2 * n1; id += (int64_t)gridDim.x * blockDim.x) {
+        const bool second = id >= n1;
+        const int64_t q = second ? id - n1 : id;
+        const int lane = (int)(q & 63);
+        f32x4 a, b;
+        if (!second) {
+            const int kk = (int)((q >> 6) % KS1), ffb = (int)((q >> 6) / KS1);
+            const float* src = W1 + (int64_t)(ffb * 16 + (lane & 15)) * D + kk * 32 + 8 * (lane >> 4);
+            a = *(const f32x4*)src;
+            b = *(const f32x4*)(src + 4);
+            *(u32x4*)(w1f + q * 8) = pack8<HT>(a, b);
+        } else {
+            const int nf = (int)((q >> 6) % NF2), fs = (int)((q >> 6) / NF2);
+            const float* src = W2 + (int64_t)(nf * 16 + (lane & 15)) * FF + fs * 32 + 4 * (lane >> 4);
+            a = *(const f32x4*)src;
+            b = *(const f32x4*)(src + 16);
+            *(u32x4*)(w2f + q * 8) = pack8<HT>(a, b);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int cfm_pack_ffn_fragments(const int64_t* jobs_dev, int32_t n_jobs, int32_t D, int32_t FF, int32_t w_dtype, cfm_stream_t stream) {
+    CFM_CHECK_ARG(jobs_dev && n_jobs > 0 && n_jobs <= 65535 && D > 0 && D % 32 == 0 && FF > 0 && FF % 32 == 0, "cfm_pack_ffn_fragments: bad arguments (D, FF multiples of 32)");
+    CFM_CHECK_ARG(w_dtype == CFM_BF16 || w_dtype == CFM_F16, "cfm_pack_ffn_fragments: 16-bit destination type");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t pieces = 2 * (int64_t)(FF / 16) * (D / 32) * 64;
+    CfmProfScope prof("pack_ffn_fragments", s, 0.0, (double)n_jobs * pieces * 48);
+    const dim3 grid((unsigned)((pieces + 255) / 256), (unsigned)n_jobs);
+    if (w_dtype == CFM_BF16) CFM_LAUNCH((cfm_pack_ffn_frag_kernel<BF16>), grid, dim3(256), 0, s, jobs_dev, D, FF);
+    else CFM_LAUNCH((cfm_pack_ffn_frag_kernel<F16>), grid, dim3(256), 0, s, jobs_dev, D, FF);
+    return cfm_launch_status("cfm_pack_ffn_fragments");
+}
 
 extern "C" int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d && d->x && d->w1f && d->w2f && d->b1 && d->b2, "cfm_ffn_fused: null pointer");
@@ -333,7 +451,7 @@ extern "C" int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream) {
                       (d->ln2_g == nullptr) == (d->ln2_b == nullptr), "cfm_ffn_fused: LayerNorm gain/bias must come in pairs");
     CFM_CHECK_ARG(!d->ln2_g || d->out16, "cfm_ffn_fused: the second LayerNorm needs out16");
     CFM_CHECK_ARG(!d->out16 || d->out16_dtype == CFM_BF16 || d->out16_dtype == CFM_F16, "cfm_ffn_fused: out16 dtype must be 16-bit");
-    FfnArgs a;
+    FfnArgs a = {};
     a.x = d->x; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.w1f = (const u16*)d->w1f; a.w2f = (const u16*)d->w2f; a.b1 = d->b1; a.b2 = d->b2;
     a.ln1_g = d->ln1_g; a.ln1_b = d->ln1_b; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b; a.out_f32 = d->out_f32; a.out16 = d->out16;
     a.M = d->M; a.FF = d->FF; a.act = d->act; a.out16_dtype = d->out16_dtype; a.add_x = d->add_x; a.alpha = d->alpha; a.eps = d->eps;

@@ -171,7 +171,17 @@ int ln_fwd(const TCtx& c, const float* x, const float* g, const float* b, void* 
 
 // ---- feed-forward sub-block: x_out = x + 1/2 drop_o(W2 drop_h(silu(W1 LN(x) + b1)) + b2) -------------------------------------------------
 int ffn_fwd(const TCtx& c, const float* x, const float* lg, const float* lb, const void* w1, const void* w1l, const float* b1, const void* w2, const void* w2l,
-            const float* b2, void* xn, void* z, void* h, float* x_out, float p_h, uint32_t s_h, float p_o, uint32_t s_o, bool xn_ready = false) {
+            const float* b2, void* xn, void* z, void* h, float* x_out, float p_h, uint32_t s_h, float p_o, uint32_t s_o, bool xn_ready = false,
+            const void* w1f = nullptr, const void* w2f = nullptr) {
+    if (w1f && w2f && !c.split && cfm_ffn_train_supported(c.D, c.FF)) {
+        // ONE launch (csrc/ffn.hip, TRAIN): LayerNorm, both products, both dropout sites, the residual -- the hidden activation goes from the
+        // first product's accumulators into the second's operand and is written out only for the backward (25 us against 5 + 19 + 17 at a
+        // window's 3 400 rows, scripts/bench_ffn_fused_rows.py)
+        cfm_ffn_train_desc d = {};
+        d.x = x; d.ln_g = lg; d.ln_b = lb; d.w1f = w1f; d.w2f = w2f; d.b1 = b1; d.b2 = b2; d.y = x_out; d.xn_out = xn; d.z_out = z; d.h_out = h;
+        d.M = c.M; d.D = c.D; d.FF = c.FF; d.w_dtype = c.wdt; d.alpha = 0.5f; d.eps = 1e-5f; d.p_hidden = p_h; d.seed_hidden = s_h; d.p_out = p_o; d.seed_out = s_o;
+        return cfm_ffn_train_forward(&d, c.st);
+    }
     if (!xn_ready) CFM_TRY(ln_fwd(c, x, lg, lb, xn, c.adt, nullptr));
     CFM_TRY(gemm(c, xn, c.adt, c.D, w1, w1l, b1, h, c.adt, c.FF, c.M, c.FF, c.D, CFM_ACT_SILU, nullptr, 0.f, nullptr, 0, z, nullptr, p_h, s_h));
     return gemm(c, h, c.adt, c.FF, w2, w2l, b2, x_out, CFM_F32, c.D, c.M, c.D, c.FF, CFM_ACT_NONE, x, 0.5f, nullptr, 0, nullptr, nullptr, p_o, s_o);
@@ -245,7 +255,7 @@ int layer_forward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_trai
     const uint32_t sd = io->seed;
     // (1) macaron feed-forward
     CFM_TRY(ffn_fwd(c, x_in, w->ln_ffm_g, w->ln_ffm_b, w->ffm_w1, w->ffm_w1_lo, w->ffm_b1, w->ffm_w2, w->ffm_w2_lo, w->ffm_b2, sv->xn1, sv->z1, sv->h1, sv->x1,
-                    io->p_hidden_m, site_seed(sd, 1), io->p_branch, site_seed(sd, 2), xn1_ready));
+                    io->p_hidden_m, site_seed(sd, 1), io->p_branch, site_seed(sd, 2), xn1_ready, w->ffm_w1f, w->ffm_w2f));
     // (2) self-attention: q + pos_bias_u rides in the projection's bias; the batch path's positional term is softmax-invariant
     CFM_TRY(ln_fwd(c, sv->x1, w->ln_mha_g, w->ln_mha_b, sv->xn2, adt, nullptr));
     CFM_TRY(gemm(c, sv->xn2, adt, D, w->qkv_w, w->qkv_w_lo, w->qkv_b, sv->qkv, adt, 3 * D, M, 3 * D, D, CFM_ACT_NONE, nullptr, 0.f, nullptr, 0, nullptr, nullptr, 0.f, 0));
@@ -281,7 +291,7 @@ int layer_forward(TCtx& c, const cfm_layer_train_saved* sv, const cfm_layer_trai
                  io->p_branch, site_seed(sd, 6)));
     // (4) feed-forward, (5) norm_final
     CFM_TRY(ffn_fwd(c, sv->x3, w->ln_ff_g, w->ln_ff_b, w->ff_w1, w->ff_w1_lo, w->ff_b1, w->ff_w2, w->ff_w2_lo, w->ff_b2, sv->xn4, sv->z2, sv->h2, sv->x4, io->p_hidden,
-                    site_seed(sd, 7), io->p_branch, site_seed(sd, 8)));
+                    site_seed(sd, 7), io->p_branch, site_seed(sd, 8), false, w->ff_w1f, w->ff_w2f));
     if (next_w && next_sv)
         return cfm_layernorm(sv->x4, w->ln_final_g, w->ln_final_b, y_out, CFM_F32, next_w->ln_ffm_g, next_w->ln_ffm_b, next_sv->xn1, adt, nullptr, 1e-5f, M, D, stream);
     return cfm_layernorm(sv->x4, w->ln_final_g, w->ln_final_b, y_out, CFM_F32, nullptr, nullptr, nullptr, 0, nullptr, 1e-5f, M, D, stream);
@@ -427,7 +437,10 @@ extern "C" int cfm_encoder_train_forward(int32_t n_layers, const cfm_layer_train
         iol.seed = layer_seed(io->seed, l);
         TCtx c;
         CFM_TRY(init_ctx(c, &w[l], &iol, stream));
-        const bool chain = l + 1 < n_layers;              // norm_final of block l and norm_ff_macaron of block l+1: one launch
+        // norm_final of block l and norm_ff_macaron of block l+1: one launch -- unless block l+1's macaron feed-forward is the fused launch, which
+        // normalises its rows itself
+        const bool fused_next = l + 1 < n_layers && w[l + 1].ffm_w1f && w[l + 1].ffm_w2f && io->act_dtype != CFM_F32 && cfm_ffn_train_supported(io->D, io->FF);
+        const bool chain = l + 1 < n_layers && !fused_next;
         CFM_TRY(layer_forward(c, &sv[l], t, xs[l], xs[l + 1], l > 0, chain ? &w[l + 1] : nullptr, chain ? &sv[l + 1] : nullptr));
     }
     return CFM_OK;

@@ -193,6 +193,30 @@ typedef struct {
 
 int cfm_ffn_fused(const cfm_ffn_desc* d, cfm_stream_t stream);
 
+/* The same launch in TRAIN mode (one feed-forward sub-block of encoder_layer.py:56-58 / :67-69 under module.train()):
+ *     y = x + alpha * drop_o( W2 . drop_h( silu( W1 . LN(x) + b1 ) ) + b2 )
+ * keeping what the backward needs: xn_out = LN(x) (16-bit [M,D], the operand of dW1), z_out = the pre-activation (16-bit [M,FF], silu'),
+ * h_out = the hidden activation after its dropout (16-bit [M,FF], the operand of dW2).  Dropout masks are the counter-based ones of the
+ * unfused products (element row*FF + column for the hidden, row*D + column for the output: the backward regenerates them).
+ * w1f / w2f: the fragment-major packs of cfm_ffn_fused (cfm_pack_ffn_fragments builds them on the device).  D = 256, FF % 128 == 0, FF <= 2048. */
+typedef struct {
+    const float* x;
+    const float *ln_g, *ln_b;
+    const void *w1f, *w2f;
+    const float *b1, *b2;
+    float* y;
+    void *xn_out, *z_out, *h_out;
+    int64_t M;
+    int32_t D, FF, w_dtype;
+    float alpha, eps;
+    float p_hidden, p_out;
+    uint32_t seed_hidden, seed_out;
+} cfm_ffn_train_desc;
+int cfm_ffn_train_supported(int32_t D, int32_t FF);
+int cfm_ffn_train_forward(const cfm_ffn_train_desc* d, cfm_stream_t stream);
+/* w1f / w2f of n_jobs feed-forwards in one launch; job = 4 x int64 on the device: W1 f32 [FF,D], W2 f32 [D,FF], w1f, w2f (16-bit, FF*D elements each). */
+int cfm_pack_ffn_fragments(const int64_t* jobs_dev, int32_t n_jobs, int32_t D, int32_t FF, int32_t w_dtype, cfm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row-local chain on 32-row tiles, one launch (csrc/rowchain.hip):
  *     x  = head_a ? head_res + mask_out( head_a . Wh^T + head_b ) : x          (head_mask zeroes the product's row)
@@ -749,6 +773,9 @@ typedef struct {
     const float *pw1_b, *pw2_b, *dw_w, *dw_b, *bn_gamma, *bn_beta;
     float *bn_running_mean, *bn_running_var;
     float bn_momentum, bn_eps;
+    /* optional: fragment-major packs of the two feed-forwards (cfm_pack_ffn_fragments).  When set (and D = 256, 16-bit mode) each feed-forward's
+     * forward is ONE launch (cfm_ffn_train_forward) instead of LayerNorm + two products. */
+    const void *ffm_w1f, *ffm_w2f, *ff_w1f, *ff_w2f;
 } cfm_layer_train_weights;
 
 

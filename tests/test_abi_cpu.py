@@ -46,7 +46,7 @@ def test_ctypes_structs_match_c_sizes(cfm, tmp_path):
                "cfm_gemm_tn_desc": cfm.GemmTnDesc, "cfm_attn_bwd_desc": cfm.AttnBwdDesc, "cfm_rowchain_desc": cfm.RowChainDesc,
                "cfm_layer_train_weights": cfm.LayerTrainWeights, "cfm_layer_train_io": cfm.LayerTrainIO, "cfm_layer_train_saved": cfm.LayerTrainSaved,
                "cfm_layer_train_scratch": cfm.LayerTrainScratch, "cfm_layer_train_grads": cfm.LayerTrainGrads,
-               "cfm_ln_bwd_desc": cfm.LnBwdDesc, "cfm_train_group": cfm.TrainGroup, "cfm_ctc_group": cfm.CtcGroup, "cfm_greedy_desc": cfm.GreedyDesc, "cfm_ffn_split_desc": cfm.FfnSplitDesc}
+               "cfm_ln_bwd_desc": cfm.LnBwdDesc, "cfm_train_group": cfm.TrainGroup, "cfm_ctc_group": cfm.CtcGroup, "cfm_ffn_train_desc": cfm.FfnTrainDesc, "cfm_greedy_desc": cfm.GreedyDesc, "cfm_ffn_split_desc": cfm.FfnSplitDesc}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "cfm.h"\nint main(){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in structs) + "return 0;}\n")
