@@ -272,6 +272,29 @@ def test_accumulation_window_equals_sequential_micro_batches(pkg, name, mode, wi
     assert e_y < tol and worst[0] < tol * (6 if is_front(worst[1]) else 1), (e_y, worst)
 
 
+def test_fused_feedforward_forward_is_the_same_function(pkg, monkeypatch):
+    """The opt-in one-launch feed-forward of the training forward (csrc/ffn.hip cfm_ffn_train_forward, packing.FFN_TRAIN_FUSED) against the default
+    LayerNorm + two products on the 12-layer config-2 architecture: loss, output and every gradient agree to the bf16 mode's rounding (the second
+    product sums its K in another order); both sit inside the reference gates (the goldens pass through either)."""
+    from cfm import packing
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(packing, "FFN_TRAIN_FUSED", fused)
+        g, meta, enc, dec, x, lens = build_train_case(pkg, "train_cfg2s", "bf16")
+        y, m = enc(x, lens, **meta["fw"])
+        loss = dec(y, m.squeeze(1).sum(1), dev(g["labels"]), dev(g["label_lens"]))
+        loss.backward()
+        if fused:
+            assert enc.__dict__["_pack_stack_train"][1].frag_jobs is not None, "the fused path was not taken"
+        res[fused] = (float(loss), y.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()})
+    a, b = res[False], res[True]
+    gmax = max(float(v.abs().max()) for v in a[2].values())
+    worst = max((float((b[2][k] - v).abs().max()) / max(float(v.abs().max()), floor_for(k, 1e-3 * gmax)), k) for k, v in a[2].items())
+    e_y = relerr(b[1], a[1])
+    print("  fused feed-forward forward vs three launches (12 layers, bf16): loss %.6f / %.6f, outputs %.3e, worst gradient %.3e (%s)" % (a[0], b[0], e_y, worst[0], worst[1]))
+    assert abs(a[0] - b[0]) < 2e-4 * abs(a[0]) and e_y < 1.5e-2 and worst[0] < (1.25e-1 if is_front(worst[1]) else 4.5e-2), (e_y, worst)
+
+
 def test_training_step_is_deterministic_and_accumulates(pkg):
     """two identical steps give bitwise-identical gradients when the weight-gradient GEMMs run unsplit ... here: accumulation semantics --
     a second backward ADDS into .grad (gradient accumulation, train.sh:36 accum_grad 2)."""
