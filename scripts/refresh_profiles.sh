@@ -1,8 +1,8 @@
 #!/bin/bash
 # Refresh the judged profile artifacts on the GPU box (everything lands in gpurun_out/refresh/, copy into profiles/ afterwards).
-# Usage (via gpurun): bash scripts/refresh_profiles.sh r02
+# Usage (via gpurun): bash scripts/refresh_profiles.sh r03
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/refresh
 mkdir -p $OUT
 ROOT=$PWD
