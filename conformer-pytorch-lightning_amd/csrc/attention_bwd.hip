@@ -339,7 +339,9 @@ __device__ __forceinline__ void tile_dot64(const u32x4* tile, const u32x4 (&fr)[
     }
 }
 
-template <typename HT>
+// MFULL: a (B, Tq, Tk) mask (chunk mask & padding, utils.py:96-160: the dynamic-chunk training recipe of train.sh:52-53) -- the byte of
+// (query, key) is read from memory by the lane that owns the pair (4 consecutive keys / queries per fragment); the key-validity row stays in LDS
+template <typename HT, bool MFULL>
 __device__ __forceinline__ void attn_bwd_dq_fast_body(const AttnBwdArgs& a, const int block_x, const int block_y, const int block_z) {
     constexpr int TP = KT * 8;                           // u32x4 per tile
     __shared__ u32x4 Ks[2][TP], Vs[2][TP];
@@ -373,9 +375,10 @@ __device__ __forceinline__ void attn_bwd_dq_fast_body(const AttnBwdArgs& a, cons
         if (tid < KT) {
             const int kj = t * KT + tid;
             rm = kj < a.Tk ? 1 : 0;
-            if (rm && a.mask) rm = a.mask[(int64_t)b * a.m_sb + kj] != 0;
+            if (!MFULL && rm && a.mask) rm = a.mask[(int64_t)b * a.m_sb + kj] != 0;
         }
     };
+    const uint8_t* const mrow = MFULL ? a.mask + (int64_t)b * a.m_sb + (int64_t)qc * a.m_sq : nullptr;   // this lane's query row of the mask
     auto put = [&](int buf) __attribute__((always_inline)) {
         tile_store64(Ks[buf], tid, rk);
         tile_store64(Vs[buf], tid, rv);
@@ -388,6 +391,16 @@ __device__ __forceinline__ void attn_bwd_dq_fast_body(const AttnBwdArgs& a, cons
         const int buf = t & 1, k0 = t * KT;
         if (t + 1 < ntiles) fetch(t + 1);
         f32x4 s[4], dp[4];
+        uint8_t mq[MFULL ? 16 : 1];
+        if constexpr (MFULL) {                            // requested before the products, used after them
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kj = k0 + f * 16 + g * 4 + r;
+                    mq[f * 4 + r] = mrow[kj < a.Tk ? kj : a.Tk - 1];
+                }
+        }
         tile_dot64<HT>(Ks[buf], qf, s, l15, g);          // s[f][r]: key k0 + f*16 + g*4 + r, query qi
         tile_dot64<HT>(Vs[buf], dof, dp, l15, g);
 #pragma unroll
@@ -396,7 +409,8 @@ __device__ __forceinline__ void attn_bwd_dq_fast_body(const AttnBwdArgs& a, cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kj = k0 + f * 16 + g * 4 + r;
-                const bool ok = ((mb >> (8 * r)) & 0xffu) != 0 && lse_q != -INFINITY;
+                bool ok = ((mb >> (8 * r)) & 0xffu) != 0 && lse_q != -INFINITY;
+                if constexpr (MFULL) ok = ok && mq[f * 4 + r] != 0;
                 const float p = ok ? __expf(s[f][r] * a.scale - lse_q) : 0.f;
                 float dpe = dp[f][r];
                 if (a.drop.thresh) dpe = cfm_drop(a.drop, (unsigned)rid * (unsigned)a.Tk + (unsigned)kj, dpe);
@@ -436,19 +450,19 @@ __device__ __forceinline__ int attn_group_pick(const AttnBwdGroupArgs& G, int b)
     return idx;
 }
 
-template <typename HT>
+template <typename HT, bool MFULL>
 __global__ __launch_bounds__(256) void cfm_attn_bwd_dq_fast_kernel(const AttnBwdArgs a) {
-    attn_bwd_dq_fast_body<HT>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    attn_bwd_dq_fast_body<HT, MFULL>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
-template <typename HT>
+template <typename HT, bool MFULL>
 __global__ __launch_bounds__(256) void cfm_attn_bwd_dq_group_kernel(const AttnBwdGroupArgs G) {
     const int idx = attn_group_pick(G, (int)blockIdx.x);
     const int rel = (int)blockIdx.x - G.first[idx], gx = G.gx[idx], H = G.a[idx].H;
-    attn_bwd_dq_fast_body<HT>(G.a[idx], rel % gx, (rel / gx) % H, rel / (gx * H));
+    attn_bwd_dq_fast_body<HT, MFULL>(G.a[idx], rel % gx, (rel / gx) % H, rel / (gx * H));
 }
 
-template <typename HT>
+template <typename HT, bool MFULL>
 __device__ __forceinline__ void attn_bwd_dkv_fast_body(const AttnBwdArgs& a, const int block_x, const int block_y, const int block_z) {
     constexpr int TP = QT * 8;
     __shared__ u32x4 Qs[2][TP], Os[2][TP];
@@ -467,7 +481,8 @@ __device__ __forceinline__ void attn_bwd_dkv_fast_body(const AttnBwdArgs& a, con
         vf[kk] = *(const u32x4*)(vp + (int64_t)b * a.v_sb + (int64_t)kc * a.v_st + h * dk + kk * 32 + g * 8);
     }
     bool key_ok = kj < a.Tk;
-    if (key_ok && a.mask) key_ok = a.mask[(int64_t)b * a.m_sb + kj] != 0;
+    if (!MFULL && key_ok && a.mask) key_ok = a.mask[(int64_t)b * a.m_sb + kj] != 0;
+    const uint8_t* const mcol = MFULL ? a.mask + (int64_t)b * a.m_sb + kc : nullptr;      // this lane's key column of the mask (row stride m_sq)
     f32x4 acc_k[4], acc_v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc_k[i] = acc_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -499,6 +514,16 @@ __device__ __forceinline__ void attn_bwd_dkv_fast_body(const AttnBwdArgs& a, con
         const int buf = t & 1, q0 = t * QT;
         if (t + 1 < ntiles) fetch(t + 1);
         f32x4 s[4], dp[4];
+        uint8_t mk[MFULL ? 16 : 1];
+        if constexpr (MFULL) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q0 + f * 16 + g * 4 + r;
+                    mk[f * 4 + r] = mcol[(int64_t)(qq < a.Tq ? qq : a.Tq - 1) * a.m_sq];
+                }
+        }
         tile_dot64<HT>(Qs[buf], kf, s, l15, g);          // s[f][r]: query q0 + f*16 + g*4 + r, key kj
         tile_dot64<HT>(Os[buf], vf, dp, l15, g);
         f32x4 pv[4];
@@ -509,7 +534,8 @@ __device__ __forceinline__ void attn_bwd_dkv_fast_body(const AttnBwdArgs& a, con
             for (int r = 0; r < 4; ++r) {
                 const int qq = q0 + f * 16 + g * 4 + r;
                 const float L = L4[r];
-                const bool ok = key_ok && L != -INFINITY;   // (queries past Tq carry L = -inf)
+                bool ok = key_ok && L != -INFINITY;         // (queries past Tq carry L = -inf)
+                if constexpr (MFULL) ok = ok && mk[f * 4 + r] != 0;
                 const float p = ok ? __expf(s[f][r] * a.scale - L) : 0.f;
                 float pd = p, dpe = dp[f][r];
                 if (a.drop.thresh) {
@@ -543,16 +569,16 @@ __device__ __forceinline__ void attn_bwd_dkv_fast_body(const AttnBwdArgs& a, con
     }
 }
 
-template <typename HT>
+template <typename HT, bool MFULL>
 __global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_fast_kernel(const AttnBwdArgs a) {
-    attn_bwd_dkv_fast_body<HT>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    attn_bwd_dkv_fast_body<HT, MFULL>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
-template <typename HT>
+template <typename HT, bool MFULL>
 __global__ __launch_bounds__(256) void cfm_attn_bwd_dkv_group_kernel(const AttnBwdGroupArgs G) {
     const int idx = attn_group_pick(G, (int)blockIdx.x);
     const int rel = (int)blockIdx.x - G.first[idx], gx = G.gx[idx], H = G.a[idx].H;
-    attn_bwd_dkv_fast_body<HT>(G.a[idx], rel % gx, (rel / gx) % H, rel / (gx * H));
+    attn_bwd_dkv_fast_body<HT, MFULL>(G.a[idx], rel % gx, (rel / gx) % H, rel / (gx * H));
 }
 
 // delta_i = dO_i . O_i for d_k = 64 16-bit rows: the row's sixteen 16-byte pieces requested together (the general kernel's loads sit behind
@@ -601,7 +627,7 @@ static bool g_attn_bwd_general_only = false;      // tests: force the general ke
 template <typename HT>
 bool bwd_fast_ok(const AttnBwdArgs& a) {
     const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    return !g_attn_bwd_general_only && a.dk == 64 && a.io_dt == HT::kId && a.do_dt == HT::kId && (!a.mask || a.m_sq == 0) && a.q_st % 8 == 0 &&
+    return !g_attn_bwd_general_only && a.dk == 64 && a.io_dt == HT::kId && a.do_dt == HT::kId && a.q_st % 8 == 0 &&
            a.k_st % 8 == 0 && a.v_st % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.dout) &&
            al16(a.out);
 }
@@ -609,6 +635,7 @@ bool bwd_fast_ok(const AttnBwdArgs& a) {
 // three launches for n problems: delta, dq, dkv -- each over all problems (callers have checked bwd_fast_ok for every one)
 template <typename HT>
 int launch_bwd_group(AttnBwdGroupArgs& G, hipStream_t s, const char* n_dq, const char* n_dkv) {
+    const bool mfull = G.a[0].mask && G.a[0].m_sq != 0;     // the caller groups problems of one mask kind
     double fl = 0.0, by = 0.0, bd = 0.0;
     int first = 0;
     for (int i = 0; i < G.n; ++i) {
@@ -635,7 +662,8 @@ int launch_bwd_group(AttnBwdGroupArgs& G, hipStream_t s, const char* n_dq, const
     for (int i = G.n; i <= ATTN_GROUP_MAX; ++i) G.first[i] = first;
     {
         CfmProfScope prof(n_dq, s, 3.0 * fl, by);
-        CFM_LAUNCH((cfm_attn_bwd_dq_group_kernel<HT>), dim3((unsigned)first), dim3(256), 0, s, G);
+        if (mfull) CFM_LAUNCH((cfm_attn_bwd_dq_group_kernel<HT, true>), dim3((unsigned)first), dim3(256), 0, s, G);
+        else CFM_LAUNCH((cfm_attn_bwd_dq_group_kernel<HT, false>), dim3((unsigned)first), dim3(256), 0, s, G);
         if (int rc = cfm_launch_status("cfm_attention_bwd_group (dq)")) return rc;
     }
     first = 0;
@@ -647,7 +675,8 @@ int launch_bwd_group(AttnBwdGroupArgs& G, hipStream_t s, const char* n_dq, const
     }
     for (int i = G.n; i <= ATTN_GROUP_MAX; ++i) G.first[i] = first;
     CfmProfScope prof(n_dkv, s, 4.0 * fl, by);
-    CFM_LAUNCH((cfm_attn_bwd_dkv_group_kernel<HT>), dim3((unsigned)first), dim3(256), 0, s, G);
+    if (mfull) CFM_LAUNCH((cfm_attn_bwd_dkv_group_kernel<HT, true>), dim3((unsigned)first), dim3(256), 0, s, G);
+    else CFM_LAUNCH((cfm_attn_bwd_dkv_group_kernel<HT, false>), dim3((unsigned)first), dim3(256), 0, s, G);
     return cfm_launch_status("cfm_attention_bwd_group (dkv)");
 }
 
@@ -672,7 +701,8 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char
         CfmProfScope prof(n_dq, s, 3.0 * fl, by);
         const dim3 grid((unsigned)((a.Tq + QT - 1) / QT), (unsigned)a.H, (unsigned)a.B);
         if constexpr (!SPLIT) {
-            if (fast) CFM_LAUNCH((cfm_attn_bwd_dq_fast_kernel<HT>), grid, dim3(256), 0, s, a);
+            if (fast && a.mask && a.m_sq != 0) CFM_LAUNCH((cfm_attn_bwd_dq_fast_kernel<HT, true>), grid, dim3(256), 0, s, a);
+            else if (fast) CFM_LAUNCH((cfm_attn_bwd_dq_fast_kernel<HT, false>), grid, dim3(256), 0, s, a);
             else CFM_LAUNCH((cfm_attn_bwd_dq_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
         } else {
             CFM_LAUNCH((cfm_attn_bwd_dq_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
@@ -682,7 +712,8 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t s, const char* n_dq, const char
     CfmProfScope prof(n_dkv, s, 4.0 * fl, by);
     const dim3 grid((unsigned)((a.Tk + KT - 1) / KT), (unsigned)a.H, (unsigned)a.B);
     if constexpr (!SPLIT) {
-        if (fast) CFM_LAUNCH((cfm_attn_bwd_dkv_fast_kernel<HT>), grid, dim3(256), 0, s, a);
+        if (fast && a.mask && a.m_sq != 0) CFM_LAUNCH((cfm_attn_bwd_dkv_fast_kernel<HT, true>), grid, dim3(256), 0, s, a);
+        else if (fast) CFM_LAUNCH((cfm_attn_bwd_dkv_fast_kernel<HT, false>), grid, dim3(256), 0, s, a);
         else CFM_LAUNCH((cfm_attn_bwd_dkv_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
     } else {
         CFM_LAUNCH((cfm_attn_bwd_dkv_kernel<HT, SPLIT>), grid, dim3(256), 0, s, a);
@@ -729,7 +760,8 @@ extern "C" int cfm_attention_bwd_group(const cfm_attn_bwd_desc* descs, int32_t n
     bool groupable = n >= 2 && n <= ATTN_GROUP_MAX;
     for (int i = 0; i < n && groupable; ++i) {
         if (int rc = attn_bwd_args(&descs[i], G.a[i])) return rc;
-        groupable = !descs[i].split && descs[i].mma_dtype == descs[0].mma_dtype &&
+        const bool mf = G.a[i].mask && G.a[i].m_sq != 0, mf0 = G.a[0].mask && G.a[0].m_sq != 0;
+        groupable = !descs[i].split && descs[i].mma_dtype == descs[0].mma_dtype && mf == mf0 &&
                     (descs[i].mma_dtype == CFM_BF16 ? bwd_fast_ok<BF16>(G.a[i]) : bwd_fast_ok<F16>(G.a[i]));
     }
     if (!groupable) {

@@ -530,7 +530,7 @@ def test_layernorm_bwd_fused_equals_separate_launches(accumulate):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
-@pytest.mark.parametrize("mkind,drop", [("none", None), ("pad", None), ("pad", (0.1, 991))])
+@pytest.mark.parametrize("mkind,drop", [("none", None), ("pad", None), ("pad", (0.1, 991)), ("chunk", None), ("chunk", (0.1, 991))])
 def test_attention_backward_fast_kernels_are_bit_identical_to_general(cfm, mode, mkind, drop):
     """d_k = 64 with 16-bit rows takes the fast backward kernels (tiles staged as they lie in memory, transposed operands by
     ds_read_b64_tr_b16, prefetched tiles); cfm_attention_bwd_force_general switches them off: same products in the same order -- identical
@@ -542,10 +542,14 @@ def test_attention_backward_fast_kernels_are_bit_identical_to_general(cfm, mode,
     qkv = rnd((B * T, 3 * D), 61, 0.7).to(dt)
     dout = rnd((B * T, D), 62).to(dt)
     mask = None
+    valid = (torch.arange(T)[None, :] < torch.tensor([T, 150, 64])[:, None]).cuda()
     if mkind == "pad":
-        mask = (torch.arange(T)[None, :] < torch.tensor([T, 150, 64])[:, None]).cuda()[:, None, :]
+        mask = valid[:, None, :]
+    elif mkind == "chunk":                              # (B, T, T): chunk window & padding -- the dynamic-chunk training masks (round 3: fast kernels too)
+        blk = torch.arange(T) // 16
+        mask = ((blk[None, :] <= blk[:, None]) & (blk[None, :] >= blk[:, None] - 2)).cuda()[None] & valid[:, None, :]
     m8 = None if mask is None else mask.contiguous().view(torch.uint8)
-    mstr = (0, 0) if mask is None else (T, 0)
+    mstr = (0, 0) if mask is None else (mask.shape[1] * T, T if mask.shape[1] > 1 else 0)
     st = (T * 3 * D, 3 * D)
     ctx = torch.empty((B * T, D), dtype=dt, device="cuda")
     lse = torch.empty((B, H, T), dtype=torch.float32, device="cuda")
