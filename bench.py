@@ -90,6 +90,8 @@ def build_train_job(device, rank, precision, n_micro=8):
     import trainer as T
     torch.manual_seed(0)
     cfg = dict(CFG2)
+    if os.environ.get("CFM_TRAIN_DYNAMIC_CHUNK") == "1":   # the reference's streaming-training recipe (train.sh:52-53): chunk & padding masks (B, T', T')
+        cfg.update(use_dynamic_chunk_size=True, use_dynamic_left_chunk=True)
     enc = enc_mod.ConformerEncoder(cmvn=None, **cfg).to(device).train()
     dec = dec_mod.CTCDecoder(5002, cfg["encoder_dim"], 0.1).to(device).train()
     if precision is not None:
