@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     u16* const hid = (u16*)lds_a;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     // HATT tiles never cross an utterance (the attention stage reads one utterance's keys): tile = (b, 32 frames), rows past the
     // utterance's end are treated like rows past M everywhere below (clamped loads, no stores)
@@ -607,9 +607,9 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr int NPAIR1 = FF / 32, P1 = (NPAIR1 + NW - 1) / NW;
     constexpr int KS2 = FF / 32, KH = KS2 / 2;
     constexpr int NPOS1 = P1 * KS1 * 2, NPOS2 = KH * 2, NPOS = NPOS1 + NPOS2;
-    constexpr int RING = 12;                             // 16 spills ~10 VGPRs at the 128-register budget
+    constexpr int RING = 10;                             // (measured, config 2 step: 8 .. 12 slots within 0.3 %; 16 spills ~10 VGPRs at the 128-register budget)
     static_assert(!MID || ((NF2 + 1) / 2 <= NW / 2 && KS2 % 2 == 0), "phase 2 maps (fragment pair, K half) onto 16 wavefronts");
-    const int np = wave & 7, kh = wave >> 3;
+    int np = wave & 7, kh = wave >> 3;
     const u32x4* w1p = (const u32x4*)a.w1f + lane;
     const u32x4* w2p = (const u32x4*)a.w2n + lane;
     const float *seg_b1 = a.b1, *seg_b2 = a.b2, *seg_ln1_g = a.ln1_g, *seg_ln1_b = a.ln1_b;
@@ -642,6 +642,10 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     const bool last_seg = sg == NSEG - 1;
     if constexpr (SEG2) {
         if (sg == 1) {
+            // the second segment's fragment offsets are the first's: left visible, the compiler keeps all of them (and a lane-derived column index)
+            // alive across the whole segment -- 102 SGPRs spilled to VGPR lanes + 9 VGPRs to scratch (40 B per lane, 10 MB per launch).
+            // Opaque copies of the wavefront scalars make them new values here: no spills, .private_segment_fixed_size 0, step -1.8 %.
+            asm volatile("" : "+s"(wave), "+s"(np), "+s"(kh));
             w1p = (const u32x4*)a.s2_w1f + lane; w2p = (const u32x4*)a.s2_w2n + lane;
             seg_b1 = a.s2_b1; seg_b2 = a.s2_b2; seg_ln1_g = nullptr; seg_ln1_b = nullptr; seg_out = a.s2_out_f32; seg_alpha = a.s2_alpha;
         }
@@ -772,6 +776,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         CFM_STAMP(sg == 0 ? 4 : 11);
 
         // ---- phase 2: y = hidden . W2^T, fragments (2 np, 2 np + 1), K half kh
+        asm volatile("" : "+s"(np), "+s"(kh));             // same reason: phase 2's 64 scalar offsets are otherwise computed (and spilled) at kernel entry
         f32x4 acc2[MF][2];
         {
             auto hfrag = [&](int mf, int k) { return *(const u32x4*)(hid + (mf * 16 + l15) * HS + (kh * KH + k) * 32 + 8 * g); };
