@@ -104,6 +104,8 @@ def pack_ffn(mod, prec):
             pk.w1f, pk.w2f = pack_ffn_fragments(mod.w_1.weight, mod.w_2.weight, prec.w_dtype)
         if _c.rowchain_supported(D, FF, prec):
             pk.w2n = pack_frag_major(mod.w_2.weight, prec.w_dtype)      # the row chains read W2 in natural k order
+            if pk.w1f is None:                                          # (D = 512: no stand-alone fused kernel, the chains only)
+                pk.w1f = pack_frag_major(mod.w_1.weight, prec.w_dtype)
         return pk
     return mod._pack.get([mod.w_1.weight, mod.w_1.bias, mod.w_2.weight, mod.w_2.bias], prec, build)
 

@@ -202,7 +202,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
         if (!merged) CFM_TRY(cfm_rowchain(&ci, stream));
         // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own
-        const bool dw_fused = io->ktaps == 15 && !io->causal_conv;
+        const bool dw_fused = io->ktaps == 15 && !io->causal_conv && cfm_rowchain_dw_supported(D);
         if (io->causal_conv) {
             CFM_TRY(cfm_dwconv_causal_bn_silu(s->glu, adt, io->conv_cache, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
             if (io->conv_cache) CFM_TRY(cfm_conv_cache_update(s->glu, adt, io->conv_cache, io->B, io->T, D, io->ktaps, stream));

@@ -3,7 +3,8 @@
 // Replaces convolution.py:60-63 for the 16-bit precision modes in eval mode.
 //
 // The second convolution is the implicit GEMM of gemm256.hip: rows m = (b, t2, f2), N = C output channels (one 256-wide tile covers
-// all of N for C <= 256), K = 9 taps x C input channels walked as 36 tiles of one tap x 64 channels.  There the A tile of a K step
+// all of N for C <= 256; C = 512 -- config 4 -- runs two workgroups per row tile, blockIdx.y = the 256-wide half of N, each producing the A tiles
+// itself: the same +12.5 % of matrix work per workgroup), K = 9 taps x C input channels walked as 9 C / 64 tiles of one tap x 64 channels.  There the A tile of a K step
 // (256 rows x 64 channels of conv1's output at tap (dt, df)) arrives by LDS-DMA from memory; here the workgroup COMPUTES it:
 //   h1[b, 2 t2 + dt, 2 f2 + df, c] = relu( sum_{i,j} w1[c,i,j] * x[b, 4 t2 + 2 dt + i, 4 f2 + 2 df + j] + b1[c] )
 // as one K = 32 MFMA per 16 rows x 16 channels with exactly the operands of cfm_conv1_mma_kernel (convmod.hip: taps of input row i in K
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(512) void cfm_conv12_kernel(const Conv12Args g) {
     constexpr int FN = 4;
     constexpr int NU = 2 * FM;                               // 16-row production units of an A tile
     constexpr int U = (NU + 7) / 8;                          // units per wavefront
-    __shared__ u32x4 smem[2 * BUF + 512];                    // two K tiles + conv1's weight fragments (u32x2 [4 slabs][4][64 lanes])
+    __shared__ u32x4 smem[2 * BUF + 1024];                   // two K tiles + conv1's weight fragments (u32x2 [<= 8 slabs][4][64 lanes])
     u32x2* const w1tab = (u32x2*)(smem + 2 * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(512) void cfm_conv12_kernel(const Conv12Args g) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, kg = lane >> 4;
     const int m0 = g.m_begin + blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;                          // this workgroup's output channels (C > 256: two halves)
     const int N = g.C, K = 9 * g.C;
     const int slabs = g.C >> 6;
 
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(512) void cfm_conv12_kernel(const Conv12Args g) {
     for (int i = 0; i < 4; ++i) {
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int n = r < N ? r : N - 1;
+        const int n = n0 + r < N ? n0 + r : N - 1;
         w_off[i] = ((unsigned)n * (unsigned)K + c * 8) * 2u;
     }
     auto stageW = [&](int buf, int kt) CFM_INL {
@@ -208,14 +210,14 @@ __global__ __launch_bounds__(512) void cfm_conv12_kernel(const Conv12Args g) {
     f32x4 bias_r[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int col = wc * 64 + j * 16 + q4;
+        const int col = n0 + wc * 64 + j * 16 + q4;
         bias_r[j] = col + 3 < N ? *(const f32x4*)(g.b2 + col) : zero4;
     }
     __syncthreads();
     for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-        for (int cs = 0; cs < 4; ++cs) {
-            if (cs < slabs) {                                // wave-uniform: C = 64 .. 256
+        for (int cs = 0; cs < 8; ++cs) {
+            if (cs < slabs) {                                // wave-uniform: C = 64 .. 512
                 const int kt = tap * slabs + cs;
                 const int cur = kt & 1;
                 const bool last_slab = cs == slabs - 1;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(512) void cfm_conv12_kernel(const Conv12Args g) {
     }
 
     // ---- epilogue: + bias, ReLU, 8-byte stores (a lane owns 4 consecutive output channels of a row)
-    const int col0 = wc * 64 + q4;
+    const int col0 = n0 + wc * 64 + q4;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = m0 + wr * (16 * FM) + i * 16 + l15;
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(512) void cfm_conv12_kernel(const Conv12Args g) {
 template <typename HT, int FM>
 int launch(const Conv12Args& a, hipStream_t s, const char* name) {
     const int rows = a.m_end - a.m_begin, BM = 32 * FM;
-    const int tiles = (rows + BM - 1) / BM;
-    CfmProfScope prof(name, s, 2.0 * rows * (double)a.C * (9.0 * a.C + 32.0), (double)rows * a.C * 2 + 9.0 * a.C * a.C * 2);
-    CFM_LAUNCH((cfm_conv12_kernel<HT, FM>), dim3(tiles), dim3(512), 0, s, a);
+    const int tiles = (rows + BM - 1) / BM, nh = (a.C + 255) / 256;
+    CfmProfScope prof(name, s, 2.0 * rows * (double)a.C * (9.0 * a.C + 32.0 * nh), (double)rows * a.C * 2 + 9.0 * a.C * a.C * 2);
+    CFM_LAUNCH((cfm_conv12_kernel<HT, FM>), dim3(tiles, nh), dim3(512), 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -263,6 +265,7 @@ template <typename HT>
 int run(Conv12Args a, int cus, hipStream_t s, const char* nm_big, const char* nm_tail) {
     // whole rounds of 256-row tiles, then the remainder as ONE round of the smallest tile that fits it on the chip's CUs
     const int M = a.M;
+    cus /= (a.C + 255) / 256;                                 // C = 512: two workgroups (halves of N) per row tile
     const int whole = (M / (256 * cus)) * cus;               // 256-row tiles in whole rounds
     int rest = M - whole * 256;
     if (rest > 0 && rest > 128 * cus) {                       // more than half a round left: it goes on 256-row tiles as well
@@ -294,12 +297,12 @@ int num_cus() {
 
 }  // namespace
 
-extern "C" int cfm_conv12_supported(int32_t C, int32_t y_dtype) { return C % 64 == 0 && C >= 64 && C <= 256 && cfm_is16(y_dtype); }
+extern "C" int cfm_conv12_supported(int32_t C, int32_t y_dtype) { return C % 64 == 0 && C >= 64 && (C <= 256 || C == 512) && cfm_is16(y_dtype); }
 
 extern "C" int cfm_conv12_relu(const float* x, const float* w1, const float* b1, const void* w2, const float* b2, void* y, int32_t y_dtype, int32_t B,
                                int32_t T, int32_t F, int32_t C, const float* cmvn_mean, const float* cmvn_istd, cfm_stream_t stream) {
     CFM_CHECK_ARG(x && w1 && b1 && w2 && b2 && y, "cfm_conv12_relu: null pointer");
-    CFM_CHECK_ARG(cfm_conv12_supported(C, y_dtype), "cfm_conv12_relu: C must be 64, 128, 192 or 256 and y 16-bit (the type its products are rounded to)");
+    CFM_CHECK_ARG(cfm_conv12_supported(C, y_dtype), "cfm_conv12_relu: C must be 64, 128, 192, 256 or 512 and y 16-bit (the type its products are rounded to)");
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
     const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
     CFM_CHECK_ARG(B > 0 && T >= 7 && F >= 7 && T2 >= 1 && F2 >= 1, "cfm_conv12_relu: the input is shorter than two 3x3 stride-2 windows");

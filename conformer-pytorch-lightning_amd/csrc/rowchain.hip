@@ -140,6 +140,40 @@ __device__ __forceinline__ void linear_step(const u16* tile, const u32x4* wp, bo
     }
 }
 
+// The same step when the whole K of a step does not fit in registers (D = 512: KS = 16): the steps' fragments are one stream of positions
+// pos = (s * KS + kk) * NFR + nf through a ring of RG registers (slot = pos % RG, every slot a compile-time constant after unrolling: `s` is
+// a constant at every call site); the slot just consumed is refilled with the fragment RG positions ahead (ptr_of(pos), clamped by the caller).
+template <typename HT, int KS, int NFR, int RG, int STRIDE, typename PtrOf>
+__device__ __forceinline__ void ring_step(const u16* tile, const int s, const int npos, PtrOf ptr_of, u32x4 (&rg)[RG], f32x4 (&acc)[MF][NFR], int g, int l15) {
+    auto frag = [&](int mf, int kk) { return *(const u32x4*)(tile + (mf * 16 + l15) * STRIDE + kk * 32 + 8 * g); };
+    u32x4 xf[2][MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        xf[0][mf] = frag(mf, 0);
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        if (kk + 1 < KS) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) xf[(kk + 1) & 1][mf] = frag(mf, kk + 1);
+        }
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) {
+            const int pos = (s * KS + kk) * NFR + nf;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc[mf][nf] = HT::mfma(rg[pos % RG], xf[kk & 1][mf], acc[mf][nf]);
+        }
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) {
+            const int pos = (s * KS + kk) * NFR + nf;
+            if (pos + RG < npos) rg[pos % RG] = *ptr_of(pos + RG);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // LayerNorm of ROWS rows held one row per wavefront pass (lane owns columns (lane + 64 it) * 4 ..+3), in place.
 template <int ROWS, int VPL, int D>
 __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x4 (&gam)[VPL], const f32x4 (&bet)[VPL], float eps, int lane) {
@@ -176,6 +210,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr int NSEG = SEG2 ? 2 : 1;
     static_assert(!SEG2 || MID, "a second segment is a second feed-forward");
     static_assert(!HATT || (HEAD && !HDW && !MID && D == 256), "the attention input stage: conv-in chain, 4 heads x 64");
+    constexpr bool WIDE = D > 256;                         // D = 512 (config 4): feed-forward in two halves of FF, K-chunked head / tail weight rings
+    static_assert(!WIDE || (!HDW && !HATT && !TVT && !SEG2 && D == 512), "the wide instances: plain macaron / conv-in / final chains at D = 512");
     static_assert(!TVT || (TAIL && !TGLU && D == 256), "transposed values: a fused-QKV tail with 64-wide heads");
     constexpr int DWK = 15, DWH = (DWK - 1) / 2, DWROWS = RBM + DWK - 1;     // depthwise taps, halo, rows of the halo tile
     constexpr int KS1 = (D + 31) / 32;                     // 32-wide K slices of a D-long row
@@ -183,11 +219,13 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr int NF2 = D / 16;                            // 16-column fragments of a D-wide output
     constexpr int XS_STRIDE = D + 4;                       // f32 tile rows (floats)
     constexpr int XN_STRIDE = KP + 16;                     // 16-bit tile rows (halfs): row step = 8 words mod 64
-    constexpr int HS = FF + 16;                            // hidden tile rows (halfs): same rule (FF/2 words = 0 or 32 mod 64)
+    constexpr int FH = MID && WIDE ? 2 : 1;                // WIDE: the 32 x FF hidden tile + the 32 x D operand tile exceed the 160 KB, so FF runs in two halves
+    constexpr int FFH = FF / FH;                           //       (phase 1, phase 2, phase 1, phase 2; the output accumulators stay in registers across them)
+    constexpr int HS = FFH + 16;                           // hidden tile rows (halfs): same rule (FFH/2 words = 0 or 32 mod 64)
     constexpr int VPL = (D + 255) / 256;
     constexpr int TFR = TGLU ? 2 : 1;                      // fragments per wavefront per tail step ((value, gate) pairs for GLU)
-    static_assert(D % 16 == 0 && D <= 256 && MF == 2 && RPW == 2, "row chain supports D % 16 == 0, D <= 256");
-    static_assert(!MID || (FF % 64 == 0 && (XN_STRIDE / 2) % 64 % 16 == 8 && (HS / 2) % 64 % 16 == 8), "FF % 64 == 0 and conflict-free LDS strides");
+    static_assert(D % 16 == 0 && (D <= 256 || D == 512) && MF == 2 && RPW == 2, "row chain supports D % 16 == 0, D <= 256, and D = 512");
+    static_assert(!MID || (FFH % 64 == 0 && (XN_STRIDE / 2) % 64 % 16 == 8 && (HS / 2) % 64 % 16 == 8), "FF % 64 == 0 and conflict-free LDS strides");
 
     // region A: the f32 x tile between HEAD and LN_in, then the 16-bit hidden tile, then the f32 y tile of the FFN
     constexpr int A_MAIN = MID && RBM * HS * 2 > RBM * XS_STRIDE * 4 ? RBM * HS * 2 : RBM * XS_STRIDE * 4;
@@ -223,12 +261,22 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     auto t_frag0 = [&](int s) { return (s * NW + wave) * TFR; };
     auto t_clamp = [&](int f) { return f < t_nfrags ? f : t_nfrags - 1; };
     const u32x4* twp = (const u32x4*)a.tail_w + lane;
-    u32x4 twr[TFR * KS1];
+    constexpr int TRG = WIDE ? (MID ? (TFR == 2 ? 8 : 6) : 10) : TFR * KS1;      // WIDE: a ring over the steps' positions (ring_step) instead of one step's whole K
+    u32x4 twr[TRG];
+    auto tail_ptr = [&](int pos) {                         // WIDE: position -> fragment (step, kk, nf)
+        const int st = pos / (KS1 * TFR), kk = (pos / TFR) % KS1, nf = pos % TFR;
+        return twp + ((int64_t)t_clamp(t_frag0(st) + nf) * KS1 + kk) * 64;
+    };
     auto tail_prefetch = [&]() {
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int nf = 0; nf < TFR; ++nf)
+            for (int t = 0; t < TRG; ++t) twr[t] = *tail_ptr(t);
+        } else {
 #pragma unroll
-            for (int kk = 0; kk < KS1; ++kk) twr[nf * KS1 + kk] = twp[((int64_t)t_clamp(t_frag0(0) + nf) * KS1 + kk) * 64];
+            for (int nf = 0; nf < TFR; ++nf)
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk) twr[nf * KS1 + kk] = twp[((int64_t)t_clamp(t_frag0(0) + nf) * KS1 + kk) * 64];
+        }
     };
 
     // ---- requests of the LayerNorm phase, issued at kernel entry so that their latency hides behind the head GEMM / the FFN ring
@@ -268,8 +316,13 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         const u32x4* wp = (const u32x4*)a.head_w + lane;
         auto frag0 = [&](int s) { return s * NW + wave; };
         auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
-        u32x4 wr[KS1];
-        if constexpr (!HDW && !HATT) {
+        constexpr int HRG = WIDE ? 10 : KS1;
+        u32x4 wr[HRG];
+        auto head_ptr = [&](int pos) { return wp + ((int64_t)clampf(frag0(pos / KS1)) * KS1 + pos % KS1) * 64; };   // WIDE: position -> (step, kk)
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int t = 0; t < HRG; ++t) wr[t] = *head_ptr(t);                                           // weights first
+        } else if constexpr (!HDW && !HATT) {
 #pragma unroll
             for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];   // weights first
         }
@@ -582,7 +635,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 for (int mf = 0; mf < MF; ++mf) keep[mf] = a.head_mask[grows[mf]] != 0;
             }
             f32x4 acc[MF][1];
-            linear_step<HT, KS1, 1, XN_STRIDE>(xn, wp, s + 1 < HSTEPS, nx, wr, acc, g, l15);
+            if constexpr (WIDE) ring_step<HT, KS1, 1, HRG, XN_STRIDE>(xn, s, HSTEPS * KS1, head_ptr, wr, acc, g, l15);
+            else linear_step<HT, KS1, 1, XN_STRIDE>(xn, wp, s + 1 < HSTEPS, nx, wr, acc, g, l15);
             if (f < NF2) {
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf) {
@@ -604,12 +658,14 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     //     phase 1: pos = (i * KS1 + kk) * 2 + nf          phase 2: pos = NPOS1 + k * 2 + nf
     // a ring of RING registers holds the next RING fragments, slot = pos % RING, and the slot just consumed is refilled with
     // the fragment RING positions ahead.
-    constexpr int NPAIR1 = FF / 32, P1 = (NPAIR1 + NW - 1) / NW;
-    constexpr int KS2 = FF / 32, KH = KS2 / 2;
-    constexpr int NPOS1 = P1 * KS1 * 2, NPOS2 = KH * 2, NPOS = NPOS1 + NPOS2;
-    constexpr int RING = 10;                             // (measured, config 2 step: 8 .. 12 slots within 0.3 %; 16 spills ~10 VGPRs at the 128-register budget)
-    static_assert(!MID || ((NF2 + 1) / 2 <= NW / 2 && KS2 % 2 == 0), "phase 2 maps (fragment pair, K half) onto 16 wavefronts");
-    int np = wave & 7, kh = wave >> 3;
+    constexpr int NPAIR1 = FFH / 32, P1 = (NPAIR1 + NW - 1) / NW;          // per half of FF (FH = 1: the whole of it)
+    constexpr int KPARTS = WIDE ? 1 : 2;                   // phase 2: wavefronts per output-fragment pair (parts of K)
+    constexpr int KS2 = FF / 32, KS2H = FFH / 32, KH = KS2H / KPARTS;
+    constexpr int NPOS1 = P1 * KS1 * 2, NPOS2 = KH * 2, NPOSH = NPOS1 + NPOS2, NPOS = FH * NPOSH;
+    constexpr int RING = WIDE && TAIL ? 8 : 10;                           // (measured, config 2 step: 8 .. 12 slots within 0.3 %; 16 spills ~10 VGPRs at the 128-register budget)
+    static_assert(!MID || ((NF2 + 1) / 2 <= NW / KPARTS && KS2H % KPARTS == 0), "phase 2 maps (fragment pair, K part) onto 16 wavefronts");
+    static_assert(!(WIDE && MID) || NPAIR1 % NW == 0, "wide: whole rounds of hidden-fragment pairs");
+    int np = KPARTS == 2 ? wave & 7 : wave, kh = KPARTS == 2 ? wave >> 3 : 0;
     const u32x4* w1p = (const u32x4*)a.w1f + lane;
     const u32x4* w2p = (const u32x4*)a.w2n + lane;
     const float *seg_b1 = a.b1, *seg_b2 = a.b2, *seg_ln1_g = a.ln1_g, *seg_ln1_b = a.ln1_b;
@@ -619,14 +675,15 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     f32x4 nx_g[VPL], nx_b[VPL];                            // SEG2: the second segment's input-norm parameters, requested during the first
     u32x4 ring[RING];
     auto pair_of = [&](int i) { const int q = i * NW + wave; return q < NPAIR1 ? q : NPAIR1 - 1; };
-    auto frag_ptr = [&](int pos) {
+    auto frag_ptr = [&](int gpos) {
+        const int fh = gpos / NPOSH, pos = gpos % NPOSH;     // (FH = 1: fh = 0, pos = gpos)
         if (pos < NPOS1) {
             const int i = pos / (2 * KS1), kk = (pos / 2) % KS1, nf = pos & 1;
-            return w1p + ((int64_t)(2 * pair_of(i) + nf) * KS1 + kk) * 64;
+            return w1p + ((int64_t)(2 * (fh * NPAIR1 + pair_of(i)) + nf) * KS1 + kk) * 64;
         }
         const int k = (pos - NPOS1) / 2, nf = pos & 1;
         const int n = 2 * np + nf < NF2 ? 2 * np + nf : NF2 - 1;
-        return w2p + ((int64_t)n * KS2 + kh * KH + k) * 64;
+        return w2p + ((int64_t)n * KS2 + fh * KS2H + kh * KH + k) * 64;
     };
     auto refill = [&](int pos) {
         if (pos + RING < NPOS) ring[pos % RING] = *frag_ptr(pos + RING);
@@ -692,7 +749,9 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                     xres[rr][it] = c < D ? *(const f32x4*)(xs + (wave * RPW + rr) * XS_STRIDE + c) : zero4;
                 }
         }
-        if constexpr (!MID) {                              // no FFN here: the rows ARE the new residual stream
+        // WIDE + feed-forward: the residual rows do not stay in registers across the feed-forward (16 VGPRs = 4 ring slots); rows made by the head
+        // GEMM are parked in out_f32 (this thread's own elements, overwritten with the result at the end), rows from memory are read again
+        if constexpr (!MID || (WIDE && HEAD)) {            // no FFN here: the rows ARE the new residual stream
             if (a.out_f32) {
 #pragma unroll
                 for (int rr = 0; rr < RPW; ++rr)
@@ -725,14 +784,23 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 
     // ================= MID: feed-forward in two phases around the hidden tile ====================================
     if constexpr (MID) {
+        f32x4 acc2[MF][2];
+#pragma unroll
+        for (int fh = 0; fh < FH; ++fh) {                   // (FH = 1 except WIDE)
+        const int pbase = fh * NPOSH;
+        if (fh > 0) {
+            __syncthreads();                                // every wavefront is done reading the previous half's hidden tile
+            asm volatile("" : "+s"(wave));                  // (new values per half: see the note at the segment boundary)
+            CFM_STAMP(15);
+        }
         // ---- phase 1: hidden = SiLU(xn . W1^T + b1) -> region A, 16 bit
 #pragma unroll
         for (int i = 0; i < P1; ++i) {
             const int q = i * NW + wave;
             const bool valid = NPAIR1 % NW == 0 ? true : q < NPAIR1;
             const int qc = pair_of(i);
-            const f32x4 bb0 = *(const f32x4*)(seg_b1 + (2 * qc) * 16 + 4 * g);      // used after this pair's MFMAs
-            const f32x4 bb1 = *(const f32x4*)(seg_b1 + (2 * qc + 1) * 16 + 4 * g);
+            const f32x4 bb0 = *(const f32x4*)(seg_b1 + (2 * (fh * NPAIR1 + qc)) * 16 + 4 * g);      // used after this pair's MFMAs
+            const f32x4 bb1 = *(const f32x4*)(seg_b1 + (2 * (fh * NPAIR1 + qc) + 1) * 16 + 4 * g);
             auto xfrag = [&](int mf, int kk) { return *(const u32x4*)(xn + (mf * 16 + l15) * XN_STRIDE + kk * 32 + 8 * g); };
             f32x4 acc1[MF][2];
             u32x4 xf[2][MF];
@@ -744,7 +812,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             }
 #pragma unroll
             for (int kk = 0; kk < KS1; ++kk) {
-                const int pos = (i * KS1 + kk) * 2;
+                const int pos = pbase + (i * KS1 + kk) * 2;
                 if (kk + 1 < KS1) {
 #pragma unroll
                     for (int mf = 0; mf < MF; ++mf) xf[(kk + 1) & 1][mf] = xfrag(mf, kk + 1);
@@ -773,23 +841,24 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             }
         }
         __syncthreads();
-        CFM_STAMP(sg == 0 ? 4 : 11);
+        CFM_STAMP(fh > 0 ? 14 : sg == 0 ? 4 : 11);
 
         // ---- phase 2: y = hidden . W2^T, fragments (2 np, 2 np + 1), K half kh
         asm volatile("" : "+s"(np), "+s"(kh));             // same reason: phase 2's 64 scalar offsets are otherwise computed (and spilled) at kernel entry
-        f32x4 acc2[MF][2];
         {
             auto hfrag = [&](int mf, int k) { return *(const u32x4*)(hid + (mf * 16 + l15) * HS + (kh * KH + k) * 32 + 8 * g); };
             u32x4 hf[2][MF];
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 hf[0][mf] = hfrag(mf, 0);
-                acc2[mf][0] = zero4;
-                acc2[mf][1] = zero4;
+                if (fh == 0) {
+                    acc2[mf][0] = zero4;
+                    acc2[mf][1] = zero4;
+                }
             }
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-                const int pos = NPOS1 + k * 2;
+                const int pos = pbase + NPOS1 + k * 2;
                 if (k + 1 < KH) {
 #pragma unroll
                     for (int mf = 0; mf < MF; ++mf) hf[(k + 1) & 1][mf] = hfrag(mf, k + 1);
@@ -803,11 +872,27 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (FH > 1) {
+            // the accumulators are next read after the LAST half: without an anchor here the compiler sinks this half's MFMAs below the next half's
+            // barrier and keeps every fragment they read alive (spilled) until then
+            asm volatile("" : "+v"(acc2[0][0]), "+v"(acc2[0][1]), "+v"(acc2[1][0]), "+v"(acc2[1][1]));
+        }
+        }   // FF halves
         // requests that land during the tile exchange below: post-norm parameters and the tail's first weights
 #pragma unroll
         for (int it = 0; it < VPL; ++it) {
             const int c = (lane + 64 * it) * 4;
             pn_b2[it] = c < D ? *(const f32x4*)(seg_b2 + c) : zero4;
+        }
+        if constexpr (WIDE) {
+            const float* rsrc = HEAD ? a.out_f32 : a.x;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    xres[rr][it] = c < D ? *(const f32x4*)(rsrc + ln_rows[rr] * D + c) : zero4;
+                }
         }
         if (seg_ln1_g) {
 #pragma unroll
@@ -835,7 +920,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 pn_be2[it] = c < D ? *(const f32x4*)(a.ln2_b + c) : zero4;
             }
         }
-        if constexpr (TAIL) {
+        if constexpr (TAIL && !WIDE) {
             if (last_seg) tail_prefetch();
         }
         __syncthreads();                                   // every wavefront is done reading the hidden tile
@@ -849,14 +934,16 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                     if (2 * np + nf < NF2) *(f32x4*)ytile(mf, nf) = acc2[mf][nf];
         }
         __syncthreads();
-        if (kh == 1) {
+        if constexpr (KPARTS == 2) {
+            if (kh == 1) {
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
+                for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
-                    if (2 * np + nf < NF2) *(f32x4*)ytile(mf, nf) = *(const f32x4*)ytile(mf, nf) + acc2[mf][nf];
+                    for (int nf = 0; nf < 2; ++nf)
+                        if (2 * np + nf < NF2) *(f32x4*)ytile(mf, nf) = *(const f32x4*)ytile(mf, nf) + acc2[mf][nf];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     CFM_STAMP(sg == 0 ? 5 : 12);
 
@@ -918,6 +1005,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 
     // ================= TAIL: t = xn . Wt^T + bt (GLU optional), 16-bit store ===================================
     if constexpr (TAIL) {
+        if constexpr (MID && WIDE) tail_prefetch();        // (not earlier: the ring would not fit beside the feed-forward's registers)
         const int ldo = TGLU ? a.tail_N / 2 : a.tail_N;
 #pragma unroll
         for (int s = 0; s < TSTEPS; ++s) {
@@ -931,7 +1019,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 bb[nf] = *(const f32x4*)(a.tail_b + t_clamp(f + nf) * 16 + 4 * g);      // issued before this step's MFMAs
             }
             f32x4 acc[MF][TFR];
-            linear_step<HT, KS1, TFR, XN_STRIDE>(xn, twp, s + 1 < TSTEPS, nx, twr, acc, g, l15);
+            if constexpr (WIDE) ring_step<HT, KS1, TFR, TRG, XN_STRIDE>(xn, s, TSTEPS * KS1 * TFR, tail_ptr, twr, acc, g, l15);
+            else linear_step<HT, KS1, TFR, XN_STRIDE>(xn, twp, s + 1 < TSTEPS, nx, twr, acc, g, l15);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int64_t grow = row0 + mf * 16 + l15;
@@ -979,7 +1068,8 @@ int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flo
 
 }  // namespace
 
-extern "C" int cfm_rowchain_supported(int32_t D, int32_t FF) { return (D == 256 && FF == 2048) || (D == 144 && FF == 576); }
+extern "C" int cfm_rowchain_supported(int32_t D, int32_t FF) { return (D == 256 && FF == 2048) || (D == 144 && FF == 576) || (D == 512 && FF == 2048); }
+extern "C" int cfm_rowchain_dw_supported(int32_t D) { return D <= 256; }   // the depthwise input stage (one (channel pair, frame group) per thread)
 
 extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d, "cfm_rowchain: null descriptor");
@@ -996,7 +1086,8 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
                   "cfm_rowchain: a second segment needs a first feed-forward, its own weights / biases / input norm / output and ln2");
     CFM_CHECK_ARG(!dw || (head && (mid ? (!tail || seg2) : !tail) && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
                   "cfm_rowchain: the depthwise input stage needs a head (+ feed-forward) chain without a tail, bias/scale/shift, 15 taps and M %% dw_T == 0");
-    CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256), "cfm_rowchain: D=%d has no instance (144, 256)", d->D);
+    CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256 || d->D == 512), "cfm_rowchain: D=%d has no instance (144, 256, 512)", d->D);
+    CFM_CHECK_ARG(d->D != 512 || (!dw && !att && !tvt && !seg2), "cfm_rowchain: D = 512 runs the plain macaron / conv-in / final chains only");
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_rowchain: w_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(head || d->x, "cfm_rowchain: need x or a head input");
     CFM_CHECK_ARG(!head || (d->head_w && d->head_b && d->head_res), "cfm_rowchain: head needs weights, bias and residual");
@@ -1049,6 +1140,10 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
         if (head && mid && !tail) { if (bf) CFM_RC(BF16, 144, 576, 1, true, 0, false, "chain_final_bf16_d144"); else CFM_RC(F16, 144, 576, 1, true, 0, false, "chain_final_f16_d144"); }
         if (!head && !mid && tail && !d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 2, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 2, false, "chain_qkv_f16_d144"); }
         if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 0, false, "chain_rows_f16_d144"); }
+    } else if (d->D == 512 && (!mid || d->FF == 2048)) {
+        if (!head && mid && tail && !d->tail_glu && tsteps == 6) { if (bf) CFM_RC(BF16, 512, 2048, 0, true, 6, false, "chain_macaron_bf16_d512"); else CFM_RC(F16, 512, 2048, 0, true, 6, false, "chain_macaron_f16_d512"); }
+        if (head && !mid && tail && d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 512, 64, 2, false, 2, true, "chain_convin_bf16_d512"); else CFM_RC(F16, 512, 64, 2, false, 2, true, "chain_convin_f16_d512"); }
+        if (head && mid && !tail) { if (bf) CFM_RC(BF16, 512, 2048, 2, true, 0, false, "chain_final_bf16_d512"); else CFM_RC(F16, 512, 2048, 2, true, 0, false, "chain_final_f16_d512"); }
     }
 #undef CFM_RC
 #undef CFM_RCDW

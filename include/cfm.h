@@ -293,6 +293,8 @@ typedef struct {
 int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
 /* 1 when cfm_rowchain has instances for all three chains of a block with these sizes (host query) */
 int cfm_rowchain_supported(int32_t D, int32_t FF);
+/* 1 when the depthwise input stage (dw_w ...) exists at this width; otherwise cfm_dwconv_bn_silu runs in front of the final chain (D = 512) */
+int cfm_rowchain_dw_supported(int32_t D);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (eps inside sqrt, biased variance), optionally two chained norms in one pass:

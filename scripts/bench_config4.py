@@ -28,12 +28,12 @@ with torch.no_grad(), torch.cuda.stream(stream):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=stream):
         y, m = enc(x, lens)
-    for _ in range(5):
+    for _ in range(60):                                   # ~0.25 s: the clocks settle (bench.py's ramp note)
         g.replay()
     stream.synchronize(); t0 = time.perf_counter()
-    for _ in range(50):
+    for _ in range(100):
         g.replay()
-    stream.synchronize(); ms = (time.perf_counter() - t0) / 50 * 1e3
+    stream.synchronize(); ms = (time.perf_counter() - t0) / 100 * 1e3
     fl = O.encoder_flops_per_utt(T, 80, 512, 2048, 15, 17) * B
     print("config 4 encoder (17 x d=512, B=16, T=1000, %s): %.3f ms per forward = %.2f M frames/s, %.1f TFLOP/s = %.3f of the dense MFMA peak"
           % (prec, ms, B * T / ms / 1e3, fl / ms / 1e9, fl / ms / 1e9 / 2500.0))

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 static void* dalloc(size_t bytes, int fill) {
@@ -106,7 +107,139 @@ static void run(const char* name, cfm_rowchain_desc d, int M) {
            tot, wsum / nb / 100.0, tot / (wsum / nb * 10.0), (w_lastst - w_first) / 100.0, (w_last - w_first) / 100.0);
 }
 
-int main() {
+// D = 512 (config 4: 3 984 rows = 125 workgroups): the three plain chains; stamps 3 -> 4 (phase 1, first half of FF) -> 15 (phase 2) -> 14 (phase 1,
+// second half) -> 5 (phase 2 + y tile)
+static void run_wide(const char* name, cfm_rowchain_desc d, int M) {
+    d.M = M;
+    const int grid = (M + 31) / 32;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) if (cfm_rowchain(&d, nullptr) != 0) { fprintf(stderr, "%s: %s\n", name, cfm_last_error()); exit(1); }
+    {
+        std::vector<long long> zero(1024 * 16, 0);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(cfm_chain_stamps), zero.data(), sizeof(long long) * 1024 * 16);
+    }
+    (void)hipEventRecord(e0, nullptr);
+    const int reps = 50;
+    for (int i = 0; i < reps; ++i) cfm_rowchain(&d, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(1024 * 16);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(cfm_chain_stamps), sizeof(long long) * 1024 * 16);
+    const int nb = grid < 1024 ? grid : 1024;
+    static const int order[10] = {0, 1, 2, 3, 4, 15, 14, 5, 6, 7};
+    static const char* what[10] = {"", "head: stage A tile", "head: GEMM + epilogue", "rows + LN_in", "FFN phase 1, half 0", "FFN phase 2, half 0", "FFN phase 1, half 1",
+                                   "FFN phase 2, half 1 + y tile", "post norms", "tail GEMM + stores"};
+    printf("%-12s D=512 M=%5d grid=%4d  %7.2f us/launch (back-to-back)\n", name, M, grid, ms * 1000.f / reps);
+    for (int b = 0; b < nb; ++b)
+        for (int i = 1; i < 10; ++i)
+            if (h[b * 16 + order[i]] == 0) h[b * 16 + order[i]] = h[b * 16 + order[i - 1]];
+    double tot = 0;
+    for (int i = 1; i < 10; ++i) {
+        double sum = 0; long long mx = 0;
+        for (int b = 0; b < nb; ++b) {
+            const long long dt = h[b * 16 + order[i]] - h[b * 16 + order[i - 1]];
+            sum += (double)dt; mx = dt > mx ? dt : mx;
+        }
+        printf("    %-30s %9.0f cycles mean   %9lld max\n", what[i], sum / nb, mx);
+        tot += sum / nb;
+    }
+    double wsum = 0;
+    for (int b = 0; b < nb; ++b) wsum += (double)(h[b * 16 + 9] - h[b * 16 + 8]);
+    printf("    in-kernel total %9.0f cycles mean = %.2f us mean by the 100 MHz wall clock\n", tot, wsum / nb / 100.0);
+}
+
+// random contents (argv[2] = 1): N(0, scale) as f32 or bf16 -- the MFMA inputs toggle as they do in the encoder (all-zero operands draw less power)
+static void fill_random(void* p, size_t n, bool half, float scale, unsigned seed) {
+    std::vector<float> f(half ? 0 : n);
+    std::vector<unsigned short> h(half ? n : 0);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        float acc = 0.f;
+        for (int k = 0; k < 4; ++k) { s = s * 1664525u + 1013904223u; acc += (float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f; }
+        const float v = acc * 1.7320508f * scale;
+        if (half) { unsigned u; memcpy(&u, &v, 4); h[i] = (unsigned short)(u >> 16); } else f[i] = v;
+    }
+    (void)hipMemcpy(p, half ? (void*)h.data() : (void*)f.data(), n * (half ? 2 : 4), hipMemcpyHostToDevice);
+}
+
+static int main_wide(bool rnd) {
+    const int D = 512, FF = 2048, MMAX = 7968;
+    cfm_rowchain_desc z = {};
+    float* x = (float*)dalloc((size_t)MMAX * D * 4, 0);
+    float* res = (float*)dalloc((size_t)MMAX * D * 4, 0);
+    float* out = (float*)dalloc((size_t)MMAX * D * 4, 0);
+    void* a16 = dalloc((size_t)MMAX * D * 2, 0);
+    void* t16 = dalloc((size_t)MMAX * 3 * D * 2, 0);
+    void* w1f = dalloc((size_t)FF * D * 2, 0x11);
+    void* w2f = dalloc((size_t)FF * D * 2, 0x11);
+    void* wh = dalloc((size_t)D * D * 2, 0x11);
+    void* wt = dalloc((size_t)3 * D * D * 2, 0x11);
+    float* vec = (float*)dalloc(4096 * 4, 0);
+    if (rnd) {
+        printf("random operands\n");
+        fill_random(x, (size_t)MMAX * D, false, 1.0f, 1); fill_random(res, (size_t)MMAX * D, false, 1.0f, 2); fill_random(a16, (size_t)MMAX * D, true, 1.0f, 3);
+        fill_random(w1f, (size_t)FF * D, true, 0.04f, 4); fill_random(w2f, (size_t)FF * D, true, 0.02f, 5); fill_random(wh, (size_t)D * D, true, 0.04f, 6);
+        fill_random(wt, (size_t)3 * D * D, true, 0.04f, 7); fill_random(vec, 4096, false, 1.0f, 8);
+    }
+    uint8_t* mask = (uint8_t*)dalloc(MMAX, 1);
+    cfm_rowchain_desc mac = z;
+    mac.x = x; mac.ln_g = vec; mac.ln_b = vec; mac.w1f = w1f; mac.w2n = w2f; mac.b1 = vec; mac.b2 = vec; mac.ln2_g = vec; mac.ln2_b = vec;
+    mac.out_f32 = out; mac.tail_w = wt; mac.tail_b = vec; mac.tail_out = t16; mac.D = D; mac.FF = FF; mac.tail_N = 3 * D; mac.w_dtype = CFM_BF16;
+    mac.alpha = 0.5f; mac.eps = 1e-5f;
+    cfm_rowchain_desc cin = z;
+    cin.head_a = a16; cin.head_w = wh; cin.head_b = vec; cin.head_res = res; cin.ln_g = vec; cin.ln_b = vec; cin.ln_mask = mask;
+    cin.out_f32 = out; cin.tail_w = wt; cin.tail_b = vec; cin.tail_out = t16; cin.D = D; cin.tail_N = 2 * D; cin.tail_glu = 1; cin.w_dtype = CFM_BF16;
+    cin.eps = 1e-5f;
+    cfm_rowchain_desc fin = z;
+    fin.head_a = a16; fin.head_w = wh; fin.head_b = vec; fin.head_res = res; fin.head_mask = mask; fin.ln_g = vec; fin.ln_b = vec;
+    fin.w1f = w1f; fin.w2n = w2f; fin.b1 = vec; fin.b2 = vec; fin.ln1_g = vec; fin.ln1_b = vec; fin.out_f32 = out; fin.D = D; fin.FF = FF;
+    fin.w_dtype = CFM_BF16; fin.alpha = 0.5f; fin.eps = 1e-5f;
+    for (int M : {32, 3984, 7968}) {
+        run_wide("macaron", mac, M);
+        run_wide("conv-in", cin, M);
+        run_wide("final", fin, M);
+    }
+    {   // cold weights: 17 rotating weight sets (as the 17 blocks of config 4 do), M = 3 984
+        const int L = 17;
+        std::vector<cfm_rowchain_desc> macs(L, mac), cins(L, cin), fins(L, fin);
+        for (int l = 0; l < L; ++l) {
+            void* a1 = dalloc((size_t)FF * D * 2, 0x11); void* a2 = dalloc((size_t)FF * D * 2, 0x11);
+            void* a3 = dalloc((size_t)3 * D * D * 2, 0x11); void* a4 = dalloc((size_t)D * D * 2, 0x11);
+            void* b1 = dalloc((size_t)FF * D * 2, 0x11); void* b2 = dalloc((size_t)FF * D * 2, 0x11);
+            void* b3 = dalloc((size_t)2 * D * D * 2, 0x11); void* b4 = dalloc((size_t)D * D * 2, 0x11);
+            macs[l].w1f = a1; macs[l].w2n = a2; macs[l].tail_w = a3; macs[l].M = 3984;
+            cins[l].head_w = a4; cins[l].tail_w = b3; cins[l].M = 3984;
+            fins[l].w1f = b1; fins[l].w2n = b2; fins[l].head_w = b4; fins[l].M = 3984;
+        }
+        for (int which = 0; which < 4; ++which) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            auto go = [&](int l) {
+                if (which == 0 || which == 3) cfm_rowchain(&macs[l], nullptr);
+                if (which == 1 || which == 3) cfm_rowchain(&cins[l], nullptr);
+                if (which == 2 || which == 3) cfm_rowchain(&fins[l], nullptr);
+            };
+            for (int l = 0; l < L; ++l) go(l);
+            (void)hipEventRecord(e0, nullptr);
+            const int reps = which == 3 ? 200 : 10;         // the whole block: long enough (0.45 s) for the clocks to settle under the load
+            for (int r = 0; r < reps; ++r)
+                for (int l = 0; l < L; ++l) go(l);
+            (void)hipEventRecord(e1, nullptr);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            static const char* nm[4] = {"macaron", "conv-in", "final", "macaron + conv-in + final"};
+            printf("%s, 17 rotating weight sets (L2-cold weights), M = 3984: %.2f us per %s back-to-back\n", nm[which], ms * 1000.f / (reps * L), which == 3 ? "block" : "launch");
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 512) return main_wide(argc > 2 && atoi(argv[2]) == 1);
     const int D = 256, FF = 2048, MMAX = 7968;
     cfm_rowchain_desc z = {};
     float* x = (float*)dalloc((size_t)MMAX * D * 4, 0);

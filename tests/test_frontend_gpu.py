@@ -15,7 +15,11 @@ def _two_kernel(cfm, x, w1, b1, w2, b2, cmvn):
     C = w1.shape[1]
     T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
     T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-    h1 = cfm.conv1_relu(x, w1, b1, w2.dtype, cmvn=cmvn, mma=True)
+    if C <= 256:
+        h1 = cfm.conv1_relu(x, w1, b1, w2.dtype, cmvn=cmvn, mma=True)
+    else:       # the stand-alone MFMA conv1 stops at 256 channels: two channel halves side by side are the same values
+        h1 = torch.cat([cfm.conv1_relu(x, w1[:, c0:c0 + 256].contiguous(), b1[c0:c0 + 256].contiguous(), w2.dtype, cmvn=cmvn, mma=True).view(B, T1, F1, 256)
+                        for c0 in range(0, C, 256)], dim=-1).contiguous()
     return cfm.gemm(h1, w2, bias=b2, act=cfm.ACT_RELU, conv=(C, T1, F1, T2, F2, B * T2 * F2), out_dtype=w2.dtype)
 
 
@@ -28,6 +32,8 @@ SHAPES = [
     (24, 1000, 80, 256),    # 113 544 rows: one whole round of 256-row tiles + a 128-row tail... (depends on the CU count)
     (32, 1000, 80, 256),    # BASELINE config 2: two whole rounds + 20 320 rows on 96-row tiles
     (40, 403, 80, 256),     # 75 240 rows: more than half a round left after one whole round
+    (2, 131, 80, 512),      # C = 512: two workgroups (halves of N) per row tile, eight channel slabs; tail tiles only
+    (16, 1000, 80, 512),    # BASELINE config 4: 75 696 rows = two whole rounds of (128 tiles x 2 halves) + a 96-row-tile round
 ]
 
 
@@ -83,7 +89,7 @@ def test_module_uses_fused_path_and_matches():
 def test_unsupported_sizes_are_refused():
     import cfm
     assert not cfm.conv12_supported(80, torch.bfloat16)
-    assert not cfm.conv12_supported(512, torch.bfloat16)
+    assert cfm.conv12_supported(512, torch.bfloat16) and not cfm.conv12_supported(384, torch.bfloat16) and not cfm.conv12_supported(1024, torch.bfloat16)
     assert not cfm.conv12_supported(256, torch.float32)
     x = torch.zeros((1, 16, 16), device=DEV)
     with pytest.raises(RuntimeError):
