@@ -85,7 +85,7 @@ class RowChainDesc(ctypes.Structure):
                 ("att_qkv", c_p), ("att_vt", c_p), ("att_p", c_p), ("att_bias_u", c_p), ("att_bias_v", c_p), ("att_mask", c_p),
                 ("att_p_sb", c_i64), ("att_m_sb", c_i64), ("att_T", c_i32), ("att_H", c_i32), ("att_vt_ld", c_i32), ("att_scale", ctypes.c_float),
                 ("s2_ln_g", c_p), ("s2_ln_b", c_p), ("s2_w1f", c_p), ("s2_w2n", c_p), ("s2_b1", c_p), ("s2_b2", c_p), ("s2_out_f32", c_p),
-                ("s2_alpha", ctypes.c_float)]
+                ("s2_alpha", ctypes.c_float), ("psum_out", c_p), ("psum_in", c_p), ("psum_b2", c_p), ("psum_alpha", ctypes.c_float), ("tail_pair", c_i32)]
 
 
 _LAYER_W_FIELDS = [
@@ -224,6 +224,7 @@ def lib():
         L.cfm_pack_ffn_fragments.argtypes = [c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_rowchain.argtypes = [ctypes.POINTER(RowChainDesc), c_p]
         L.cfm_rowchain_supported.argtypes = [c_i32, c_i32]
+        L.cfm_rowchain_pair_supported.argtypes = [c_i32, c_i32]
         L.cfm_layernorm.argtypes = [c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, ctypes.c_float, c_i64, c_i32, c_p]
         L.cfm_kv_cache_pack.argtypes = [c_p, c_i32, c_p, c_p, c_i32, c_i64, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_dwconv_bn_silu.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]

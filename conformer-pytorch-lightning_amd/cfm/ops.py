@@ -10,7 +10,7 @@ import cfm as _c
 
 __all__ = ["stream_prep", "stream_advance", "dwconv_causal_bn_silu", "conv_cache_update", "dropout_rows", "dropout_mask", "set_deterministic", "gemm_tn", "gemm_tn_group", "layernorm_bwd", "glu_bwd", "dwconv_bn_train", "dwconv_bn_train_bwd", "col2im_relu_bwd", "conv1_wgrad", "attention_bwd",
            "ctc_nll_train", "ctc_nll_train_groups", "ctc_grad", "ffn_split", "adam_step", "adam_clip_step", "sumsq", "scratch_stats",
-           "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "conv12_relu", "conv12_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
+           "gemm", "ffn_fused", "ffn_fused_supported", "rowchain", "rowchain_supported", "rowchain_pair_supported", "layernorm", "attention", "kv_cache_pack", "dwconv_bn_silu", "conv1_relu", "conv1_relu_mma_supported", "conv12_relu", "conv12_supported", "ctc_nll", "joint_act", "valid_mask", "chunk_mask",
            "attn_mask_combine", "cast", "add_rows", "scratch", "prof_enable", "prof_reset", "prof_table", "as_u8_mask"]
 
 
@@ -146,6 +146,11 @@ def ffn_fused(x, w1f, w2f, b1, b2, FF, act=_c.ACT_SILU, ln=None, alpha=1.0, add_
 
 def rowchain_supported(D, FF, prec):
     return (not prec.split) and bool(_c.lib().cfm_rowchain_supported(D, FF))
+
+
+def rowchain_pair_supported(D, FF, prec):
+    """The feed-forward split over workgroup pairs (cfm_rowchain_desc.psum_out / psum_in, D = 512)."""
+    return (not prec.split) and bool(_c.lib().cfm_rowchain_pair_supported(D, FF))
 
 
 def ffn_split(x, w_code, mode, psum=None, psum_b2=None, psum_alpha=1.0, ln1=None, ln2=None, rows_out=None, rows2_out=None, ln=None, w1=None, b1=None,

@@ -106,7 +106,21 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         f.M = M; f.D = D; f.mode = mode; f.w_dtype = c.w_dt; f.eps = eps;
         return f;
     };
-    if (ffsplit) {
+    // D = 512 with at most one row tile per CU pair (config 4: 125 tiles): both feed-forwards split over workgroup pairs, one half of FF each
+    // (rowchain.hip FSPLIT); the halves meet in the next launch's row load
+    static const int pair_rows = getenv("CFM_PAIR_MAX_ROWS") ? atoi(getenv("CFM_PAIR_MAX_ROWS")) : CFM_PAIR_MAX_ROWS;
+    const bool pair = chains && s->psum && s->psum_splits >= 3 && M <= pair_rows && cfm_rowchain_pair_supported(D, FF) && !io->macaron_done && !io->next_w;
+    if (pair) {
+        cfm_rowchain_desc m = {};
+        m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2n = w->ffm_w2n; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
+        m.psum_out = s->psum; m.M = M; m.D = D; m.FF = FF; m.w_dtype = c.w_dt; m.alpha = 0.5f; m.eps = eps;
+        CFM_TRY(cfm_rowchain(&m, stream));
+        cfm_rowchain_desc q = {};                         // rows = x + 1/2 (half 0 + half 1 + b2) -> x_out, LN_mha, fused q|k|v projection
+        q.x = x_in; q.psum_in = s->psum; q.psum_b2 = w->ffm_b2; q.psum_alpha = 0.5f; q.out_f32 = x_out; q.ln_g = w->ln_mha_g; q.ln_b = w->ln_mha_b;
+        q.tail_w = w->qkv_wf; q.tail_b = w->qkv_b; q.tail_out = s->qkv; q.tail_N = 3 * D; q.M = M; q.D = D; q.FF = FF; q.w_dtype = c.w_dt; q.alpha = 1.0f; q.eps = eps;
+        q.tail_pair = 1;
+        CFM_TRY(cfm_rowchain(&q, stream));
+    } else if (ffsplit) {
         // macaron feed-forward as partial slabs; then rows = x + 1/2 (sum + b2) -> x_out, LN_mha, fused q|k|v projection
         cfm_ffn_split_desc f = split_desc(2);
         f.x = x_in; f.ln_g = w->ln_ffm_g; f.ln_b = w->ln_ffm_b; f.w1 = w->ffm_w1f; f.b1 = w->ffm_b1; f.N1 = FF; f.act = CFM_ACT_SILU; f.w2 = w->ffm_w2n;
@@ -118,7 +132,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         ring_written = ring && dk % 4 == 0;
         if (ring_written) { q.kv_ring = io->kv_ring; q.ring_offsets = io->stream_offset; q.ring_T = io->ring_T; q.ring_H = H; q.ring_Tq = io->T; }
         CFM_TRY(cfm_ffn_split(&q, stream));
-    } else if (chains && !io->macaron_done) {
+    } else if (chains && !io->macaron_done && !pair) {
         cfm_rowchain_desc m = {};
         if (merged) { m.tail_vt = s->vt; m.vt_T = io->T; m.vt_ld = s->vt_ld; }
         m.x = x_in; m.ln_g = w->ln_ffm_g; m.ln_b = w->ln_ffm_b; m.w1f = w->ffm_w1f; m.w2n = w->ffm_w2n; m.b1 = w->ffm_b1; m.b2 = w->ffm_b2;
@@ -200,6 +214,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         ci.head_a = s->ctx; ci.head_w = w->out_wf; ci.head_b = w->out_b; ci.head_res = x_out; ci.ln_g = w->ln_conv_g; ci.ln_b = w->ln_conv_b;
         ci.ln_mask = io->pad_valid; ci.out_f32 = x_out; ci.tail_w = w->pw1_wf; ci.tail_b = w->pw1_b; ci.tail_out = s->glu;
         ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
+        if (pair) { ci.tail_pair = 1; ci.out_f32 = s->psum + (int64_t)2 * M * D; }   // the pair's other workgroup still reads x_out: the rows go to the third slab
         if (!merged) CFM_TRY(cfm_rowchain(&ci, stream));
         // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own
         const bool dw_fused = io->ktaps == 15 && !io->causal_conv && cfm_rowchain_dw_supported(D);
@@ -229,6 +244,21 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
             r.rows_out = x_out;
             if (io->after_out) { r.ln2_g = io->after_g; r.ln2_b = io->after_b; r.rows2_out = io->after_out; }
             return cfm_ffn_split(&r, stream);
+        }
+        if (pair) {
+            // pointwise-conv-2 + pad mask + residual (the conv-in chain's rows in the third slab) -> rows, parked in x_out -> LN_ff -> this workgroup's
+            // half of the feed-forward; then rows + 1/2 (halves + b2) -> LN_final, in place on x_out (one workgroup per row tile)
+            float* const park = s->psum + (int64_t)2 * M * D;  // the conv-in chain's rows
+            cfm_rowchain_desc fa = {};
+            fa.head_a = s->dw; fa.head_w = w->pw2_wf; fa.head_b = w->pw2_b; fa.head_res = park; fa.head_mask = io->pad_valid;
+            fa.ln_g = w->ln_ff_g; fa.ln_b = w->ln_ff_b; fa.w1f = w->ff_w1f; fa.w2n = w->ff_w2n; fa.b1 = w->ff_b1; fa.b2 = w->ff_b2;
+            fa.out_f32 = x_out; fa.psum_out = s->psum; fa.M = M; fa.D = D; fa.FF = FF; fa.w_dtype = c.w_dt; fa.alpha = 0.5f; fa.eps = eps;
+            CFM_TRY(cfm_rowchain(&fa, stream));
+            cfm_rowchain_desc fr = {};
+            fr.x = x_out; fr.psum_in = s->psum; fr.psum_b2 = w->ff_b2; fr.psum_alpha = 0.5f; fr.ln_g = w->ln_final_g; fr.ln_b = w->ln_final_b;
+            fr.out2_f32 = x_out; fr.M = M; fr.D = D; fr.FF = FF; fr.w_dtype = c.w_dt; fr.alpha = 1.0f; fr.eps = eps;
+            CFM_TRY(cfm_rowchain(&fr, stream));
+            return after_tail();
         }
         // final chain: pointwise-conv-2 + pad mask + residual -> LN_ff -> FFN -> +res -> LN_final, in place on x_out
         cfm_rowchain_desc fi = {};

@@ -88,6 +88,11 @@ struct ChainArgs {
     const float *s2_b1, *s2_b2;
     float* s2_out_f32;
     float s2_alpha;
+    // FSPLIT (D = 512): this launch computes ONE half of the feed-forward per workgroup and leaves partial sums psum_out[half][M][D]; the reduce rides in
+    // the next launch's row load: rows = x + psum_alpha * (psum_in[0] + psum_in[1] + psum_b2)
+    float* psum_out;
+    const float *psum_in, *psum_b2;
+    float psum_alpha;
 };
 
 // Phase stamps for scripts/probe_chain.hip (built with -DCFM_CHAIN_STAMPS; never defined in the product build): thread 0 of each
@@ -204,7 +209,7 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
             if ((lane + 64 * it) * 4 < D) v[rr][it] = (v[rr][it] - mean[rr]) * rstd[rr] * gam[it] + bet[it];
 }
 
-template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false>
+template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false, bool FSPLIT = false, bool TSPLIT = false>
 __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr bool HEAD = HSTEPS > 0, TAIL = TSTEPS > 0;
     constexpr int NSEG = SEG2 ? 2 : 1;
@@ -212,6 +217,9 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     static_assert(!HATT || (HEAD && !HDW && !MID && D == 256), "the attention input stage: conv-in chain, 4 heads x 64");
     constexpr bool WIDE = D > 256;                         // D = 512 (config 4): feed-forward in two halves of FF, K-chunked head / tail weight rings
     static_assert(!WIDE || (!HDW && !HATT && !TVT && !SEG2 && D == 512), "the wide instances: plain macaron / conv-in / final chains at D = 512");
+    static_assert(!FSPLIT || (WIDE && MID && TSTEPS == 0), "the pair split: a wide feed-forward chain without a tail");
+    static_assert(!TSPLIT || (WIDE && !MID && TSTEPS > 0), "the tail split: a wide chain without a feed-forward, half of the tail's columns per workgroup");
+    constexpr bool PAIRED = FSPLIT || TSPLIT;
     static_assert(!TVT || (TAIL && !TGLU && D == 256), "transposed values: a fused-QKV tail with 64-wide heads");
     constexpr int DWK = 15, DWH = (DWK - 1) / 2, DWROWS = RBM + DWK - 1;     // depthwise taps, halo, rows of the halo tile
     constexpr int KS1 = (D + 31) / 32;                     // 32-wide K slices of a D-long row
@@ -250,7 +258,16 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     if constexpr (HATT) {
         if ((int64_t)att_b * a.att_T >= a.M) return;     // uniform, before any barrier
     }
-    const int64_t row0 = HATT ? (int64_t)att_b * a.att_T + att_t0 : (int64_t)blockIdx.x * RBM;
+    // FSPLIT: workgroup id -> (row tile, half of FF).  Workgroups go round-robin over the 8 XCDs: XCDs 0-3 take the first half, 4-7 the second, so an
+    // XCD's L2 streams ONE half's weights (2 MB of a feed-forward, not 4); ids past the last tile exit
+    // TSPLIT: the same pairs, each workgroup HALF of the tail's columns (rows and LayerNorm computed by both, the rows written by the first)
+    const int fs_xcd = blockIdx.x & 7;
+    const int fsel = FSPLIT ? fs_xcd >> 2 : 0, tsel = TSPLIT ? fs_xcd >> 2 : 0;
+    const int fs_tile = PAIRED ? (int)(blockIdx.x >> 3) * 4 + (fs_xcd & 3) : (int)blockIdx.x;
+    if constexpr (PAIRED) {
+        if ((int64_t)fs_tile * RBM >= a.M) return;         // uniform, before any barrier
+    }
+    const int64_t row0 = HATT ? (int64_t)att_b * a.att_T + att_t0 : (int64_t)fs_tile * RBM;
     const int64_t Mlim = HATT ? (int64_t)(att_b + 1) * a.att_T : a.M;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     CFM_STAMP(0);
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     // The tail's weight ring is declared here so that its first fill can be issued a phase or two before the tail runs
     // (with no FFN in between: at kernel start; otherwise at the end of the FFN's second phase).
     const int t_nfrags = TAIL ? a.tail_N / 16 : 1;
-    auto t_frag0 = [&](int s) { return (s * NW + wave) * TFR; };
+    auto t_frag0 = [&](int s) { return (s * NW + wave) * TFR + (TSPLIT ? tsel * (t_nfrags / 2) : 0); };
     auto t_clamp = [&](int f) { return f < t_nfrags ? f : t_nfrags - 1; };
     const u32x4* twp = (const u32x4*)a.tail_w + lane;
     constexpr int TRG = WIDE ? (MID ? (TFR == 2 ? 8 : 6) : 10) : TFR * KS1;      // WIDE: a ring over the steps' positions (ring_step) instead of one step's whole K
@@ -295,6 +312,20 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             for (int it = 0; it < VPL; ++it) {
                 const int c = (lane + 64 * it) * 4;
                 xres[rr][it] = c < D ? *(const f32x4*)(a.x + ln_rows[rr] * D + c) : zero4;
+            }
+            if constexpr (WIDE && !MID) {
+                if (a.psum_in) {                           // the pair-split feed-forward of the previous launch: the two halves meet here, fixed order
+#pragma unroll
+                    for (int it = 0; it < VPL; ++it) {
+                        const int c = (lane + 64 * it) * 4;
+                        if (c < D) {
+                            const f32x4 p0 = *(const f32x4*)(a.psum_in + ln_rows[rr] * D + c);
+                            const f32x4 p1 = *(const f32x4*)(a.psum_in + (a.M + ln_rows[rr]) * D + c);
+                            const f32x4 pb = *(const f32x4*)(a.psum_b2 + c);
+                            xres[rr][it] = a.psum_alpha * ((p0 + p1) + pb) + xres[rr][it];
+                        }
+                    }
+                }
             }
         }
     }
@@ -661,7 +692,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr int NPAIR1 = FFH / 32, P1 = (NPAIR1 + NW - 1) / NW;          // per half of FF (FH = 1: the whole of it)
     constexpr int KPARTS = WIDE ? 1 : 2;                   // phase 2: wavefronts per output-fragment pair (parts of K)
     constexpr int KS2 = FF / 32, KS2H = FFH / 32, KH = KS2H / KPARTS;
-    constexpr int NPOS1 = P1 * KS1 * 2, NPOS2 = KH * 2, NPOSH = NPOS1 + NPOS2, NPOS = FH * NPOSH;
+    constexpr int FHL = FSPLIT ? 1 : FH;                   // halves of FF this workgroup runs (FSPLIT: one, chosen by fsel)
+    constexpr int NPOS1 = P1 * KS1 * 2, NPOS2 = KH * 2, NPOSH = NPOS1 + NPOS2, NPOS = FHL * NPOSH;
     constexpr int RING = WIDE && TAIL ? 8 : 10;                           // (measured, config 2 step: 8 .. 12 slots within 0.3 %; 16 spills ~10 VGPRs at the 128-register budget)
     static_assert(!MID || ((NF2 + 1) / 2 <= NW / KPARTS && KS2H % KPARTS == 0), "phase 2 maps (fragment pair, K part) onto 16 wavefronts");
     static_assert(!(WIDE && MID) || NPAIR1 % NW == 0, "wide: whole rounds of hidden-fragment pairs");
@@ -676,7 +708,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     u32x4 ring[RING];
     auto pair_of = [&](int i) { const int q = i * NW + wave; return q < NPAIR1 ? q : NPAIR1 - 1; };
     auto frag_ptr = [&](int gpos) {
-        const int fh = gpos / NPOSH, pos = gpos % NPOSH;     // (FH = 1: fh = 0, pos = gpos)
+        const int fh = FSPLIT ? fsel : gpos / NPOSH, pos = gpos % NPOSH;     // (FH = 1: fh = 0, pos = gpos)
         if (pos < NPOS1) {
             const int i = pos / (2 * KS1), kk = (pos / 2) % KS1, nf = pos & 1;
             return w1p + ((int64_t)(2 * (fh * NPAIR1 + pair_of(i)) + nf) * KS1 + kk) * 64;
@@ -752,7 +784,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
         // WIDE + feed-forward: the residual rows do not stay in registers across the feed-forward (16 VGPRs = 4 ring slots); rows made by the head
         // GEMM are parked in out_f32 (this thread's own elements, overwritten with the result at the end), rows from memory are read again
         if constexpr (!MID || (WIDE && HEAD)) {            // no FFN here: the rows ARE the new residual stream
-            if (a.out_f32) {
+            if (a.out_f32 && (!TSPLIT || tsel == 0)) {
 #pragma unroll
                 for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
@@ -768,6 +800,17 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
             for (int it = 0; it < VPL; ++it) w[rr][it] = xres[rr][it];
         if (a.ln_g) rows_layernorm<RPW, VPL, D>(w, gam, bet, a.eps, lane);
+        if constexpr (WIDE && !MID && !TAIL) {             // a bare rows chain (the reduce behind a pair-split final feed-forward): the normalised rows ARE the output
+            if (a.out2_f32) {
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                    for (int it = 0; it < VPL; ++it) {
+                        const int c = (lane + 64 * it) * 4;
+                        if (c < D && row0 + wave * RPW + rr < Mlim) *(f32x4*)(a.out2_f32 + (row0 + wave * RPW + rr) * D + c) = w[rr][it];
+                    }
+            }
+        }
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
@@ -786,9 +829,10 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     if constexpr (MID) {
         f32x4 acc2[MF][2];
 #pragma unroll
-        for (int fh = 0; fh < FH; ++fh) {                   // (FH = 1 except WIDE)
-        const int pbase = fh * NPOSH;
-        if (fh > 0) {
+        for (int fhi = 0; fhi < FHL; ++fhi) {               // (FH = 1 except WIDE)
+        const int fh = FSPLIT ? fsel : fhi;
+        const int pbase = fhi * NPOSH;
+        if (fhi > 0) {
             __syncthreads();                                // every wavefront is done reading the previous half's hidden tile
             asm volatile("" : "+s"(wave));                  // (new values per half: see the note at the segment boundary)
             CFM_STAMP(15);
@@ -841,7 +885,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             }
         }
         __syncthreads();
-        CFM_STAMP(fh > 0 ? 14 : sg == 0 ? 4 : 11);
+        CFM_STAMP(fhi > 0 ? 14 : sg == 0 ? 4 : 11);
 
         // ---- phase 2: y = hidden . W2^T, fragments (2 np, 2 np + 1), K half kh
         asm volatile("" : "+s"(np), "+s"(kh));             // same reason: phase 2's 64 scalar offsets are otherwise computed (and spilled) at kernel entry
@@ -851,7 +895,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 hf[0][mf] = hfrag(mf, 0);
-                if (fh == 0) {
+                if (fhi == 0) {
                     acc2[mf][0] = zero4;
                     acc2[mf][1] = zero4;
                 }
@@ -872,13 +916,14 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (FH > 1) {
+        if constexpr (FHL > 1) {
             // the accumulators are next read after the LAST half: without an anchor here the compiler sinks this half's MFMAs below the next half's
             // barrier and keeps every fragment they read alive (spilled) until then
             asm volatile("" : "+v"(acc2[0][0]), "+v"(acc2[0][1]), "+v"(acc2[1][0]), "+v"(acc2[1][1]));
         }
         }   // FF halves
         // requests that land during the tile exchange below: post-norm parameters and the tail's first weights
+        if constexpr (!FSPLIT) {
 #pragma unroll
         for (int it = 0; it < VPL; ++it) {
             const int c = (lane + 64 * it) * 4;
@@ -920,6 +965,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 pn_be2[it] = c < D ? *(const f32x4*)(a.ln2_b + c) : zero4;
             }
         }
+        }   // !FSPLIT
         if constexpr (TAIL && !WIDE) {
             if (last_seg) tail_prefetch();
         }
@@ -948,6 +994,20 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     CFM_STAMP(sg == 0 ? 5 : 12);
 
     // ================= post norms: y1 -> out_f32, y2 -> out16 / next LDS tile =====================================
+    if constexpr (FSPLIT) {
+        // this half's partial sums leave as they are (no bias, no residual): full rows, 16 bytes per lane
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            const int64_t grow = row0 + r;
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                if (c < D && grow < Mlim) *(f32x4*)(a.psum_out + ((int64_t)fsel * a.M + grow) * D + c) = *(const f32x4*)(xs + r * XS_STRIDE + c);
+            }
+        }
+        return;
+    }
     if constexpr (MID) {
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
@@ -1057,19 +1117,21 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     CFM_STAMP(7);
 }
 
-template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false>
+template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false, bool FSPLIT = false, bool TSPLIT = false>
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
-    // HATT: tiles do not cross utterances (B x ceil(T / 32) workgroups)
-    const unsigned grid = HATT ? (unsigned)((((a.M / a.att_T) + 7) / 8) * 8 * ((a.att_T + RBM - 1) / RBM)) : (unsigned)((a.M + RBM - 1) / RBM);
+    // HATT: tiles do not cross utterances (B x ceil(T / 32) workgroups); FSPLIT: groups of 8 workgroups = 4 row tiles x 2 halves of FF
+    const unsigned tiles = (unsigned)((a.M + RBM - 1) / RBM);
+    const unsigned grid = HATT ? (unsigned)((((a.M / a.att_T) + 7) / 8) * 8 * ((a.att_T + RBM - 1) / RBM)) : (FSPLIT || TSPLIT) ? ((tiles + 3) / 4) * 8 : tiles;
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU, HATT, TVT, SEG2>), dim3(grid), dim3(NT), 0, s, a);
+    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU, HATT, TVT, SEG2, FSPLIT, TSPLIT>), dim3(grid), dim3(NT), 0, s, a);
     return cfm_launch_status(name);
 }
 
 }  // namespace
 
 extern "C" int cfm_rowchain_supported(int32_t D, int32_t FF) { return (D == 256 && FF == 2048) || (D == 144 && FF == 576) || (D == 512 && FF == 2048); }
-extern "C" int cfm_rowchain_dw_supported(int32_t D) { return D <= 256; }   // the depthwise input stage (one (channel pair, frame group) per thread)
+extern "C" int cfm_rowchain_dw_supported(int32_t D) { return D <= 256; }
+extern "C" int cfm_rowchain_pair_supported(int32_t D, int32_t FF) { return D == 512 && FF == 2048; }   // the depthwise input stage (one (channel pair, frame group) per thread)
 
 extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(d, "cfm_rowchain: null descriptor");
@@ -1095,7 +1157,15 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(!tail || (d->tail_b && d->tail_out && d->tail_N % 16 == 0 && d->tail_N > 0 && (!d->tail_glu || d->tail_N % 32 == 0)),
                   "cfm_rowchain: tail needs bias, output and N %% 16 == 0 (GLU: N %% 32 == 0)");
     CFM_CHECK_ARG(!tail || (mid ? d->ln2_g != nullptr : true), "cfm_rowchain: a tail after the FFN takes its input from the second LayerNorm");
+    const bool ps_out = d->psum_out != nullptr, ps_in = d->psum_in != nullptr;
+    CFM_CHECK_ARG(!ps_out || (mid && !tail && !seg2 && !dw && !att && !d->ln1_g && !d->ln2_g && cfm_rowchain_pair_supported(d->D, d->FF) &&
+                              (!head || (d->out_f32 && d->out_f32 != d->head_res))),
+                  "cfm_rowchain: psum_out needs a feed-forward chain at D = 512 without tail / post norms, and (with a head) out_f32 distinct from head_res");
+    CFM_CHECK_ARG(!ps_in || (!head && !mid && d->D == 512 && d->psum_b2 && d->x), "cfm_rowchain: psum_in needs a rows chain (no head, no feed-forward) at D = 512, x and psum_b2");
+    CFM_CHECK_ARG(!d->tail_pair || (tail && !mid && d->D == 512 && (d->tail_N / 16) % 2 == 0 && (!head || d->out_f32 != d->head_res)),
+                  "cfm_rowchain: tail_pair needs a chain with a tail and no feed-forward at D = 512, and (with a head) out_f32 distinct from head_res");
     ChainArgs a;
+    a.psum_out = d->psum_out; a.psum_in = d->psum_in; a.psum_b2 = d->psum_b2; a.psum_alpha = d->psum_alpha;
     a.x = d->x; a.head_a = (const u16*)d->head_a; a.head_w = (const u16*)d->head_w; a.head_b = d->head_b; a.head_res = d->head_res;
     a.dw_w = d->dw_w; a.dw_b = d->dw_b; a.dw_scale = d->dw_scale; a.dw_shift = d->dw_shift; a.dw_T = d->dw_T;
     a.head_mask = d->head_mask; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_mask = d->ln_mask; a.w1f = (const u16*)d->w1f; a.w2n = (const u16*)d->w2n;
@@ -1141,9 +1211,16 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
         if (!head && !mid && tail && !d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 2, false, "chain_qkv_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 2, false, "chain_qkv_f16_d144"); }
         if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 144, 64, 0, false, 0, false, "chain_rows_bf16_d144"); else CFM_RC(F16, 144, 64, 0, false, 0, false, "chain_rows_f16_d144"); }
     } else if (d->D == 512 && (!mid || d->FF == 2048)) {
+        if (d->tail_pair && !head && !d->tail_glu && tsteps == 6) { if (bf) return launch_chain<BF16, 512, 64, 0, false, false, 3, false, false, false, false, false, true>(a, s, "chain_qkv_pair_bf16_d512", fl); else return launch_chain<F16, 512, 64, 0, false, false, 3, false, false, false, false, false, true>(a, s, "chain_qkv_pair_f16_d512", fl); }
+        if (d->tail_pair && head && d->tail_glu && tsteps == 2) { if (bf) return launch_chain<BF16, 512, 64, 2, false, false, 1, true, false, false, false, false, true>(a, s, "chain_convin_pair_bf16_d512", fl); else return launch_chain<F16, 512, 64, 2, false, false, 1, true, false, false, false, false, true>(a, s, "chain_convin_pair_f16_d512", fl); }
+        if (d->tail_pair) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: tail_pair on the q|k|v rows chain and the conv-in chain only");
         if (!head && mid && tail && !d->tail_glu && tsteps == 6) { if (bf) CFM_RC(BF16, 512, 2048, 0, true, 6, false, "chain_macaron_bf16_d512"); else CFM_RC(F16, 512, 2048, 0, true, 6, false, "chain_macaron_f16_d512"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 512, 64, 2, false, 2, true, "chain_convin_bf16_d512"); else CFM_RC(F16, 512, 64, 2, false, 2, true, "chain_convin_f16_d512"); }
+        if (ps_out && head) { if (bf) return launch_chain<BF16, 512, 2048, 2, false, true, 0, false, false, false, false, true>(a, s, "chain_final_half_bf16_d512", fl); else return launch_chain<F16, 512, 2048, 2, false, true, 0, false, false, false, false, true>(a, s, "chain_final_half_f16_d512", fl); }
+        if (ps_out) { if (bf) return launch_chain<BF16, 512, 2048, 0, false, true, 0, false, false, false, false, true>(a, s, "chain_macaron_half_bf16_d512", fl); else return launch_chain<F16, 512, 2048, 0, false, true, 0, false, false, false, false, true>(a, s, "chain_macaron_half_f16_d512", fl); }
         if (head && mid && !tail) { if (bf) CFM_RC(BF16, 512, 2048, 2, true, 0, false, "chain_final_bf16_d512"); else CFM_RC(F16, 512, 2048, 2, true, 0, false, "chain_final_f16_d512"); }
+        if (!head && !mid && tail && !d->tail_glu && tsteps == 6) { if (bf) CFM_RC(BF16, 512, 64, 0, false, 6, false, "chain_qkv_bf16_d512"); else CFM_RC(F16, 512, 64, 0, false, 6, false, "chain_qkv_f16_d512"); }
+        if (!head && !mid && !tail) { if (bf) CFM_RC(BF16, 512, 64, 0, false, 0, false, "chain_rows_bf16_d512"); else CFM_RC(F16, 512, 64, 0, false, 0, false, "chain_rows_f16_d512"); }
     }
 #undef CFM_RC
 #undef CFM_RCDW

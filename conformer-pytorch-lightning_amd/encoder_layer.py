@@ -22,6 +22,7 @@ from convolution import ConvolutionModule
 from feedforward import PositionwiseFeedForwardModule, _inference_only
 
 _ABSENT = torch.ones((0, 0, 0), dtype=torch.bool)
+PAIR_MAX_ROWS = 4096       # include/cfm.h CFM_PAIR_MAX_ROWS: the pair-split feed-forward of the D = 512 row chains (one workgroup per CU up to 128 row tiles)
 SPLIT_FFN_FEW_ROWS = True  # STREAMING steps of <= 1536 rows run their feed-forwards split over FF/256 workgroups per row tile (csrc/ffnsplit.hip).  Only
 # the streaming entry points ask for it (split_ffn=True): a whole-utterance forward keeps one algorithm for every batch size, so that a batch shard
 # reproduces the batch bit for bit
@@ -144,6 +145,9 @@ class ConformerEncoderLayer(nn.Module):
         if split_ffn and SPLIT_FFN_FEW_ROWS and split_rows(M, D, FF) and adt != torch.float32 and chain_next is None and not macaron_done:
             # partial slabs of the feed-forward split over FF (cfm.h cfm_layer_scratch.psum, csrc/ffnsplit.hip): few rows, e.g. a streaming step
             s.psum, s.psum_splits = cfm.scratch("psum", (FF // 256) * M * D, torch.float32, dev).data_ptr(), FF // 256
+        elif M <= PAIR_MAX_ROWS and cfm.rowchain_pair_supported(D, FF, prec) and chain_next is None and not macaron_done:
+            # D = 512, at most 128 row tiles: feed-forwards split over workgroup pairs -- two partial slabs + the parked rows of the final chain
+            s.psum, s.psum_splits = cfm.scratch("psum", 3 * M * D, torch.float32, dev).data_ptr(), 3
         io = cfm.LayerIO()
         io.B, io.T, io.D, io.H, io.FF, io.ktaps = B, T, D, H, FF, self.kernel_size
         io.act_dtype, io.w_dtype = prec.act_code, prec.w_code

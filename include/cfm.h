@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFM_VERSION 300 /* 0.3.0: row groups in the train entry points (cfm_train_group, cfm_layer_train_io.n_groups), cfm_gemm_tn_group + deferred weight gradients, cfm_encoder_train_forward / _backward (the whole stack from one host call). 0.2.3: cfm_ffn_split, cfm_layer_scratch.psum (the feed-forward split over FF for few rows). 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
+#define CFM_VERSION 301 /* 0.3.1: row chains at D = 512, cfm_rowchain_desc.psum_out / psum_in (feed-forward split over workgroup pairs), cfm_conv12_relu at C = 512. 0.3.0: row groups in the train entry points (cfm_train_group, cfm_layer_train_io.n_groups), cfm_gemm_tn_group + deferred weight gradients, cfm_encoder_train_forward / _backward (the whole stack from one host call). 0.2.3: cfm_ffn_split, cfm_layer_scratch.psum (the feed-forward split over FF for few rows). 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
 
 typedef void* cfm_stream_t;
 
@@ -288,6 +288,18 @@ typedef struct {
     const float *s2_b1, *s2_b2;
     float* s2_out_f32;
     float s2_alpha;
+    /* D = 512 (config 4: 3 984 rows are 125 row tiles for 256 CUs): the feed-forward of a chain split over PAIRS of workgroups, one half of FF each.
+     *   psum_out  (with w1f, no tail, no ln1 / ln2): the launch runs [head ->] LN -> this workgroup's half of the feed-forward and leaves the partial
+     *             sums psum_out[half][M][D] (f32, without b2 / alpha / residual); a head chain also writes its rows x to out_f32, which must NOT alias
+     *             head_res then (the pair's other workgroup still reads it).  2 x ceil(M/32) workgroups, halves on different XCDs.
+     *   psum_in   (a chain without head and feed-forward): the rows are x + psum_alpha * (psum_in[0] + psum_in[1] + psum_b2) -> out_f32, then LN -> the
+     *             tail; without a tail the normalised rows go to out2_f32. */
+    float* psum_out;
+    const float* psum_in;
+    const float* psum_b2;
+    float psum_alpha;
+    int32_t tail_pair; /* D = 512, a chain with a tail and no feed-forward: the tail's columns split over workgroup pairs (rows and LayerNorm computed by
+                          both, written by the first); out_f32 must NOT alias head_res then */
 } cfm_rowchain_desc;
 
 int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
@@ -295,6 +307,8 @@ int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream);
 int cfm_rowchain_supported(int32_t D, int32_t FF);
 /* 1 when the depthwise input stage (dw_w ...) exists at this width; otherwise cfm_dwconv_bn_silu runs in front of the final chain (D = 512) */
 int cfm_rowchain_dw_supported(int32_t D);
+/* 1 when the pair-split feed-forward (psum_out / psum_in) has instances at this size */
+int cfm_rowchain_pair_supported(int32_t D, int32_t FF);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (eps inside sqrt, biased variance), optionally two chained norms in one pass:
@@ -460,9 +474,12 @@ typedef struct {
     int32_t vt_ld; /* elements per row of vt: >= 256, multiple of 4 */
     float* psum;   /* optional f32 [psum_splits, M, D]: partial slabs of the split feed-forward (cfm_ffn_split).  Given with psum_splits >= FF/256,
                       blocks of at most CFM_FFSPLIT_MAX_ROWS rows at D = 256 run their two feed-forwards split over FF/256 workgroups per 32-row
-                      tile instead of inside the row chains (few rows: a streaming step); null = never */
+                      tile instead of inside the row chains (few rows: a streaming step); null = never.  At D = 512 (cfm_rowchain_pair_supported) with
+                      psum_splits >= 3 and at most CFM_PAIR_MAX_ROWS rows, both feed-forwards run split over workgroup PAIRS (two slabs + the parked rows of
+                      the final chain): 125 row tiles alone leave half of the CUs idle */
     int32_t psum_splits;
 } cfm_layer_scratch;
+#define CFM_PAIR_MAX_ROWS 4096    /* 128 row tiles x 2 halves = one workgroup per CU */
 #define CFM_FFSPLIT_MAX_ROWS 1536 /* measured crossover against the row chains: 996 rows -21 %, 1992 rows +4 % (scripts/bench_small_batch.py) */
 
 typedef struct {
