@@ -250,9 +250,15 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
             // half of the feed-forward; then rows + 1/2 (halves + b2) -> LN_final, in place on x_out (one workgroup per row tile)
             float* const park = s->psum + (int64_t)2 * M * D;  // the conv-in chain's rows
             cfm_rowchain_desc fa = {};
-            fa.head_a = s->dw; fa.head_w = w->pw2_wf; fa.head_b = w->pw2_b; fa.head_res = park; fa.head_mask = io->pad_valid;
+            if (w->pw2_w && getenv("CFM_PAIR_HEAD_IN_CHAIN") == nullptr) {
+                // the 0.5 MB head would be streamed by BOTH workgroups of every pair (+18 us per launch): it runs as a plain product over all CUs instead
+                CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, park, 1.0f, io->pad_valid));
+                fa.x = x_out;
+            } else {
+                fa.head_a = s->dw; fa.head_w = w->pw2_wf; fa.head_b = w->pw2_b; fa.head_res = park; fa.head_mask = io->pad_valid; fa.out_f32 = x_out;
+            }
             fa.ln_g = w->ln_ff_g; fa.ln_b = w->ln_ff_b; fa.w1f = w->ff_w1f; fa.w2n = w->ff_w2n; fa.b1 = w->ff_b1; fa.b2 = w->ff_b2;
-            fa.out_f32 = x_out; fa.psum_out = s->psum; fa.M = M; fa.D = D; fa.FF = FF; fa.w_dtype = c.w_dt; fa.alpha = 0.5f; fa.eps = eps;
+            fa.psum_out = s->psum; fa.M = M; fa.D = D; fa.FF = FF; fa.w_dtype = c.w_dt; fa.alpha = 0.5f; fa.eps = eps;
             CFM_TRY(cfm_rowchain(&fa, stream));
             cfm_rowchain_desc fr = {};
             fr.x = x_out; fr.psum_in = s->psum; fr.psum_b2 = w->ff_b2; fr.psum_alpha = 0.5f; fr.ln_g = w->ln_final_g; fr.ln_b = w->ln_final_b;

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr int KS2 = FF / 32, KS2H = FFH / 32, KH = KS2H / KPARTS;
     constexpr int FHL = FSPLIT ? 1 : FH;                   // halves of FF this workgroup runs (FSPLIT: one, chosen by fsel)
     constexpr int NPOS1 = P1 * KS1 * 2, NPOS2 = KH * 2, NPOSH = NPOS1 + NPOS2, NPOS = FHL * NPOSH;
-    constexpr int RING = WIDE && TAIL ? 8 : 10;                           // (measured, config 2 step: 8 .. 12 slots within 0.3 %; 16 spills ~10 VGPRs at the 128-register budget)
+    constexpr int RING = FSPLIT ? 14 : WIDE && TAIL ? 8 : 10;                           // (measured, config 2 step: 8 .. 12 slots within 0.3 %; 16 spills ~10 VGPRs at the 128-register budget)
     static_assert(!MID || ((NF2 + 1) / 2 <= NW / KPARTS && KS2H % KPARTS == 0), "phase 2 maps (fragment pair, K part) onto 16 wavefronts");
     static_assert(!(WIDE && MID) || NPAIR1 % NW == 0, "wide: whole rounds of hidden-fragment pairs");
     int np = KPARTS == 2 ? wave & 7 : wave, kh = KPARTS == 2 ? wave >> 3 : 0;

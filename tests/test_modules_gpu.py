@@ -334,8 +334,8 @@ def test_config2_full_size_against_oracle_and_properties(pkg, mode):
 @pytest.mark.parametrize("mode", MODES)
 def test_config4_encoder_shape_against_oracle(pkg, mode):
     """BASELINE config 4's encoder architecture (d=512, h=8, ff=2048, SURVEY 8: 17 layers) at a size the oracle finishes in
-    seconds: 3 layers, ragged batch of 3.  d=512 has no row-chain instance, so this exercises the general path of
-    cfm_encoder_layer_forward (separate GEMMs + LayerNorm + stand-alone depthwise kernel) against the same oracle."""
+    seconds: 3 layers, ragged batch of 3.  bf16 / fp16 take the D = 512 row chains on workgroup pairs (csrc/rowchain.hip FSPLIT / TSPLIT), fp32 the
+    general path of cfm_encoder_layer_forward (separate GEMMs + LayerNorm + stand-alone depthwise kernel), against the same oracle."""
     from oracle import conformer_oracle as O
     pkg.cfm.set_precision(mode)
     cfg = dict(input_dim=80, kernel_size=15, encoder_dim=512, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
@@ -392,6 +392,55 @@ def test_config4_real_size_encoder_and_joint(pkg, mode):
     print("  [%s] config 4 joint at full size, 16 sampled rows vs oracle: %.3e" % (mode, worst))
     assert worst < JOINT_TOL[mode] * 1.5
     del logits
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_config4_width_all_three_paths_agree(pkg, mode):
+    """d = 512 has three routes through a block (csrc/encoder.cpp): the row chains with both feed-forwards split over workgroup PAIRS and the tails
+    over the pairs' columns (at most 4 096 rows: config 4's 3 984), the plain D = 512 row chains (more rows), and separate GEMMs + LayerNorms
+    (no fragment-major packs / precision fp32).  The same 4-layer encoder on the same utterances through all three, against the CPU oracle and
+    against each other; the routes taken are read from the library's kernel table."""
+    from oracle import conformer_oracle as O
+    import encoder_layer as el
+    cfm = pkg.cfm
+    cfm.set_precision(mode)
+    cfg = dict(input_dim=80, kernel_size=15, encoder_dim=512, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+               hidden_dim=2048, num_heads=8, encoder_num_layers=4, max_len=5000, use_relative=True)
+    enc = build_encoder(pkg, cfg, 47)
+    B, T = 3, 400
+    x = dev(synth.fbank(4747, B, T))
+    lens = [400, 333, 270]
+    lt = torch.tensor(lens, dtype=torch.int32, device=DEV)
+
+    def run(tag):
+        cfm.prof_reset(); cfm.prof_enable(True)
+        with torch.no_grad():
+            y, m = enc(x, lt)
+        torch.cuda.synchronize(); cfm.prof_enable(False)
+        names = set(cfm.prof_table().keys())
+        return y, m, names
+
+    y_pair, m, k_pair = run("pairs")
+    assert any(n.startswith("chain_macaron_half") for n in k_pair) and any(n.startswith("chain_qkv_pair") for n in k_pair) and \
+        any(n.startswith("chain_convin_pair") for n in k_pair) and any(n.startswith("chain_rows") for n in k_pair), sorted(k_pair)
+    keep = el.PAIR_MAX_ROWS
+    try:
+        el.PAIR_MAX_ROWS = 0                                   # no slabs -> the plain D = 512 chains
+        y_chain, _, k_chain = run("chains")
+    finally:
+        el.PAIR_MAX_ROWS = keep
+    assert any(n.startswith("chain_macaron_") and "half" not in n for n in k_chain) and any(n.startswith("chain_final_") for n in k_chain) and \
+        not any("pair" in n or "half" in n for n in k_chain), sorted(k_chain)
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    y_ref, m_ref = O.encoder_forward(P, O.Config(**cfg), x.cpu(), lens)
+    assert np.array_equal(m.cpu().numpy(), np.asarray(m_ref))
+    check("d=512 pairs vs oracle", y_pair, y_ref, mode)
+    check("d=512 plain chains vs oracle", y_chain, y_ref, mode)
+    check("d=512 pairs vs plain chains", y_pair, y_chain, mode)
+    # a shard reproduces the batch bit for bit on the pair route too (every row's arithmetic is independent of the batch around it)
+    with torch.no_grad():
+        y_one, _ = enc(x[:1].contiguous(), lt[:1])
+    assert torch.equal(y_one, y_pair[:1])
 
 
 @pytest.mark.parametrize("D,H,FF,K,L,B,T,lens", [
