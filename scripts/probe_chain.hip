@@ -128,7 +128,8 @@ static void run_wide(const char* name, cfm_rowchain_desc d, int M) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> h(1024 * 16);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(cfm_chain_stamps), sizeof(long long) * 1024 * 16);
-    const int nb = grid < 1024 ? grid : 1024;
+    const int pgrid = (d.psum_out || d.tail_pair) ? ((grid + 3) / 4) * 8 : grid;
+    const int nb = pgrid < 1024 ? pgrid : 1024;
     static const int order[10] = {0, 1, 2, 3, 4, 15, 14, 5, 6, 7};
     static const char* what[10] = {"", "head: stage A tile", "head: GEMM + epilogue", "rows + LN_in", "FFN phase 1, half 0", "FFN phase 2, half 0", "FFN phase 1, half 1",
                                    "FFN phase 2, half 1 + y tile", "post norms", "tail GEMM + stores"};
@@ -201,6 +202,23 @@ static int main_wide(bool rnd) {
         run_wide("macaron", mac, M);
         run_wide("conv-in", cin, M);
         run_wide("final", fin, M);
+    }
+    {   // the workgroup-pair launches config 4 runs (M = 3 984: 125 tiles x 2)
+        float* ps = (float*)dalloc((size_t)3 * MMAX * D * 4, 0);
+        cfm_rowchain_desc mh = mac;                        // macaron half: LN -> half of FF -> partial slab
+        mh.ln2_g = nullptr; mh.ln2_b = nullptr; mh.tail_w = nullptr; mh.tail_b = nullptr; mh.tail_out = nullptr; mh.tail_N = 0; mh.out_f32 = nullptr; mh.psum_out = ps;
+        cfm_rowchain_desc qp = z;                          // reduce + LN_mha + q|k|v, columns split over the pair
+        qp.x = x; qp.psum_in = ps; qp.psum_b2 = vec; qp.psum_alpha = 0.5f; qp.out_f32 = out; qp.ln_g = vec; qp.ln_b = vec; qp.tail_w = wt; qp.tail_b = vec;
+        qp.tail_out = t16; qp.tail_N = 3 * D; qp.D = D; qp.FF = FF; qp.w_dtype = CFM_BF16; qp.alpha = 1.0f; qp.eps = 1e-5f; qp.tail_pair = 1;
+        cfm_rowchain_desc cp = cin;                        // conv-in, GLU tail split over the pair (rows to a third buffer)
+        cp.tail_pair = 1; cp.out_f32 = ps + (size_t)2 * MMAX * D;
+        cfm_rowchain_desc rw = z;                          // reduce + LN_final
+        rw.x = x; rw.psum_in = ps; rw.psum_b2 = vec; rw.psum_alpha = 0.5f; rw.ln_g = vec; rw.ln_b = vec; rw.out2_f32 = out; rw.D = D; rw.FF = FF; rw.w_dtype = CFM_BF16;
+        rw.alpha = 1.0f; rw.eps = 1e-5f;
+        run_wide("macaron-half", mh, 3984);
+        run_wide("q|k|v pair", qp, 3984);
+        run_wide("conv-in pair", cp, 3984);
+        run_wide("rows", rw, 3984);
     }
     {   // cold weights: 17 rotating weight sets (as the 17 blocks of config 4 do), M = 3 984
         const int L = 17;
