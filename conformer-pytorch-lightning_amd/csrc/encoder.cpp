@@ -218,10 +218,11 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         if (!merged) CFM_TRY(cfm_rowchain(&ci, stream));
         // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own
         const bool dw_fused = io->ktaps == 15 && !io->causal_conv && cfm_rowchain_dw_supported(D);
+        const bool pair_dw = pair && io->ktaps == 15 && !io->causal_conv && getenv("CFM_PAIR_HEAD_GEMM") == nullptr;   // depthwise stage + pointwise-conv-2, columns over the pairs
         if (io->causal_conv) {
             CFM_TRY(cfm_dwconv_causal_bn_silu(s->glu, adt, io->conv_cache, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
             if (io->conv_cache) CFM_TRY(cfm_conv_cache_update(s->glu, adt, io->conv_cache, io->B, io->T, D, io->ktaps, stream));
-        } else if (!dw_fused)
+        } else if (!dw_fused && !pair_dw)
             CFM_TRY(cfm_dwconv_bn_silu(s->glu, adt, w->dw_w, w->dw_b, w->bn_scale, w->bn_shift, s->dw, adt, io->B, io->T, D, io->ktaps, stream));
         if (ffsplit) {
             // depthwise + BN + SiLU, pointwise-conv-2 + pad mask + residual (in place on x_out), then the feed-forward as partial slabs and the
@@ -250,7 +251,16 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
             // half of the feed-forward; then rows + 1/2 (halves + b2) -> LN_final, in place on x_out (one workgroup per row tile)
             float* const park = s->psum + (int64_t)2 * M * D;  // the conv-in chain's rows
             cfm_rowchain_desc fa = {};
-            if (w->pw2_w && getenv("CFM_PAIR_HEAD_IN_CHAIN") == nullptr) {
+            if (pair_dw) {
+                // depthwise conv + BatchNorm + SiLU as the input stage of pointwise-conv-2, each workgroup of a pair HALF of its output columns (no LayerNorm
+                // behind the head in this launch, so half rows are complete results): + pad mask + residual -> x_out
+                cfm_rowchain_desc dh = {};
+                dh.head_a = s->glu; dh.head_w = w->pw2_wf; dh.head_b = w->pw2_b; dh.head_res = park; dh.head_mask = io->pad_valid;
+                dh.dw_w = w->dw_w; dh.dw_b = w->dw_b; dh.dw_scale = w->bn_scale; dh.dw_shift = w->bn_shift; dh.dw_T = io->T; dh.dw_K = 15;
+                dh.out_f32 = x_out; dh.tail_pair = 1; dh.M = M; dh.D = D; dh.FF = FF; dh.w_dtype = c.w_dt; dh.alpha = 1.0f; dh.eps = eps;
+                CFM_TRY(cfm_rowchain(&dh, stream));
+                fa.x = x_out;
+            } else if (w->pw2_w && getenv("CFM_PAIR_HEAD_IN_CHAIN") == nullptr) {
                 // the 0.5 MB head would be streamed by BOTH workgroups of every pair (+18 us per launch): it runs as a plain product over all CUs instead
                 CFM_TRY(gemm(c, s->dw, adt, D, w->pw2_w, w->pw2_w_lo, w->pw2_b, x_out, CFM_F32, D, M, D, D, CFM_ACT_NONE, park, 1.0f, io->pad_valid));
                 fa.x = x_out;

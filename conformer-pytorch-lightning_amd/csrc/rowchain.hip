@@ -216,10 +216,11 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     static_assert(!SEG2 || MID, "a second segment is a second feed-forward");
     static_assert(!HATT || (HEAD && !HDW && !MID && D == 256), "the attention input stage: conv-in chain, 4 heads x 64");
     constexpr bool WIDE = D > 256;                         // D = 512 (config 4): feed-forward in two halves of FF, K-chunked head / tail weight rings
-    static_assert(!WIDE || (!HDW && !HATT && !TVT && !SEG2 && D == 512), "the wide instances: plain macaron / conv-in / final chains at D = 512");
+    static_assert(!WIDE || (!HATT && !TVT && !SEG2 && D == 512 && (!HDW || (!MID && TSTEPS == 0))), "the wide instances: plain macaron / conv-in / final chains at D = 512 (+ the depthwise head)");
     static_assert(!FSPLIT || (WIDE && MID && TSTEPS == 0), "the pair split: a wide feed-forward chain without a tail");
-    static_assert(!TSPLIT || (WIDE && !MID && TSTEPS > 0), "the tail split: a wide chain without a feed-forward, half of the tail's columns per workgroup");
+    static_assert(!TSPLIT || (WIDE && !MID && (TSTEPS > 0 || HSTEPS > 0)), "the tail split: a wide chain without a feed-forward, half of the last product's columns per workgroup");
     constexpr bool PAIRED = FSPLIT || TSPLIT;
+    constexpr bool HSPLIT = TSPLIT && TSTEPS == 0;         // no tail: the HEAD's columns are split, its rows go straight to out_f32 (no LayerNorm behind it)
     static_assert(!TVT || (TAIL && !TGLU && D == 256), "transposed values: a fused-QKV tail with 64-wide heads");
     constexpr int DWK = 15, DWH = (DWK - 1) / 2, DWROWS = RBM + DWK - 1;     // depthwise taps, halo, rows of the halo tile
     constexpr int KS1 = (D + 31) / 32;                     // 32-wide K slices of a D-long row
@@ -345,12 +346,12 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     // ================= HEAD: x = res + mask(A . Wh^T + bh) =====================================================
     if constexpr (HEAD) {
         const u32x4* wp = (const u32x4*)a.head_w + lane;
-        auto frag0 = [&](int s) { return s * NW + wave; };
+        auto frag0 = [&](int s) { return s * NW + wave + (HSPLIT ? tsel * (NF2 / 2) : 0); };
         auto clampf = [&](int f) { return f < NF2 ? f : NF2 - 1; };   // out-of-range fragments re-read the last one (unused)
         constexpr int HRG = WIDE ? 10 : KS1;
         u32x4 wr[HRG];
         auto head_ptr = [&](int pos) { return wp + ((int64_t)clampf(frag0(pos / KS1)) * KS1 + pos % KS1) * 64; };   // WIDE: position -> (step, kk)
-        if constexpr (WIDE) {
+        if constexpr (WIDE && !HDW) {
 #pragma unroll
             for (int t = 0; t < HRG; ++t) wr[t] = *head_ptr(t);                                           // weights first
         } else if constexpr (!HDW && !HATT) {
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             // fp32 FMAs in the tap order of cfm_dwconv_bn_silu (bit-identical results), 16-bit results into the xn tile.
             u16* const halo = (u16*)lds_a;
             constexpr int C8 = D / 8, CP = D / 2, RG = RBM / 4;
-            static_assert(CP * RG <= NT, "one (channel pair, frame group) per thread");
+            constexpr int NPASS = (CP * RG + NT - 1) / NT;      // (channel pair, frame group) items per thread: 1 up to D = 256, 2 at D = 512
+            static_assert(NPASS == 1 || (NT % CP == 0 && (CP * RG) % NT == 0), "whole passes, the same channel pair in every pass of a thread");
             constexpr int NHALO = (DWROWS * C8 + NT - 1) / NT;
             u32x4 hv[NHALO];
 #pragma unroll
@@ -377,18 +379,22 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 const u32x4 v = *(const u32x4*)(a.head_a + gc * D + (idc % C8) * 8);
                 hv[i] = (id < DWROWS * C8 && grow >= 0 && grow < Mlim) ? v : (u32x4){0u, 0u, 0u, 0u};
             }
-            const bool worker = tid < CP * RG;
-            const int cp = worker ? tid % CP : 0, rg = worker ? tid / CP : 0;   // channel pair, frame group (wave-uniform: CP % 64 == 0 or idle tail)
+            const int cp = tid < CP * RG ? tid % CP : 0;                         // channel pair (wave-uniform: CP % 64 == 0 or idle tail; the same in every pass)
             float* const taps = (float*)(lds_a + DWROWS * D * 2);                // [D][15] as in memory, staged with 16-byte loads
-            static_assert((DWK * D) % 4 == 0 && DWK * D / 4 <= NT, "one 16-byte piece of the taps per thread");
-            const f32x4 tv = *(const f32x4*)(a.dw_w + 4 * (tid < DWK * D / 4 ? tid : 0));
+            constexpr int NTAP4 = (DWK * D / 4 + NT - 1) / NT;                   // 16-byte pieces of the taps per thread
+            static_assert((DWK * D) % 4 == 0, "16-byte pieces of the taps");
+            f32x4 tv[NTAP4];
+#pragma unroll
+            for (int i = 0; i < NTAP4; ++i) tv[i] = *(const f32x4*)(a.dw_w + 4 * (tid + i * NT < DWK * D / 4 ? tid + i * NT : 0));
             const f32x2 pb = *(const f32x2*)(a.dw_b + 2 * cp), ps = *(const f32x2*)(a.dw_scale + 2 * cp), ph = *(const f32x2*)(a.dw_shift + 2 * cp);
 #pragma unroll
             for (int i = 0; i < NHALO; ++i) {
                 const int id = tid + i * NT;
                 if (id < DWROWS * C8) *(u32x4*)(halo + (id / C8) * D + (id % C8) * 8) = hv[i];
             }
-            if (tid < DWK * D / 4) *(f32x4*)(taps + 4 * tid) = tv;
+#pragma unroll
+            for (int i = 0; i < NTAP4; ++i)
+                if (tid + i * NT < DWK * D / 4) *(f32x4*)(taps + 4 * (tid + i * NT)) = tv[i];
             // pad columns of the xn tile (K padded to a multiple of 32)
             if constexpr (KP > D) {
                 for (int id = tid; id < RBM * (KP - D) / 2; id += NT) {
@@ -397,6 +403,10 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 }
             }
             __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+            const bool worker = tid + pass * NT < CP * RG;
+            const int rg = worker ? (tid + pass * NT) / CP : 0;                  // frame group (wave-uniform)
             if (worker) {
                 f32x2 tw[DWK];                                 // taps of channels 2cp, 2cp+1: 30 consecutive floats
                 {
@@ -440,6 +450,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                     *(unsigned*)(xn + (rg * 4 + i) * XN_STRIDE + 2 * cp) = o;
                 }
             }
+            }   // passes
         } else if constexpr (HATT) {
             // ================= attention input stage ==================================================================
             // The head input IS the attention context of this tile's 32 frames (attention.py:81-96; the stand-alone kernel is
@@ -639,8 +650,13 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             }
         }
         if constexpr (HDW) {                               // (after the depthwise stage: its register window leaves no room before)
+            if constexpr (WIDE) {
 #pragma unroll
-            for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
+                for (int t = 0; t < HRG; ++t) wr[t] = *head_ptr(t);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk) wr[kk] = wp[((int64_t)clampf(frag0(0)) * KS1 + kk) * 64];
+            }
         }
         __syncthreads();
         CFM_STAMP(1);
@@ -674,10 +690,15 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                     f32x4 v = acc[mf][0] + bb;
                     if (!keep[mf]) v = zero4;
                     v += rs[mf];
-                    *(f32x4*)(xs + (mf * 16 + l15) * XS_STRIDE + col) = v;
+                    if constexpr (HSPLIT) {                 // this workgroup's half of the columns is all there is: no row phase behind it
+                        if (row0 + mf * 16 + l15 < Mlim) *(f32x4*)(a.out_f32 + grows[mf] * D + col) = v;
+                    } else {
+                        *(f32x4*)(xs + (mf * 16 + l15) * XS_STRIDE + col) = v;
+                    }
                 }
             }
         }
+        if constexpr (HSPLIT) return;
         __syncthreads();
     }
     if constexpr (TAIL && !MID) tail_prefetch();           // lands during the LayerNorm phase
@@ -1149,7 +1170,7 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     CFM_CHECK_ARG(!dw || (head && (mid ? (!tail || seg2) : !tail) && d->dw_b && d->dw_scale && d->dw_shift && d->dw_K == 15 && d->dw_T > 0 && d->M % d->dw_T == 0),
                   "cfm_rowchain: the depthwise input stage needs a head (+ feed-forward) chain without a tail, bias/scale/shift, 15 taps and M %% dw_T == 0");
     CFM_CHECK_ARG(d->M > 0 && (d->D == 144 || d->D == 256 || d->D == 512), "cfm_rowchain: D=%d has no instance (144, 256, 512)", d->D);
-    CFM_CHECK_ARG(d->D != 512 || (!dw && !att && !tvt && !seg2), "cfm_rowchain: D = 512 runs the plain macaron / conv-in / final chains only");
+    CFM_CHECK_ARG(d->D != 512 || (!att && !tvt && !seg2 && (!dw || (d->tail_pair && !mid && !tail))), "cfm_rowchain: D = 512 runs the plain macaron / conv-in / final chains (and the paired depthwise head) only");
     CFM_CHECK_ARG(d->w_dtype == CFM_BF16 || d->w_dtype == CFM_F16, "cfm_rowchain: w_dtype must be bf16 or fp16");
     CFM_CHECK_ARG(head || d->x, "cfm_rowchain: need x or a head input");
     CFM_CHECK_ARG(!head || (d->head_w && d->head_b && d->head_res), "cfm_rowchain: head needs weights, bias and residual");
@@ -1162,8 +1183,9 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
                               (!head || (d->out_f32 && d->out_f32 != d->head_res))),
                   "cfm_rowchain: psum_out needs a feed-forward chain at D = 512 without tail / post norms, and (with a head) out_f32 distinct from head_res");
     CFM_CHECK_ARG(!ps_in || (!head && !mid && d->D == 512 && d->psum_b2 && d->x), "cfm_rowchain: psum_in needs a rows chain (no head, no feed-forward) at D = 512, x and psum_b2");
-    CFM_CHECK_ARG(!d->tail_pair || (tail && !mid && d->D == 512 && (d->tail_N / 16) % 2 == 0 && (!head || d->out_f32 != d->head_res)),
-                  "cfm_rowchain: tail_pair needs a chain with a tail and no feed-forward at D = 512, and (with a head) out_f32 distinct from head_res");
+    CFM_CHECK_ARG(!d->tail_pair || (!mid && d->D == 512 && (tail ? (d->tail_N / 16) % 2 == 0 : (head && dw && d->out_f32 && !d->ln_g)) && (!head || d->out_f32 != d->head_res)),
+                  "cfm_rowchain: tail_pair needs a chain without a feed-forward at D = 512 -- with a tail, or the depthwise head alone (no LayerNorm, rows to out_f32) -- "
+                  "and (with a head) out_f32 distinct from head_res");
     ChainArgs a;
     a.psum_out = d->psum_out; a.psum_in = d->psum_in; a.psum_b2 = d->psum_b2; a.psum_alpha = d->psum_alpha;
     a.x = d->x; a.head_a = (const u16*)d->head_a; a.head_w = (const u16*)d->head_w; a.head_b = d->head_b; a.head_res = d->head_res;
@@ -1213,7 +1235,8 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
     } else if (d->D == 512 && (!mid || d->FF == 2048)) {
         if (d->tail_pair && !head && !d->tail_glu && tsteps == 6) { if (bf) return launch_chain<BF16, 512, 64, 0, false, false, 3, false, false, false, false, false, true>(a, s, "chain_qkv_pair_bf16_d512", fl); else return launch_chain<F16, 512, 64, 0, false, false, 3, false, false, false, false, false, true>(a, s, "chain_qkv_pair_f16_d512", fl); }
         if (d->tail_pair && head && d->tail_glu && tsteps == 2) { if (bf) return launch_chain<BF16, 512, 64, 2, false, false, 1, true, false, false, false, false, true>(a, s, "chain_convin_pair_bf16_d512", fl); else return launch_chain<F16, 512, 64, 2, false, false, 1, true, false, false, false, false, true>(a, s, "chain_convin_pair_f16_d512", fl); }
-        if (d->tail_pair) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: tail_pair on the q|k|v rows chain and the conv-in chain only");
+        if (d->tail_pair && head && dw && !tail) { if (bf) return launch_chain<BF16, 512, 64, 1, true, false, 0, false, false, false, false, false, true>(a, s, "chain_dwhead_pair_bf16_d512", fl); else return launch_chain<F16, 512, 64, 1, true, false, 0, false, false, false, false, false, true>(a, s, "chain_dwhead_pair_f16_d512", fl); }
+        if (d->tail_pair) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: tail_pair on the q|k|v rows chain, the conv-in chain and the depthwise head only");
         if (!head && mid && tail && !d->tail_glu && tsteps == 6) { if (bf) CFM_RC(BF16, 512, 2048, 0, true, 6, false, "chain_macaron_bf16_d512"); else CFM_RC(F16, 512, 2048, 0, true, 6, false, "chain_macaron_f16_d512"); }
         if (head && !mid && tail && d->tail_glu && tsteps == 2) { if (bf) CFM_RC(BF16, 512, 64, 2, false, 2, true, "chain_convin_bf16_d512"); else CFM_RC(F16, 512, 64, 2, false, 2, true, "chain_convin_f16_d512"); }
         if (ps_out && head) { if (bf) return launch_chain<BF16, 512, 2048, 2, false, true, 0, false, false, false, false, true>(a, s, "chain_final_half_bf16_d512", fl); else return launch_chain<F16, 512, 2048, 2, false, true, 0, false, false, false, false, true>(a, s, "chain_final_half_f16_d512", fl); }
