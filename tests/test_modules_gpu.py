@@ -631,6 +631,30 @@ def test_streaming_dk64_long_cache_against_oracle(pkg, mode):
     check("streaming d_k=64, stream 3 of 3 in lockstep", y3[2:3], y_ref2, mode)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_streaming_config4_width_against_oracle(pkg, mode):
+    """forward_chunk at config 4's width (d = 512, h = 8): a chunk's few rows take the workgroup-pair route of the D = 512 row chains (one tile x 2)
+    with a growing K/V cache around it, chunk by chunk against the oracle's restatement of encoder.py:125-153; two streams in lockstep reproduce the single one."""
+    from oracle import conformer_oracle as O
+    pkg.cfm.set_precision(mode)
+    cfg = dict(input_dim=80, kernel_size=15, encoder_dim=512, dropout=0.1, attention_dropout=0.1, pos_enc_dropout=0.1,
+               hidden_dim=2048, num_heads=8, encoder_num_layers=2, max_len=5000, use_relative=True)
+    enc = build_encoder(pkg, cfg, 57)
+    frames, chunk = 420, 16
+    x = dev(synth.fbank(58, 2, frames))
+    pkg.cfm.prof_reset(); pkg.cfm.prof_enable(True)
+    with torch.no_grad():
+        y1, _ = enc.forward_chunk_by_chunk(x[:1], chunk, 4)
+        y2, _ = enc.forward_chunk_by_chunk(x, chunk, 4)
+    torch.cuda.synchronize(); pkg.cfm.prof_enable(False)
+    names = set(pkg.cfm.prof_table().keys())
+    assert any(n.startswith("chain_macaron_half") for n in names) and any(n.startswith("chain_qkv_pair") for n in names), sorted(names)
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    y_ref = O.encoder_forward_chunk_by_chunk(P, O.Config(**cfg), x[:1].cpu(), chunk, 4)
+    check("streaming d=512, 4 cached chunks (%d frames out)" % y1.size(1), y1, y_ref, mode)
+    assert torch.equal(y2[:1], y1)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
 def test_streaming_session_graph_equals_eager(pkg, mode):
     """encoder.StreamingSession (one captured HIP graph per steady-state step) against the eager forward_chunk loop it wraps: same
