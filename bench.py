@@ -240,7 +240,7 @@ def selftest_cpu(args):
         dist.destroy_process_group()
 
 
-KERNEL_SYMBOL = {"chain_dwfinal_macaron": "cfm_rowchain_kernel", "chain_macaron": "cfm_rowchain_kernel", "chain_dwfinal": "cfm_rowchain_kernel", "chain_final": "cfm_rowchain_kernel", "chain_convin": "cfm_rowchain_kernel",
+KERNEL_SYMBOL = {"chain_convin_dwfinal_macaron": "cfm_rowchain_kernel", "chain_dwfinal_macaron": "cfm_rowchain_kernel", "chain_macaron": "cfm_rowchain_kernel", "chain_dwfinal": "cfm_rowchain_kernel", "chain_final": "cfm_rowchain_kernel", "chain_convin": "cfm_rowchain_kernel",
                  "chain_qkv": "cfm_rowchain_kernel", "ffn_fused": "cfm_ffn_kernel", "ffn_partial": "cfm_ffnpart_kernel",
                  "gemm_conv": "cfm_gemm_kernel", "gemm": "cfm_gemm_kernel", "attn2": "cfm_attn2_kernel", "attn": "cfm_attn_kernel"}
 
@@ -264,7 +264,8 @@ def short_kernel_name(name):
 def pick_traffic(kernels, kernel_name, d_model):
     """kernels: {short symbol with template arguments: bytes per launch}; the entry of the bench's dominant kernel, or None."""
     # template arguments after <type, D, FF,: head steps, depthwise input stage, feed-forward, tail steps, GLU
-    role = {"chain_dwfinal_macaron": "1, true, true, 3, false, false, false, true", "chain_macaron": "0, false, true, 3, false",
+    role = {"chain_convin_dwfinal_macaron": "1, true, true, 3, false, false, false, true, false, false, true",
+            "chain_dwfinal_macaron": "1, true, true, 3, false, false, false, true, false, false, false", "chain_macaron": "0, false, true, 3, false",
             "chain_dwfinal": "1, true, true, 0, false", "chain_final": "1, false, true, 0, false", "chain_convin": "1, false, false, 1, true"}
     for prefix, sym in KERNEL_SYMBOL.items():
         if kernel_name.startswith(prefix):
@@ -568,13 +569,15 @@ def main():
             if tables is not None:
                 roofline["traffic"] = pick_traffic(tables, name, CFG2["encoder_dim"])
             roofline["traffic_source"] = note
-            if name.startswith("chain_macaron") or name.startswith("chain_dwfinal") or name.startswith("chain_final"):
+            if name.startswith("chain_macaron") or name.startswith("chain_dwfinal") or name.startswith("chain_final") or name.startswith("chain_convin_dwfinal"):
                 # what actually bounds the row chains: every CU streams the block's weights through its own
                 # vector-memory path, 64 B/clk/CU at the 2.4 GHz the MFMA peak is quoted at
                 D, FF = CFG2["encoder_dim"], CFG2["hidden_dim"]
                 wbytes = 2 * (2 * D * FF + (3 * D * D if name.startswith("chain_macaron") else D * D))
                 if name.startswith("chain_dwfinal_macaron"):     # two feed-forwards + pointwise-conv-2 + the fused QKV projection
                     wbytes = 2 * (4 * D * FF + D * D + 3 * D * D)
+                if name.startswith("chain_convin_dwfinal_macaron"):   # ... + the out-projection and pointwise-conv-1 of the conv-in stage
+                    wbytes = 2 * (4 * D * FF + D * D + 3 * D * D + D * D + 2 * D * D)
                 floor_us = wbytes / 64.0 / 2.4e9 * 1e6
                 roofline["weight_stream"] = {"bytes_per_cu_per_launch": wbytes, "path_peak": "64 B/clk/CU", "floor_us": round(floor_us, 2),
                                              "frac": round(floor_us / (avg_ms * 1e3), 4)}

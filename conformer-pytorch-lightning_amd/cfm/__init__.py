@@ -85,7 +85,9 @@ class RowChainDesc(ctypes.Structure):
                 ("att_qkv", c_p), ("att_vt", c_p), ("att_p", c_p), ("att_bias_u", c_p), ("att_bias_v", c_p), ("att_mask", c_p),
                 ("att_p_sb", c_i64), ("att_m_sb", c_i64), ("att_T", c_i32), ("att_H", c_i32), ("att_vt_ld", c_i32), ("att_scale", ctypes.c_float),
                 ("s2_ln_g", c_p), ("s2_ln_b", c_p), ("s2_w1f", c_p), ("s2_w2n", c_p), ("s2_b1", c_p), ("s2_b2", c_p), ("s2_out_f32", c_p),
-                ("s2_alpha", ctypes.c_float), ("psum_out", c_p), ("psum_in", c_p), ("psum_b2", c_p), ("psum_alpha", ctypes.c_float), ("tail_pair", c_i32)]
+                ("s2_alpha", ctypes.c_float), ("psum_out", c_p), ("psum_in", c_p), ("psum_b2", c_p), ("psum_alpha", ctypes.c_float),
+                ("cin_a", c_p), ("cin_w", c_p), ("cin_b", c_p), ("cin_res", c_p), ("cin_out", c_p), ("cin_ln_g", c_p), ("cin_ln_b", c_p), ("cin_mask", c_p),
+                ("cin_tail_w", c_p), ("cin_tail_b", c_p), ("tail_pair", c_i32)]
 
 
 _LAYER_W_FIELDS = [

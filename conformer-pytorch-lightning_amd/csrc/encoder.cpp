@@ -215,7 +215,12 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         ci.ln_mask = io->pad_valid; ci.out_f32 = x_out; ci.tail_w = w->pw1_wf; ci.tail_b = w->pw1_b; ci.tail_out = s->glu;
         ci.M = M; ci.D = D; ci.FF = FF; ci.tail_N = 2 * D; ci.tail_glu = 1; ci.w_dtype = c.w_dt; ci.alpha = 1.0f; ci.eps = eps;
         if (pair) { ci.tail_pair = 1; ci.out_f32 = s->psum + (int64_t)2 * M * D; }   // the pair's other workgroup still reads x_out: the rows go to the third slab
-        if (!merged) CFM_TRY(cfm_rowchain(&ci, stream));
+        // chained blocks at D = 256: the conv-in chain runs as the input stage of the next launch (depthwise + final chain + the next block's macaron chain) on
+        // the tile's 32 + 14 halo rows -- no launch of its own (cfm.h cfm_rowchain_desc.cin_*)
+        static const bool cin_ok = getenv("CFM_CIN_MERGE") == nullptr || atoi(getenv("CFM_CIN_MERGE")) != 0;
+        const bool cin = cin_ok && !merged && !pair && !ffsplit && io->next_w && io->next_x_out && D == 256 && FF == 2048 && io->ktaps == 15 && !io->causal_conv &&
+                         !io->after_out;
+        if (!merged && !cin) CFM_TRY(cfm_rowchain(&ci, stream));
         // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own
         const bool dw_fused = io->ktaps == 15 && !io->causal_conv && cfm_rowchain_dw_supported(D);
         const bool pair_dw = pair && io->ktaps == 15 && !io->causal_conv && getenv("CFM_PAIR_HEAD_GEMM") == nullptr;   // depthwise stage + pointwise-conv-2, columns over the pairs
@@ -294,6 +299,12 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
             fi.s2_ln_g = nw->ln_ffm_g; fi.s2_ln_b = nw->ln_ffm_b; fi.s2_w1f = nw->ffm_w1f; fi.s2_w2n = nw->ffm_w2n; fi.s2_b1 = nw->ffm_b1; fi.s2_b2 = nw->ffm_b2;
             fi.s2_out_f32 = io->next_x_out; fi.s2_alpha = 0.5f;
             fi.ln2_g = nw->ln_mha_g; fi.ln2_b = nw->ln_mha_b; fi.tail_w = nw->qkv_wf; fi.tail_b = nw->qkv_b; fi.tail_out = s->qkv; fi.tail_N = 3 * D; fi.tail_glu = 0;
+            if (cin) {
+                // the residual rows of the conv-in stage go to next_x_out (this tile's own rows: read back as the head's residual, overwritten at the end with
+                // the next block's residual -- all by the same workgroup); halo rows are read from x_out, which this launch does not write
+                fi.cin_a = s->ctx; fi.cin_w = w->out_wf; fi.cin_b = w->out_b; fi.cin_res = x_out; fi.cin_out = io->next_x_out; fi.cin_ln_g = w->ln_conv_g;
+                fi.cin_ln_b = w->ln_conv_b; fi.cin_mask = io->pad_valid; fi.cin_tail_w = w->pw1_wf; fi.cin_tail_b = w->pw1_b; fi.head_res = io->next_x_out;
+            }
         }
         return cfm_rowchain(&fi, stream);
     }

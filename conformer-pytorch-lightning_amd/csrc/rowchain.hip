@@ -93,6 +93,18 @@ struct ChainArgs {
     float* psum_out;
     const float *psum_in, *psum_b2;
     float psum_alpha;
+    // CIN: the conv-in chain of the SAME block as the input stage of the depthwise stage (out-proj + residual -> LN_conv -> pointwise-conv-1 + GLU), computed
+    // for the tile's 32 + 14 halo rows; its GLU rows go to the halo tile in LDS (head_a is not read), its residual rows to cin_out (which the head then reads
+    // as head_res: the launcher sets head_res = cin_out)
+    const u16* cin_a;         // attention context [M, D], 16 bit
+    const u16* cin_w;         // out-proj, fragment-major [D/16][KS][64][8]
+    const float* cin_b;
+    const float* cin_res;     // f32 [M, D]: the residual stream in front of the out-projection (halo rows are read from OTHER tiles: never written in this launch)
+    float* cin_out;           // f32 [M, D]: residual + out-proj, this tile's own rows
+    const float *cin_ln_g, *cin_ln_b;
+    const uint8_t* cin_mask;  // pad validity per row (zeroes the normalised row), or null
+    const u16* cin_tw;        // pointwise-conv-1, GLU-interleaved, fragment-major [2D/16][KS][64][8]
+    const float* cin_tb;
 };
 
 // Phase stamps for scripts/probe_chain.hip (built with -DCFM_CHAIN_STAMPS; never defined in the product build): thread 0 of each
@@ -116,13 +128,13 @@ constexpr int MF = RBM / 16;                               // 16-row MFMA fragme
 // One "linear step": NFR 16-column output fragments of this wavefront over the whole K (KS 32-wide slices) of an LDS tile.
 // With `refill` the weights of the NEXT step (fragments nx[], clamped by the caller) replace the current ones in the ring as
 // they are consumed; the last step of a phase passes false (a compile-time constant after unrolling) and issues no loads.
-template <typename HT, int KS, int NFR, int STRIDE>
+template <typename HT, int KS, int NFR, int STRIDE, int MFX = MF>
 __device__ __forceinline__ void linear_step(const u16* tile, const u32x4* wp, bool refill, const int (&nx)[NFR], u32x4 (&wr)[NFR * KS],
-                                            f32x4 (&acc)[MF][NFR], int g, int l15) {
+                                            f32x4 (&acc)[MFX][NFR], int g, int l15) {
     auto frag = [&](int mf, int kk) { return *(const u32x4*)(tile + (mf * 16 + l15) * STRIDE + kk * 32 + 8 * g); };
-    u32x4 xf[2][MF];                                       // activation fragments: this kk and the next (one-ahead LDS reads)
+    u32x4 xf[2][MFX];                                       // activation fragments: this kk and the next (one-ahead LDS reads)
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
+    for (int mf = 0; mf < MFX; ++mf) {
         xf[0][mf] = frag(mf, 0);
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -131,12 +143,12 @@ __device__ __forceinline__ void linear_step(const u16* tile, const u32x4* wp, bo
     for (int kk = 0; kk < KS; ++kk) {
         if (kk + 1 < KS) {
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) xf[(kk + 1) & 1][mf] = frag(mf, kk + 1);
+            for (int mf = 0; mf < MFX; ++mf) xf[(kk + 1) & 1][mf] = frag(mf, kk + 1);
         }
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) acc[mf][nf] = HT::mfma(wr[nf * KS + kk], xf[kk & 1][mf], acc[mf][nf]);
+            for (int mf = 0; mf < MFX; ++mf) acc[mf][nf] = HT::mfma(wr[nf * KS + kk], xf[kk & 1][mf], acc[mf][nf]);
         if (refill) {
 #pragma unroll
             for (int nf = 0; nf < NFR; ++nf) wr[nf * KS + kk] = wp[((int64_t)nx[nf] * KS + kk) * 64];
@@ -148,12 +160,12 @@ __device__ __forceinline__ void linear_step(const u16* tile, const u32x4* wp, bo
 // The same step when the whole K of a step does not fit in registers (D = 512: KS = 16): the steps' fragments are one stream of positions
 // pos = (s * KS + kk) * NFR + nf through a ring of RG registers (slot = pos % RG, every slot a compile-time constant after unrolling: `s` is
 // a constant at every call site); the slot just consumed is refilled with the fragment RG positions ahead (ptr_of(pos), clamped by the caller).
-template <typename HT, int KS, int NFR, int RG, int STRIDE, typename PtrOf>
-__device__ __forceinline__ void ring_step(const u16* tile, const int s, const int npos, PtrOf ptr_of, u32x4 (&rg)[RG], f32x4 (&acc)[MF][NFR], int g, int l15) {
+template <typename HT, int KS, int NFR, int RG, int STRIDE, typename PtrOf, int MFX = MF>
+__device__ __forceinline__ void ring_step(const u16* tile, const int s, const int npos, PtrOf ptr_of, u32x4 (&rg)[RG], f32x4 (&acc)[MFX][NFR], int g, int l15) {
     auto frag = [&](int mf, int kk) { return *(const u32x4*)(tile + (mf * 16 + l15) * STRIDE + kk * 32 + 8 * g); };
-    u32x4 xf[2][MF];
+    u32x4 xf[2][MFX];
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
+    for (int mf = 0; mf < MFX; ++mf) {
         xf[0][mf] = frag(mf, 0);
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -162,13 +174,13 @@ __device__ __forceinline__ void ring_step(const u16* tile, const int s, const in
     for (int kk = 0; kk < KS; ++kk) {
         if (kk + 1 < KS) {
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) xf[(kk + 1) & 1][mf] = frag(mf, kk + 1);
+            for (int mf = 0; mf < MFX; ++mf) xf[(kk + 1) & 1][mf] = frag(mf, kk + 1);
         }
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) {
             const int pos = (s * KS + kk) * NFR + nf;
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) acc[mf][nf] = HT::mfma(rg[pos % RG], xf[kk & 1][mf], acc[mf][nf]);
+            for (int mf = 0; mf < MFX; ++mf) acc[mf][nf] = HT::mfma(rg[pos % RG], xf[kk & 1][mf], acc[mf][nf]);
         }
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) {
@@ -182,6 +194,9 @@ __device__ __forceinline__ void ring_step(const u16* tile, const int s, const in
 // LayerNorm of ROWS rows held one row per wavefront pass (lane owns columns (lane + 64 it) * 4 ..+3), in place.
 template <int ROWS, int VPL, int D>
 __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x4 (&gam)[VPL], const f32x4 (&bet)[VPL], float eps, int lane) {
+    // No FMA contraction here: under the default (-ffp-contract=fast) the optimiser decides per instance which multiplies and adds to fuse, and instances that
+    // must agree bit for bit (a chain with and without the depthwise / conv-in input stage, chained and unchained blocks) then round differently.
+#pragma clang fp contract(off)
     float mean[ROWS], rstd[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
@@ -209,7 +224,7 @@ __device__ __forceinline__ void rows_layernorm(f32x4 (&v)[ROWS][VPL], const f32x
             if ((lane + 64 * it) * 4 < D) v[rr][it] = (v[rr][it] - mean[rr]) * rstd[rr] * gam[it] + bet[it];
 }
 
-template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false, bool FSPLIT = false, bool TSPLIT = false>
+template <typename HT, int D, int FF, int HSTEPS, bool HDW, bool MID, int TSTEPS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false, bool FSPLIT = false, bool TSPLIT = false, bool CIN = false>
 __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     constexpr bool HEAD = HSTEPS > 0, TAIL = TSTEPS > 0;
     constexpr int NSEG = SEG2 ? 2 : 1;
@@ -220,6 +235,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     static_assert(!FSPLIT || (WIDE && MID && TSTEPS == 0), "the pair split: a wide feed-forward chain without a tail");
     static_assert(!TSPLIT || (WIDE && !MID && (TSTEPS > 0 || HSTEPS > 0)), "the tail split: a wide chain without a feed-forward, half of the last product's columns per workgroup");
     constexpr bool PAIRED = FSPLIT || TSPLIT;
+    static_assert(!CIN || (HDW && D == 256 && !WIDE), "the conv-in input stage: in front of the depthwise stage, D = 256 (one out-proj fragment and one GLU pair per wavefront)");
     constexpr bool HSPLIT = TSPLIT && TSTEPS == 0;         // no tail: the HEAD's columns are split, its rows go straight to out_f32 (no LayerNorm behind it)
     static_assert(!TVT || (TAIL && !TGLU && D == 256), "transposed values: a fused-QKV tail with 64-wide heads");
     constexpr int DWK = 15, DWH = (DWK - 1) / 2, DWROWS = RBM + DWK - 1;     // depthwise taps, halo, rows of the halo tile
@@ -238,15 +254,18 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 
     // region A: the f32 x tile between HEAD and LN_in, then the 16-bit hidden tile, then the f32 y tile of the FFN
     constexpr int A_MAIN = MID && RBM * HS * 2 > RBM * XS_STRIDE * 4 ? RBM * HS * 2 : RBM * XS_STRIDE * 4;
-    constexpr int A_DW = HDW ? DWROWS * D * 2 + DWK * D * 4 : 0;          // 16-bit halo tile + the f32 taps of the depthwise input stage
+    constexpr int CIN_ROWS = 48;                                            // CIN: the 32 + 14 halo rows as three 16-row MFMA fragments
+    constexpr int TAPS_OFF = CIN ? ((CIN_ROWS * XS_STRIDE * 4 + 1023) / 1024) * 1024 : DWROWS * D * 2;   // CIN: behind the 48-row f32 tile of the out-projection
+    constexpr int A_DW = HDW ? TAPS_OFF + DWK * D * 4 : 0;                // 16-bit halo tile + the f32 taps of the depthwise input stage
     constexpr int A_ATT = HATT ? 4 * RBM * XS_STRIDE * 4 : 0;             // four partial context tiles (one per key quarter), f32
     constexpr int A_BYTES = A_MAIN > A_DW ? (A_MAIN > A_ATT ? A_MAIN : A_ATT) : (A_DW > A_ATT ? A_DW : A_ATT);
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[A_BYTES];
-    __shared__ __attribute__((aligned(16))) u16 xn[RBM * XN_STRIDE];
+    __shared__ __attribute__((aligned(16))) u16 xn[(CIN ? CIN_ROWS : RBM) * XN_STRIDE];
     float* const xs = (float*)lds_a;
     u16* const hid = (u16*)lds_a;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     // HATT tiles never cross an utterance (the attention stage reads one utterance's keys): tile = (b, 32 frames), rows past the
@@ -330,18 +349,21 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             }
         }
     }
-    if (a.ln_g) {
+    auto ln_requests = [&]() {
+        if (a.ln_g) {
 #pragma unroll
-        for (int it = 0; it < VPL; ++it) {
-            const int c = (lane + 64 * it) * 4;
-            ln_gam[it] = c < D ? *(const f32x4*)(a.ln_g + c) : zero4;
-            ln_bet[it] = c < D ? *(const f32x4*)(a.ln_b + c) : zero4;
+            for (int it = 0; it < VPL; ++it) {
+                const int c = (lane + 64 * it) * 4;
+                ln_gam[it] = c < D ? *(const f32x4*)(a.ln_g + c) : zero4;
+                ln_bet[it] = c < D ? *(const f32x4*)(a.ln_b + c) : zero4;
+            }
         }
-    }
-    if (a.ln_mask) {
+        if (a.ln_mask) {
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) ln_keep[rr] = a.ln_mask[ln_rows[rr]] != 0;
-    }
+            for (int rr = 0; rr < RPW; ++rr) ln_keep[rr] = a.ln_mask[ln_rows[rr]] != 0;
+        }
+    };
+    if constexpr (!CIN) ln_requests();                     // (CIN: behind the conv-in stage -- at kernel entry they would be held, spilled, across it)
 
     // ================= HEAD: x = res + mask(A . Wh^T + bh) =====================================================
     if constexpr (HEAD) {
@@ -368,8 +390,9 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             constexpr int C8 = D / 8, CP = D / 2, RG = RBM / 4;
             constexpr int NPASS = (CP * RG + NT - 1) / NT;      // (channel pair, frame group) items per thread: 1 up to D = 256, 2 at D = 512
             static_assert(NPASS == 1 || (NT % CP == 0 && (CP * RG) % NT == 0), "whole passes, the same channel pair in every pass of a thread");
-            constexpr int NHALO = (DWROWS * C8 + NT - 1) / NT;
+            constexpr int NHALO = CIN ? 1 : (DWROWS * C8 + NT - 1) / NT;
             u32x4 hv[NHALO];
+            if constexpr (!CIN) {
 #pragma unroll
             for (int i = 0; i < NHALO; ++i) {               // all requests first, then the LDS stores.  UNCONDITIONAL loads (clamped address, value
                 const int id = tid + i * NT;                // selected afterwards): behind a branch each load waits out its own latency
@@ -379,14 +402,125 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 const u32x4 v = *(const u32x4*)(a.head_a + gc * D + (idc % C8) * 8);
                 hv[i] = (id < DWROWS * C8 && grow >= 0 && grow < Mlim) ? v : (u32x4){0u, 0u, 0u, 0u};
             }
+            }
             const int cp = tid < CP * RG ? tid % CP : 0;                         // channel pair (wave-uniform: CP % 64 == 0 or idle tail; the same in every pass)
-            float* const taps = (float*)(lds_a + DWROWS * D * 2);                // [D][15] as in memory, staged with 16-byte loads
+            float* const taps = (float*)(lds_a + TAPS_OFF);                      // [D][15] as in memory, staged with 16-byte loads
             constexpr int NTAP4 = (DWK * D / 4 + NT - 1) / NT;                   // 16-byte pieces of the taps per thread
             static_assert((DWK * D) % 4 == 0, "16-byte pieces of the taps");
             f32x4 tv[NTAP4];
 #pragma unroll
             for (int i = 0; i < NTAP4; ++i) tv[i] = *(const f32x4*)(a.dw_w + 4 * (tid + i * NT < DWK * D / 4 ? tid + i * NT : 0));
             const f32x2 pb = *(const f32x2*)(a.dw_b + 2 * cp), ps = *(const f32x2*)(a.dw_scale + 2 * cp), ph = *(const f32x2*)(a.dw_shift + 2 * cp);
+            if constexpr (CIN) {
+                // ================= conv-in input stage =====================================================================
+                // The halo tile is COMPUTED here: the conv-in chain of this block (attention.py:99 out-projection + residual, encoder_layer.py:62-64
+                // LN_conv with the pad mask, convolution.py:41-42 pointwise-conv-1 + GLU) on the tile's 32 + 14 halo rows -- three 16-row MFMA
+                // fragments; the 14 rows recomputed per tile cost no extra weight bytes (0.375 MB per workgroup either way) and save a launch, the
+                // [M, D] GLU round trip and the halo load's latency.  Same operations on the same values in the same order as the stand-alone conv-in
+                // chain, row by row: bit-identical (asserted against the unchained path).
+                constexpr int MF3 = CIN_ROWS / 16, RPW3 = CIN_ROWS / NW;
+                static_assert(NF2 == NW && RPW3 * NW == CIN_ROWS, "one out-proj fragment and one GLU fragment pair per wavefront, three rows per wavefront");
+                const u32x4* cwp = (const u32x4*)a.cin_w + lane;
+                u32x4 cwr[KS1];
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk) cwr[kk] = cwp[((int64_t)wave * KS1 + kk) * 64];            // weights first
+                for (int id = tid; id < CIN_ROWS * CPRW; id += NT) {                                        // the context rows (clamped), 16 bit
+                    const int r = id / CPRW, c = id % CPRW;
+                    int64_t grow = row0 - DWH + r;
+                    grow = grow < 0 ? 0 : (grow < Mlim ? grow : Mlim - 1);
+                    *(u32x4*)(xn + r * XN_STRIDE + c * 8) = *(const u32x4*)(a.cin_a + grow * D + c * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < NTAP4; ++i)
+                    if (tid + i * NT < DWK * D / 4) *(f32x4*)(taps + 4 * (tid + i * NT)) = tv[i];
+                const int ccol = wave * 16 + 4 * g;
+                const f32x4 cbb = *(const f32x4*)(a.cin_b + ccol);
+                f32x4 crs[MF3];
+#pragma unroll
+                for (int mf = 0; mf < MF3; ++mf) {
+                    int64_t gr = row0 - DWH + mf * 16 + l15;
+                    gr = gr < 0 ? 0 : (gr < Mlim ? gr : Mlim - 1);
+                    crs[mf] = *(const f32x4*)(a.cin_res + gr * D + ccol);
+                }
+                __syncthreads();
+                {
+                    f32x4 cacc[MF3][1];
+                    const int nx0[1] = {0};
+                    linear_step<HT, KS1, 1, XN_STRIDE, MF3>(xn, cwp, false, nx0, cwr, cacc, g, l15);
+#pragma unroll
+                    for (int mf = 0; mf < MF3; ++mf) {
+                        f32x4 v = cacc[mf][0] + cbb;
+                        v += crs[mf];
+                        *(f32x4*)(xs + (mf * 16 + l15) * XS_STRIDE + ccol) = v;
+                    }
+                }
+                // the GLU product's weights (value / gate fragments 2 wave, 2 wave + 1) and the row phase's operands: requested now, used after the barrier
+                const u32x4* ctp = (const u32x4*)a.cin_tw + lane;
+                constexpr int CRG = 8;                         // a ring over the 2 x KS1 fragments (all 16 at once + three row fragments: over the 128 VGPRs)
+                u32x4 ctw[CRG];
+                auto ct_ptr = [&](int pos) { return ctp + ((int64_t)(2 * wave + pos % 2) * KS1 + pos / 2) * 64; };
+#pragma unroll
+                for (int t = 0; t < CRG; ++t) ctw[t] = *ct_ptr(t);
+                f32x4 cg[VPL], cb[VPL];
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    cg[it] = c < D ? *(const f32x4*)(a.cin_ln_g + c) : zero4;
+                    cb[it] = c < D ? *(const f32x4*)(a.cin_ln_b + c) : zero4;
+                }
+                bool ckeep[RPW3];
+#pragma unroll
+                for (int rr = 0; rr < RPW3; ++rr) {
+                    int64_t gr = row0 - DWH + wave * RPW3 + rr;
+                    gr = gr < 0 ? 0 : (gr < Mlim ? gr : Mlim - 1);
+                    ckeep[rr] = a.cin_mask ? a.cin_mask[gr] != 0 : true;
+                }
+                __syncthreads();
+                {   // rows: the residual rows of THIS tile -> cin_out; LN_conv (+ pad mask) of all 48 -> the operand tile
+                    f32x4 cv[RPW3][VPL];
+#pragma unroll
+                    for (int rr = 0; rr < RPW3; ++rr) {
+                        const int r = wave * RPW3 + rr;
+                        const int64_t gr = row0 - DWH + r;
+#pragma unroll
+                        for (int it = 0; it < VPL; ++it) {
+                            const int c = (lane + 64 * it) * 4;
+                            cv[rr][it] = c < D ? *(const f32x4*)(xs + r * XS_STRIDE + c) : zero4;
+                            if (c < D && r >= DWH && r < DWH + RBM && gr < Mlim) *(f32x4*)(a.cin_out + gr * D + c) = cv[rr][it];
+                        }
+                    }
+                    rows_layernorm<RPW3, VPL, D>(cv, cg, cb, a.eps, lane);
+#pragma unroll
+                    for (int rr = 0; rr < RPW3; ++rr)
+#pragma unroll
+                        for (int it = 0; it < VPL; ++it) {
+                            const int c = (lane + 64 * it) * 4;
+                            if (c < KP) {
+                                const f32x4 o = (c < D && ckeep[rr]) ? cv[rr][it] : zero4;
+                                *(u32x2*)(xn + (wave * RPW3 + rr) * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
+                            }
+                        }
+                }
+                const f32x4 tb0 = *(const f32x4*)(a.cin_tb + (2 * wave) * 16 + 4 * g), tb1 = *(const f32x4*)(a.cin_tb + (2 * wave + 1) * 16 + 4 * g);
+                __syncthreads();                               // the operand tile is complete; every read of the f32 tile is done (the halo tile overlays it)
+                {
+                    f32x4 tacc[MF3][2];
+                    ring_step<HT, KS1, 2, CRG, XN_STRIDE, decltype(ct_ptr), MF3>(xn, 0, 2 * KS1, ct_ptr, ctw, tacc, g, l15);
+#pragma unroll
+                    for (int mf = 0; mf < MF3; ++mf) {
+                        const int r = mf * 16 + l15;
+                        const int64_t gr = row0 - DWH + r;
+                        f32x4 v0 = tacc[mf][0] + tb0;
+                        const f32x4 v1 = tacc[mf][1] + tb1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v0[q] *= sigmoidf_(v1[q]);
+                        const bool in = gr >= 0 && gr < Mlim;
+                        const u32x2 pk = in ? (u32x2){pack2<HT>(v0.x, v0.y), pack2<HT>(v0.z, v0.w)} : (u32x2){0u, 0u};
+                        if (r < DWROWS) *(u32x2*)(halo + r * D + wave * 16 + 4 * g) = pk;
+                    }
+                }
+                ln_requests();
+            } else {
 #pragma unroll
             for (int i = 0; i < NHALO; ++i) {
                 const int id = tid + i * NT;
@@ -395,6 +529,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
 #pragma unroll
             for (int i = 0; i < NTAP4; ++i)
                 if (tid + i * NT < DWK * D / 4) *(f32x4*)(taps + 4 * (tid + i * NT)) = tv[i];
+            }
             // pad columns of the xn tile (K padded to a multiple of 32)
             if constexpr (KP > D) {
                 for (int id = tid; id < RBM * (KP - D) / 2; id += NT) {
@@ -756,6 +891,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
             // alive across the whole segment -- 102 SGPRs spilled to VGPR lanes + 9 VGPRs to scratch (40 B per lane, 10 MB per launch).
             // Opaque copies of the wavefront scalars make them new values here: no spills, .private_segment_fixed_size 0, step -1.8 %.
             asm volatile("" : "+s"(wave), "+s"(np), "+s"(kh));
+            if constexpr (CIN) asm volatile("" : "+v"(lane));   // (and the lane: column offsets derived from it are otherwise kept from the first phase to the last store)
             w1p = (const u32x4*)a.s2_w1f + lane; w2p = (const u32x4*)a.s2_w2n + lane;
             seg_b1 = a.s2_b1; seg_b2 = a.s2_b2; seg_ln1_g = nullptr; seg_ln1_b = nullptr; seg_out = a.s2_out_f32; seg_alpha = a.s2_alpha;
         }
@@ -1138,13 +1274,13 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
     CFM_STAMP(7);
 }
 
-template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false, bool FSPLIT = false, bool TSPLIT = false>
+template <typename HT, int D, int FF, int HS, bool HDW, bool MID, int TS, bool TGLU, bool HATT = false, bool TVT = false, bool SEG2 = false, bool FSPLIT = false, bool TSPLIT = false, bool CIN = false>
 int launch_chain(const ChainArgs& a, hipStream_t s, const char* name, double flops) {
     // HATT: tiles do not cross utterances (B x ceil(T / 32) workgroups); FSPLIT: groups of 8 workgroups = 4 row tiles x 2 halves of FF
     const unsigned tiles = (unsigned)((a.M + RBM - 1) / RBM);
     const unsigned grid = HATT ? (unsigned)((((a.M / a.att_T) + 7) / 8) * 8 * ((a.att_T + RBM - 1) / RBM)) : (FSPLIT || TSPLIT) ? ((tiles + 3) / 4) * 8 : tiles;
     CfmProfScope prof(name, s, flops, (double)a.M * D * 8);
-    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU, HATT, TVT, SEG2, FSPLIT, TSPLIT>), dim3(grid), dim3(NT), 0, s, a);
+    CFM_LAUNCH((cfm_rowchain_kernel<HT, D, FF, HS, HDW, MID, TS, TGLU, HATT, TVT, SEG2, FSPLIT, TSPLIT, CIN>), dim3(grid), dim3(NT), 0, s, a);
     return cfm_launch_status(name);
 }
 
@@ -1188,6 +1324,13 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
                   "and (with a head) out_f32 distinct from head_res");
     ChainArgs a;
     a.psum_out = d->psum_out; a.psum_in = d->psum_in; a.psum_b2 = d->psum_b2; a.psum_alpha = d->psum_alpha;
+    const bool cin = d->cin_a != nullptr;
+    CFM_CHECK_ARG(!cin || (seg2 && dw && d->D == 256 && d->cin_w && d->cin_b && d->cin_res && d->cin_out && d->cin_ln_g && d->cin_ln_b && d->cin_tail_w && d->cin_tail_b &&
+                           d->head_res == d->cin_out && d->cin_out != d->cin_res),
+                  "cfm_rowchain: the conv-in input stage (cin_*) needs the depthwise + final + next-macaron chain at D = 256, all of its operands, head_res == cin_out "
+                  "and cin_out distinct from cin_res (halo rows of cin_res belong to other tiles)");
+    a.cin_a = (const u16*)d->cin_a; a.cin_w = (const u16*)d->cin_w; a.cin_b = d->cin_b; a.cin_res = d->cin_res; a.cin_out = d->cin_out; a.cin_ln_g = d->cin_ln_g;
+    a.cin_ln_b = d->cin_ln_b; a.cin_mask = d->cin_mask; a.cin_tw = (const u16*)d->cin_tail_w; a.cin_tb = d->cin_tail_b;
     a.x = d->x; a.head_a = (const u16*)d->head_a; a.head_w = (const u16*)d->head_w; a.head_b = d->head_b; a.head_res = d->head_res;
     a.dw_w = d->dw_w; a.dw_b = d->dw_b; a.dw_scale = d->dw_scale; a.dw_shift = d->dw_shift; a.dw_T = d->dw_T;
     a.head_mask = d->head_mask; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_mask = d->ln_mask; a.w1f = (const u16*)d->w1f; a.w2n = (const u16*)d->w2n;
@@ -1215,6 +1358,7 @@ extern "C" int cfm_rowchain(const cfm_rowchain_desc* d, cfm_stream_t stream) {
         if (att) { if (bf) return launch_chain<BF16, 256, 64, 1, false, false, 1, true, true, false>(a, s, "chain_attconvin_bf16_d256", fl); else return launch_chain<F16, 256, 64, 1, false, false, 1, true, true, false>(a, s, "chain_attconvin_f16_d256", fl); }
         if (tvt && !head && mid && tsteps == 3) { if (bf) return launch_chain<BF16, 256, 2048, 0, false, true, 3, false, false, true>(a, s, "chain_macaron_vt_bf16_d256", fl); else return launch_chain<F16, 256, 2048, 0, false, true, 3, false, false, true>(a, s, "chain_macaron_vt_f16_d256", fl); }
         if (tvt) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: transposed values only on the macaron chain");
+        if (cin && seg2 && head && dw && tail && !d->tail_glu && tsteps == 3) { if (bf) return launch_chain<BF16, 256, 2048, 1, true, true, 3, false, false, false, true, false, false, true>(a, s, "chain_convin_dwfinal_macaron_bf16_d256", fl + 2.0 * M * d->D * 3 * d->D); else return launch_chain<F16, 256, 2048, 1, true, true, 3, false, false, false, true, false, false, true>(a, s, "chain_convin_dwfinal_macaron_f16_d256", fl + 2.0 * M * d->D * 3 * d->D); }
         if (seg2 && head && dw && tail && !d->tail_glu && tsteps == 3) { if (bf) return launch_chain<BF16, 256, 2048, 1, true, true, 3, false, false, false, true>(a, s, "chain_dwfinal_macaron_bf16_d256", fl); else return launch_chain<F16, 256, 2048, 1, true, true, 3, false, false, false, true>(a, s, "chain_dwfinal_macaron_f16_d256", fl); }
         if (seg2) return cfm_fail(CFM_ERR_UNSUPPORTED, "cfm_rowchain: a second segment only on the depthwise + final chain followed by a QKV tail (D = 256)");
         if (!head && mid && tail && !d->tail_glu && tsteps == 3) { if (bf) CFM_RC(BF16, 256, 2048, 0, true, 3, false, "chain_macaron_bf16_d256"); else CFM_RC(F16, 256, 2048, 0, true, 3, false, "chain_macaron_f16_d256"); }

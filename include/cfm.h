@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFM_VERSION 301 /* 0.3.1: row chains at D = 512, cfm_rowchain_desc.psum_out / psum_in (feed-forward split over workgroup pairs), cfm_conv12_relu at C = 512. 0.3.0: row groups in the train entry points (cfm_train_group, cfm_layer_train_io.n_groups), cfm_gemm_tn_group + deferred weight gradients, cfm_encoder_train_forward / _backward (the whole stack from one host call). 0.2.3: cfm_ffn_split, cfm_layer_scratch.psum (the feed-forward split over FF for few rows). 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
+#define CFM_VERSION 302 /* 0.3.2: cfm_rowchain_desc.cin_* (the conv-in chain as the input stage of the next launch). 0.3.1: row chains at D = 512, cfm_rowchain_desc.psum_out / psum_in (feed-forward split over workgroup pairs), cfm_conv12_relu at C = 512. 0.3.0: row groups in the train entry points (cfm_train_group, cfm_layer_train_io.n_groups), cfm_gemm_tn_group + deferred weight gradients, cfm_encoder_train_forward / _backward (the whole stack from one host call). 0.2.3: cfm_ffn_split, cfm_layer_scratch.psum (the feed-forward split over FF for few rows). 0.2.2: cfm_ctc_nll_train / cfm_ctc_grad take a beta buffer (both recursions in one launch); GEMM tile ids 9-11 (K groups). 0.2.1: fused front-end (cfm_conv12_relu); attention stage of the conv-in chain (cfm_rowchain_desc.att_*, cfm_layer_scratch.vt). 0.2.0: training entry points */
 
 typedef void* cfm_stream_t;
 
@@ -298,6 +298,17 @@ typedef struct {
     const float* psum_in;
     const float* psum_b2;
     float psum_alpha;
+    /* The conv-in chain of the SAME block as the input stage of the depthwise stage (with dw_w and the second segment, D = 256): out-projection of the
+     * attention context cin_a [M,D] (16 bit) + residual cin_res -> cin_out (this tile's rows; == head_res, != cin_res), LN(cin_ln_*; rows with cin_mask == 0
+     * zeroed), pointwise-conv-1 + GLU (cin_tail_w: GLU-interleaved, fragment-major) -- computed per tile for its 32 + 14 halo rows, the GLU rows go
+     * straight to the depthwise stage (head_a is not read).  One launch per block less than conv-in chain + this chain. */
+    const void *cin_a, *cin_w;
+    const float *cin_b, *cin_res;
+    float* cin_out;
+    const float *cin_ln_g, *cin_ln_b;
+    const uint8_t* cin_mask;
+    const void* cin_tail_w;
+    const float* cin_tail_b;
     int32_t tail_pair; /* D = 512, a chain with a tail and no feed-forward: the tail's columns split over workgroup pairs (rows and LayerNorm computed by
                           both, written by the first); out_f32 must NOT alias head_res then */
 } cfm_rowchain_desc;

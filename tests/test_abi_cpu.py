@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(cfm):
     assert len(names) >= 20 and "cfm_gemm" in names and "cfm_ffn_fused" in names and "cfm_encoder_layer_forward" in names
     for n in names:
         assert hasattr(lib, n), "libconformer_gfx950.so does not export %s" % n
-    assert lib.cfm_version() == 301
+    assert lib.cfm_version() == 302
     assert isinstance(lib.cfm_last_error(), bytes)
 
 
@@ -59,7 +59,7 @@ def test_ctypes_structs_match_c_sizes(cfm, tmp_path):
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "c.c"
-    src.write_text('#include "cfm.h"\nint main(void){return CFM_VERSION == 301 ? 0 : 1;}\n')
+    src.write_text('#include "cfm.h"\nint main(void){return CFM_VERSION == 302 ? 0 : 1;}\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "c")], check=True)
 
 

@@ -863,7 +863,7 @@ def test_config5_64_streams_against_oracle(pkg, mode, split, monkeypatch):
         pkg.cfm.prof_enable(False)
         names = set(pkg.cfm.prof_table())
         pkg.cfm.prof_reset()
-        assert any(n.startswith("ffnsplit_ffn") for n in names) == split and any(n.startswith("chain_dwfinal_macaron") for n in names) == (not split), names
+        assert any(n.startswith("ffnsplit_ffn") for n in names) == split and any("dwfinal_macaron" in n for n in names) == (not split), names   # (chain_convin_dwfinal_macaron: the conv-in stage rides in that launch)
     P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
     cfg = O.Config(**CFG2)
     worst = 0.0
