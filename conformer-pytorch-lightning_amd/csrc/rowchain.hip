@@ -424,15 +424,15 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 u32x4 cwr[KS1];
 #pragma unroll
                 for (int kk = 0; kk < KS1; ++kk) cwr[kk] = cwp[((int64_t)wave * KS1 + kk) * 64];            // weights first
-                for (int id = tid; id < CIN_ROWS * CPRW; id += NT) {                                        // the context rows (clamped), 16 bit
-                    const int r = id / CPRW, c = id % CPRW;
-                    int64_t grow = row0 - DWH + r;
-                    grow = grow < 0 ? 0 : (grow < Mlim ? grow : Mlim - 1);
-                    *(u32x4*)(xn + r * XN_STRIDE + c * 8) = *(const u32x4*)(a.cin_a + grow * D + c * 8);
-                }
+                constexpr int NCTX = (CIN_ROWS * CPRW + NT - 1) / NT;                                       // the context rows (clamped), 16 bit: all requests first
+                u32x4 cxv[NCTX];
 #pragma unroll
-                for (int i = 0; i < NTAP4; ++i)
-                    if (tid + i * NT < DWK * D / 4) *(f32x4*)(taps + 4 * (tid + i * NT)) = tv[i];
+                for (int i = 0; i < NCTX; ++i) {
+                    const int id = tid + i * NT < CIN_ROWS * CPRW ? tid + i * NT : CIN_ROWS * CPRW - 1;
+                    int64_t grow = row0 - DWH + id / CPRW;
+                    grow = grow < 0 ? 0 : (grow < Mlim ? grow : Mlim - 1);
+                    cxv[i] = *(const u32x4*)(a.cin_a + grow * D + (id % CPRW) * 8);
+                }
                 const int ccol = wave * 16 + 4 * g;
                 const f32x4 cbb = *(const f32x4*)(a.cin_b + ccol);
                 f32x4 crs[MF3];
@@ -442,7 +442,32 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                     gr = gr < 0 ? 0 : (gr < Mlim ? gr : Mlim - 1);
                     crs[mf] = *(const f32x4*)(a.cin_res + gr * D + ccol);
                 }
+#pragma unroll
+                for (int i = 0; i < NCTX; ++i) {
+                    const int id = tid + i * NT;
+                    if (id < CIN_ROWS * CPRW) *(u32x4*)(xn + (id / CPRW) * XN_STRIDE + (id % CPRW) * 8) = cxv[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NTAP4; ++i)
+                    if (tid + i * NT < DWK * D / 4) *(f32x4*)(taps + 4 * (tid + i * NT)) = tv[i];
                 __syncthreads();
+                // the row phase's operands (LN_conv parameters, pad-mask bytes): requested behind the first barrier (it waits for every outstanding request: only the
+                // context tile and the residual rows are in front of it), they land during the product
+                f32x4 cg[VPL], cb[VPL];
+#pragma unroll
+                for (int it = 0; it < VPL; ++it) {
+                    const int c = (lane + 64 * it) * 4;
+                    cg[it] = c < D ? *(const f32x4*)(a.cin_ln_g + c) : zero4;
+                    cb[it] = c < D ? *(const f32x4*)(a.cin_ln_b + c) : zero4;
+                }
+                unsigned ckb[RPW3];                            // the raw bytes: a comparison here would wait for them in front of the product
+#pragma unroll
+                for (int rr = 0; rr < RPW3; ++rr) {
+                    int64_t gr = row0 - DWH + wave * RPW3 + rr;
+                    gr = gr < 0 ? 0 : (gr < Mlim ? gr : Mlim - 1);
+                    ckb[rr] = 1u;
+                    if (a.cin_mask) ckb[rr] = a.cin_mask[gr];
+                }
                 {
                     f32x4 cacc[MF3][1];
                     const int nx0[1] = {0};
@@ -454,6 +479,7 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                         *(f32x4*)(xs + (mf * 16 + l15) * XS_STRIDE + ccol) = v;
                     }
                 }
+                CFM_STAMP(14);
                 // the GLU product's weights (value / gate fragments 2 wave, 2 wave + 1) and the row phase's operands: requested now, used after the barrier
                 const u32x4* ctp = (const u32x4*)a.cin_tw + lane;
                 constexpr int CRG = 8;                         // a ring over the 2 x KS1 fragments (all 16 at once + three row fragments: over the 128 VGPRs)
@@ -461,20 +487,6 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                 auto ct_ptr = [&](int pos) { return ctp + ((int64_t)(2 * wave + pos % 2) * KS1 + pos / 2) * 64; };
 #pragma unroll
                 for (int t = 0; t < CRG; ++t) ctw[t] = *ct_ptr(t);
-                f32x4 cg[VPL], cb[VPL];
-#pragma unroll
-                for (int it = 0; it < VPL; ++it) {
-                    const int c = (lane + 64 * it) * 4;
-                    cg[it] = c < D ? *(const f32x4*)(a.cin_ln_g + c) : zero4;
-                    cb[it] = c < D ? *(const f32x4*)(a.cin_ln_b + c) : zero4;
-                }
-                bool ckeep[RPW3];
-#pragma unroll
-                for (int rr = 0; rr < RPW3; ++rr) {
-                    int64_t gr = row0 - DWH + wave * RPW3 + rr;
-                    gr = gr < 0 ? 0 : (gr < Mlim ? gr : Mlim - 1);
-                    ckeep[rr] = a.cin_mask ? a.cin_mask[gr] != 0 : true;
-                }
                 __syncthreads();
                 {   // rows: the residual rows of THIS tile -> cin_out; LN_conv (+ pad mask) of all 48 -> the operand tile
                     f32x4 cv[RPW3][VPL];
@@ -496,13 +508,14 @@ __global__ __launch_bounds__(NT) void cfm_rowchain_kernel(const ChainArgs a) {
                         for (int it = 0; it < VPL; ++it) {
                             const int c = (lane + 64 * it) * 4;
                             if (c < KP) {
-                                const f32x4 o = (c < D && ckeep[rr]) ? cv[rr][it] : zero4;
+                                const f32x4 o = (c < D && ckb[rr] != 0u) ? cv[rr][it] : zero4;
                                 *(u32x2*)(xn + (wave * RPW3 + rr) * XN_STRIDE + c) = (u32x2){pack2<HT>(o.x, o.y), pack2<HT>(o.z, o.w)};
                             }
                         }
                 }
                 const f32x4 tb0 = *(const f32x4*)(a.cin_tb + (2 * wave) * 16 + 4 * g), tb1 = *(const f32x4*)(a.cin_tb + (2 * wave + 1) * 16 + 4 * g);
                 __syncthreads();                               // the operand tile is complete; every read of the f32 tile is done (the halo tile overlays it)
+                CFM_STAMP(15);
                 {
                     f32x4 tacc[MF3][2];
                     ring_step<HT, KS1, 2, CRG, XN_STRIDE, decltype(ct_ptr), MF3>(xn, 0, 2 * KS1, ct_ptr, ctw, tacc, g, l15);

@@ -42,6 +42,11 @@ static void run_seg2(const char* name, cfm_rowchain_desc d, int M) {
                                    "FFN phase 2 + y tile", "post norms (LN_final)", "LN_ffm (next block)", "FFN_m phase 1", "FFN_m phase 2 + y tile",
                                    "post norms (LN_mha)", "tail GEMM (q|k|v) + stores"};
     printf("%-10s M=%5d grid=%4d  %7.2f us/launch (back-to-back)\n", name, M, grid, ms * 1000.f / reps);
+    if (d.cin_a) {
+        double s14 = 0, s15 = 0, s1 = 0;
+        for (int b = 0; b < nb; ++b) { s14 += (double)(h[b * 16 + 14] - h[b * 16 + 0]); s15 += (double)(h[b * 16 + 15] - h[b * 16 + 14]); s1 += (double)(h[b * 16 + 1] - h[b * 16 + 15]); }
+        printf("    conv-in stage: context tile + out-projection %9.0f cycles, rows + LN_conv %9.0f, GLU product + depthwise stage %9.0f (inside the first line below)\n", s14 / nb, s15 / nb, s1 / nb);
+    }
     double tot = 0;
     for (int i = 1; i < 12; ++i) {
         double sum = 0; long long mx = 0;
@@ -296,6 +301,12 @@ int main(int argc, char** argv) {
         ch.s2_ln_g = vec; ch.s2_ln_b = vec; ch.s2_w1f = w1f; ch.s2_w2n = w2f; ch.s2_b1 = vec; ch.s2_b2 = vec; ch.s2_out_f32 = out; ch.s2_alpha = 0.5f;
         ch.ln2_g = vec; ch.ln2_b = vec; ch.tail_w = wt; ch.tail_b = vec; ch.tail_out = t16; ch.tail_N = 768;
         run_seg2("dw-final+macaron", ch, 7968);
+        cfm_rowchain_desc cm = ch;                        // + this block's conv-in chain as the input stage (CIN): stamps 14 = out-proj done, 15 = LN_conv done
+        float* x2 = (float*)dalloc((size_t)MMAX * D * 4, 0);
+        void* wg = dalloc((size_t)2 * D * D * 2, 0x11);
+        cm.cin_a = a16; cm.cin_w = wh; cm.cin_b = vec; cm.cin_res = res; cm.cin_out = x2; cm.cin_ln_g = vec; cm.cin_ln_b = vec; cm.cin_mask = mask;
+        cm.cin_tail_w = wg; cm.cin_tail_b = vec; cm.head_res = x2;
+        run_seg2("conv-in+dw-final+macaron", cm, 7968);
     }
 
     {   // cold weights: rotate 12 weight sets (as 12 layers do), so every launch first-touches its weights on all 8 XCDs
