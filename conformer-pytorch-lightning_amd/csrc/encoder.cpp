@@ -1,4 +1,5 @@
-// encoder.cpp -- composite: one conformer block enqueued from C++ (3 launches with the row-local chains of rowchain.hip when the attention rides in the
+// encoder.cpp -- composite: one conformer block enqueued from C++ (2 launches when consecutive blocks are chained: attention, then the conv-in chain + depthwise + final chain
+// + the next block's macaron chain in one; 3 launches with the row-local chains of rowchain.hip when the attention rides in the
 // conv-in chain, 4 otherwise, 17 on the general path; no host sync).
 //
 // Mirrors reference src/encoder_layer.py:49-71:

@@ -7,7 +7,7 @@ encoder.py also runs unchanged on top of the drop-in modules of this directory. 
 
 * masks are built on the device from the lengths (one launch each; the subsampled padding mask directly as
   ``6 + 4 j < len``), bit-identical to the reference's arange / slicing / python row loop;
-* each block is one C call (3 launches on the row-chain path with consecutive blocks chained, 4 without, 17 on the general one); consecutive blocks hand over the already-normalised macaron-FFN operand
+* each block is one C call (2 launches on the row-chain path with consecutive blocks chained -- attention, then conv-in + depthwise + final + the next block's macaron chain --, 4 without, 17 on the general one); consecutive blocks hand over the already-normalised macaron-FFN operand
   (norm_final of block i and norm_ff_macaron of block i+1 are chained in registers);
 * the batch path does not materialise the per-layer cat(k,v) cache that the reference builds and discards.
 """
