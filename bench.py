@@ -578,6 +578,10 @@ def main():
                     wbytes = 2 * (4 * D * FF + D * D + 3 * D * D)
                 if name.startswith("chain_convin_dwfinal_macaron"):   # ... + the out-projection and pointwise-conv-1 of the conv-in stage
                     wbytes = 2 * (4 * D * FF + D * D + 3 * D * D + D * D + 2 * D * D)
+                    roofline["note"] = ("this launch = conv-in chain (on the depthwise halo: 32 + 14 rows per tile, FLOPs counted once) + depthwise + final chain of block i + "
+                                        "macaron chain of block i+1; the conv-in stage is a latency chain of 3 GFLOP, so `frac` is lower than that of the narrower launch it "
+                                        "replaced (0.25 at 58-60 us) while the step is 0.5-1.5 % faster (DESIGN 4, 'two launches per block'); config.whole_encoder_frac_of_mfma_peak "
+                                        "is the fraction over the whole step")
                 floor_us = wbytes / 64.0 / 2.4e9 * 1e6
                 roofline["weight_stream"] = {"bytes_per_cu_per_launch": wbytes, "path_peak": "64 B/clk/CU", "floor_us": round(floor_us, 2),
                                              "frac": round(floor_us / (avg_ms * 1e3), 4)}
