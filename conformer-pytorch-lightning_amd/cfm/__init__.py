@@ -240,6 +240,8 @@ def lib():
         L.cfm_ffn_split_supported.argtypes = [c_i32, c_i32]
         L.cfm_attention_bwd_force_general.argtypes = [c_i32]
         L.cfm_attention_bwd_force_general.restype = None
+        L.cfm_set_cin_merge.argtypes = [c_i32]
+        L.cfm_set_cin_merge.restype = c_i32
         L.cfm_dwconv_bn_train_bwd_acc.argtypes = [c_p, c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]
         L.cfm_layernorm_bwd_fused.argtypes = [ctypes.POINTER(LnBwdDesc), c_p]
         L.cfm_conv12_relu.argtypes = [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]

@@ -44,6 +44,11 @@ int ffn_fused(const Ctx& c, const float* x, const float* ln_g, const float* ln_b
     return cfm_ffn_fused(&d, c.st);
 }
 
+int& cin_merge_flag() {
+    static int flag = getenv("CFM_CIN_MERGE") == nullptr || atoi(getenv("CFM_CIN_MERGE")) != 0;
+    return flag;
+}
+
 #define CFM_TRY(expr)            \
     do {                         \
         int rc__ = (expr);       \
@@ -51,6 +56,12 @@ int ffn_fused(const Ctx& c, const float* x, const float* ln_g, const float* ln_b
     } while (0)
 
 }  // namespace
+
+extern "C" int32_t cfm_set_cin_merge(int32_t on) {
+    const int prev = cin_merge_flag();
+    cin_merge_flag() = on != 0;
+    return prev;
+}
 
 extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_layer_scratch* s, const cfm_layer_io* io,
                                          const float* x_in, float* x_out, int xn_ready, const float* next_g,
@@ -218,8 +229,7 @@ extern "C" int cfm_encoder_layer_forward(const cfm_layer_weights* w, const cfm_l
         if (pair) { ci.tail_pair = 1; ci.out_f32 = s->psum + (int64_t)2 * M * D; }   // the pair's other workgroup still reads x_out: the rows go to the third slab
         // chained blocks at D = 256: the conv-in chain runs as the input stage of the next launch (depthwise + final chain + the next block's macaron chain) on
         // the tile's 32 + 14 halo rows -- no launch of its own (cfm.h cfm_rowchain_desc.cin_*)
-        static const bool cin_ok = getenv("CFM_CIN_MERGE") == nullptr || atoi(getenv("CFM_CIN_MERGE")) != 0;
-        const bool cin = cin_ok && !merged && !pair && !ffsplit && io->next_w && io->next_x_out && D == 256 && FF == 2048 && io->ktaps == 15 && !io->causal_conv &&
+        const bool cin = cin_merge_flag() != 0 && !merged && !pair && !ffsplit && io->next_w && io->next_x_out && D == 256 && FF == 2048 && io->ktaps == 15 && !io->causal_conv &&
                          !io->after_out;
         if (!merged && !cin) CFM_TRY(cfm_rowchain(&ci, stream));
         // the depthwise conv runs inside the final chain's input stage (15 taps); otherwise on its own

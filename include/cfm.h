@@ -692,6 +692,10 @@ int cfm_attention_bwd_group(const cfm_attn_bwd_desc* descs, int32_t n, cfm_strea
  * they lie in memory, transposed operands read with ds_read_b64_tr_b16, next tile prefetched) -- bit-identical to the general ones, which
  * this switch forces (tests). */
 void cfm_attention_bwd_force_general(int32_t on);
+/* Chained blocks (cfm_layer_io.next_w): run the conv-in chain as the input stage of the block's last launch (two launches per block; the default, also
+ * switched off by CFM_CIN_MERGE=0 in the environment at first use) or as a launch of its own (three).  The results are bit-identical; bench.py times the
+ * narrower launch beside the merged one with it.  Returns the previous setting. */
+int32_t cfm_set_cin_merge(int32_t on);
 
 /* Feed-forward for FEW rows, the hidden dimension split across workgroups (csrc/ffnsplit.hip; feedforward.py:17-20 inside encoder_layer.py:55-58,
  * 67-70 when B*T' is a few hundred rows: a streaming step, BASELINE config 5).  One launch = the row-reduce input stage + (by mode) nothing, a

@@ -945,6 +945,35 @@ def test_general_path_matches_chain_path_including_after_norm(pkg):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_conv_in_stage_merged_or_not_is_the_same_function(pkg, mode):
+    """cfm_set_cin_merge: chained blocks with the conv-in chain as the input stage of the block's last launch (two launches per block, the default) and
+    as a launch of its own (three) -- bit-identical, with the route read from the kernel table; utterances shorter than the depthwise halo included."""
+    cfm = pkg.cfm
+    cfm.set_precision(mode)
+    enc = build_encoder(pkg, CFG2 | dict(encoder_num_layers=3), 95)
+    x = dev(synth.fbank(96, 4, 470))
+    lens = torch.tensor([470, 333, 40, 9], dtype=torch.int32, device=DEV)
+
+    def run():
+        cfm.prof_reset(); cfm.prof_enable(True)
+        with torch.no_grad():
+            y, m = enc(x, lens)
+        torch.cuda.synchronize(); cfm.prof_enable(False)
+        return y, set(cfm.prof_table().keys())
+
+    prev = cfm.lib().cfm_set_cin_merge(1)
+    try:
+        y2, k2 = run()
+        cfm.lib().cfm_set_cin_merge(0)
+        y3, k3 = run()
+    finally:
+        cfm.lib().cfm_set_cin_merge(prev)
+    assert any(n.startswith("chain_convin_dwfinal_macaron") for n in k2), sorted(k2)
+    assert any(n.startswith("chain_dwfinal_macaron") for n in k3) and not any(n.startswith("chain_convin_dwfinal") for n in k3), sorted(k3)
+    assert torch.isfinite(y2).all() and torch.equal(y2, y3), relerr(y2, y3)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
 def test_chained_blocks_are_bit_identical_to_one_launch_per_chain(pkg, mode):
     """encoder_layer.CHAIN_BLOCKS: the final chain of block i also runs the macaron chain of block i+1 on rows that stay in registers
     (rowchain.hip SEG2).  Same operations in the same order on the same values -- bit-identical to separate launches; ragged batch,
