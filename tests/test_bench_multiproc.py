@@ -64,3 +64,23 @@ def test_bench_refuses_more_gpus_than_devices():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "HIP device(s) visible" in out.stderr
+
+
+def test_traffic_lookup_tells_the_chain_instances_apart():
+    """bench.pick_traffic: the PMC table is keyed by demangled kernel names; the merged launch (conv-in stage inside), the narrower chained launch and the
+    stand-alone conv-in chain are instances of ONE template and must not be mistaken for each other."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = {"cfm_rowchain_kernel<BF16, 256, 2048, 1, true, true, 3, false, false, false, true, false, false, true>": 97.0e6,
+         "cfm_rowchain_kernel<BF16, 256, 2048, 1, true, true, 3, false, false, false, true, false, false, false>": 60.0e6,
+         "cfm_rowchain_kernel<BF16, 256, 64, 1, false, false, 1, true, false, false, false, false, false, false>": 24.0e6,
+         "cfm_rowchain_kernel<BF16, 256, 2048, 0, false, true, 3, false, false, false, false, false, false, false>": 42.0e6,
+         "cfm_attn2_kernel<BF16, 1, false, false>": 20.0e6}
+    assert bench.pick_traffic(t, "chain_convin_dwfinal_macaron_bf16_d256", 256) == 97.0e6
+    assert bench.pick_traffic(t, "chain_dwfinal_macaron_bf16_d256", 256) == 60.0e6
+    assert bench.pick_traffic(t, "chain_convin_bf16_d256", 256) == 24.0e6
+    assert bench.pick_traffic(t, "chain_macaron_bf16_d256", 256) == 42.0e6
+    assert bench.pick_traffic(t, "attn2_rel_bf16", 256) == 20.0e6
+    assert bench.pick_traffic(t, "chain_convin_dwfinal_macaron_bf16_d256", 512) is None
