@@ -267,12 +267,13 @@ __device__ __forceinline__ u32x4 load_row8(const void* base, unsigned off) {
     }
 }
 
-template <typename HT, int PMODE, bool MFULL, bool KVF32>
+template <typename HT, int PMODE, bool MFULL, bool KVF32, int NWQ = 4>
 __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block_x) {
+    constexpr int QTL = 16 * NWQ, NTH = 64 * NWQ, NST = SK * 8 / NTH;   // queries and threads per workgroup (NWQ wavefronts x 16 queries), staging pieces per thread
     __shared__ u32x4 Kl[SK * 8];
     __shared__ u32x4 Pl[PMODE == 2 ? SK * 8 : 1];
     __shared__ __attribute__((aligned(16))) u16 Vl[SK * V2STR];
-    __shared__ __attribute__((aligned(16))) uint8_t Ml[(MFULL ? QT : 1) * MLSTR];
+    __shared__ __attribute__((aligned(16))) uint8_t Ml[(MFULL ? QTL : 1) * MLSTR];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,12 +281,12 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block_x)
     // XCD-aware block order (1-D grid).  Workgroups go round-robin over the 8 XCDs, so the q-tiles of ONE (b, h) pair are given
     // ids 8 apart: they then share an L2 and K/V are fetched from memory once instead of once per q-tile (measured 41 MB of HBM
     // traffic per launch for 16 MB of compulsory bytes).  Groups of 8 pairs; padding blocks of the last group exit.
-    const int nq = (a.Tq + QT - 1) / QT;
+    const int nq = (a.Tq + QTL - 1) / QTL;
     const int grp = block_x / (8 * nq), rem = block_x % (8 * nq);
     const int pair = grp * 8 + rem % 8;
     if (pair >= a.B * a.H) return;                         // uniform, before any barrier
     const int b = pair / a.H, h = pair % a.H;
-    const int q0 = (rem / 8) * QT;
+    const int q0 = (rem / 8) * QTL;
     const int qi = q0 + wave * 16 + l15;
     const int qc = qi < a.Tq ? qi : a.Tq - 1;
     constexpr int dk = 64;
@@ -306,7 +307,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block_x)
         }
         if constexpr (PMODE == 1) praw[kk] = *(const u32x4*)((const u16*)a.p + (int64_t)b * a.p_sb + h * dk + d0);
     }
-    u32x4 kr[8], vr[8], pr[PMODE == 2 ? 8 : 1];
+    u32x4 kr[NST], vr[NST], pr[PMODE == 2 ? NST : 1];
     // (b, h) bases are wave-uniform (scalar 64-bit arithmetic); what varies per thread is a 32-bit element offset -- the host checks
     // that Tk * stride fits.  The first version did three 64-bit VALU multiply-adds per load: 66 of them per thread.
     using kv_t = std::conditional_t<KVF32, float, u16>;
@@ -316,8 +317,8 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block_x)
     const unsigned kst = (unsigned)a.k_st, vst = (unsigned)a.v_st, pst = (unsigned)a.p_st;
     auto stage_load = [&](int ks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int id = i * 256 + tid;
+        for (int i = 0; i < NST; ++i) {
+            const int id = i * NTH + tid;
             const int key = id >> 3, c = id & 7;
             const int kj = ks + key;
             const bool ok = kj < a.Tk;
@@ -386,18 +387,18 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block_x)
                 const int kj = ks + tid;
                 uint8_t mv = kj < a.Tk ? 1 : 0;
                 if (mv && a.mask) mv = a.mask[(int64_t)b * a.m_sb + kj] != 0;
-                Ml[tid] = mv;
+                if (tid < SK) Ml[tid] = mv;
             } else {
 #pragma unroll 4
-                for (int i = 0; i < QT; ++i) {
-                    const int kj = ks + tid;
+                for (int i = 0; i < QTL; ++i) {
+                    const int kj = ks + (tid < SK ? tid : SK - 1);
                     const int qr = q0 + i < a.Tq ? q0 + i : a.Tq - 1;
-                    Ml[i * MLSTR + tid] = kj < a.Tk ? (a.mask[(int64_t)b * a.m_sb + (int64_t)qr * a.m_sq + kj] != 0) : 0;
+                    if (tid < SK) Ml[i * MLSTR + tid] = kj < a.Tk ? (a.mask[(int64_t)b * a.m_sb + (int64_t)qr * a.m_sq + kj] != 0) : 0;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int id = i * 256 + tid;
+            for (int i = 0; i < NST; ++i) {
+                const int id = i * NTH + tid;
                 const int key = id >> 3, c = id & 7;
                 Kl[k_swz(key, c)] = kr[i];
                 *(u32x4*)(Vl + key * V2STR + c * 8) = vr[i];
@@ -506,6 +507,13 @@ __global__ __launch_bounds__(256, 2) void cfm_attn2_kernel(const AttnArgs a) {  
     attn2_body<HT, PMODE, MFULL, KVF32>(a, (int)blockIdx.x);
 }
 
+// The same body with 8 wavefronts = 128 queries per workgroup (one workgroup per CU, still 2 wavefronts per SIMD): half the workgroups to dispatch and
+// the keys / values of a (b, h) pair staged twice instead of four times at T = 249 (launch_attn2 picks it when it still fills the chip)
+template <typename HT, int PMODE>
+__global__ __launch_bounds__(512, 1) void cfm_attn2_q128_kernel(const AttnArgs a) {
+    attn2_body<HT, PMODE, false, false, 8>(a, (int)blockIdx.x);
+}
+
 // Several attention problems in ONE launch (cfm_attention_group): the micro-batches of a training window have different lengths T_g, so each
 // is its own (B_g, H, T_g) problem with its own mask and strides -- but none of them fills the chip (8 x 4 x 4 tiles at a micro-batch of 8
 // utterances), and as separate launches they ran one after the other.  Workgroup b belongs to the problem with first[i] <= b < first[i+1].
@@ -536,6 +544,17 @@ int launch_attn2(const AttnArgs& a, hipStream_t s, const char* name) {
     const int pmode = a.p ? (a.p_st == 0 ? 1 : 2) : 0;
     const bool mfull = a.mask && a.m_sq != 0;
     const bool kvf32 = a.kv_dtype == CFM_F32;
+    // 128 queries per workgroup when that still gives every CU a workgroup (config 2 / config 4: 128 (b, h) pairs x 2 tiles = 256): half the workgroups to
+    // dispatch, keys / values staged twice instead of four times per pair -- measured 1.217 -> 1.201 ms per config-2 step (A/B on one box, CFM_ATTN_Q128=0 for the
+    // 64-query form); per query the same arithmetic in the same order: bit-identical
+    static const bool q128 = getenv("CFM_ATTN_Q128") == nullptr || atoi(getenv("CFM_ATTN_Q128")) != 0;
+    if (q128 && !mfull && !kvf32 && pmode != 2 && a.Tq > 64 && ((pairs + 7) / 8) * 8 * ((a.Tq + 127) / 128) >= 192) {
+        const int nq8 = (a.Tq + 127) / 128;
+        const dim3 grid8((unsigned)(((pairs + 7) / 8) * 8 * nq8)), block8(512);
+        if (pmode == 0) CFM_LAUNCH((cfm_attn2_q128_kernel<HT, 0>), grid8, block8, 0, s, a);
+        else CFM_LAUNCH((cfm_attn2_q128_kernel<HT, 1>), grid8, block8, 0, s, a);
+        return cfm_launch_status(name);
+    }
 #define CFM_A2(PM)                                                                                       \
     do {                                                                                                 \
         if (mfull && kvf32) CFM_LAUNCH((cfm_attn2_kernel<HT, PM, true, true>), grid, block, 0, s, a);      \
